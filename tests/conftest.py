@@ -1,0 +1,24 @@
+import os
+import sys
+
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden_kats():
+    import json
+    with open(os.path.join(os.path.dirname(__file__), "golden", "kats.json")) as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope="session")
+def golden_arrays():
+    import numpy as np
+    return np.load(os.path.join(os.path.dirname(__file__), "golden", "arrays.npz"))
