@@ -1,0 +1,88 @@
+"""ctypes binding of the C ABI in include/biolib_amd.h (biolib_amd/lib/libbiolib_amd.so).
+
+There is no CPU fallback: if the HIP library is missing or no gfx950 device is visible,
+loading / context creation raises.  (Build it with `python -c "import __graft_entry__ as g; g.build()"`
+or `make -C biolib_amd/csrc`.)
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libbiolib_amd.so")
+
+BL_OK, BL_ERR_INVALID, BL_ERR_HIP, BL_ERR_OOM, BL_ERR_CAPACITY, BL_ERR_NO_DEVICE, BL_ERR_INTERNAL = 0, -1, -2, -3, -4, -5, -6
+FLAG_CANONICAL, FLAG_DROP_LAST, FLAG_SYNC = 1, 2, 4
+
+# every symbol include/biolib_amd.h declares (tests check the library exports exactly these)
+SYMBOLS = [
+    "bl_last_error", "bl_version", "bl_device_count", "bl_ctx_create", "bl_ctx_destroy", "bl_ctx_set_stream", "bl_ctx_sync",
+    "bl_batch_upload", "bl_batch_from_device", "bl_batch_synth", "bl_batch_destroy", "bl_batch_n_bases", "bl_batch_n_seqs",
+    "bl_batch_device_bases", "bl_batch_download", "bl_scan_kmers", "bl_scan_minimizers", "bl_scan_super_kmers", "bl_scan_syncmers",
+    "bl_ctx_last_scan_ms", "bl_device_alloc", "bl_device_free", "bl_copy_to_host", "bl_hash64_u64",
+]
+
+
+class BiolibError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"biolib_amd error {code}: {msg}")
+        self.code = code
+
+
+class Result(C.Structure):
+    _fields_ = [("count", C.c_uint64), ("xor_value", C.c_uint64), ("xor_hash", C.c_uint64), ("xor_pos", C.c_uint64),
+                ("aux", C.c_uint64), ("status", C.c_int32), ("reserved", C.c_int32)]
+
+    def as_dict(self):
+        return dict(count=int(self.count), xor_value=int(self.xor_value), xor_hash=int(self.xor_hash), xor_pos=int(self.xor_pos),
+                    aux=int(self.aux), status=int(self.status))
+
+
+_lib = None
+
+
+def lib():
+    """Load the HIP library; raises if it has not been built (no silent fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: build the HIP extension first (__graft_entry__.build()); "
+                          "biolib_amd has no CPU fallback")
+    L = C.CDLL(LIB_PATH)
+    vp, u64, u32 = C.c_void_p, C.c_uint64, C.c_uint32
+    L.bl_last_error.restype = C.c_char_p
+    L.bl_version.restype = C.c_int
+    L.bl_device_count.argtypes = [C.POINTER(C.c_int)]
+    L.bl_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
+    L.bl_ctx_destroy.argtypes = [vp]
+    L.bl_ctx_set_stream.argtypes = [vp, vp]
+    L.bl_ctx_sync.argtypes = [vp]
+    L.bl_batch_upload.argtypes = [vp, vp, u64, vp, u64, C.POINTER(vp)]
+    L.bl_batch_from_device.argtypes = [vp, vp, u64, vp, u64, u64, C.POINTER(vp)]
+    L.bl_batch_synth.argtypes = [vp, u64, u64, u64, C.POINTER(vp)]
+    L.bl_batch_destroy.argtypes = [vp]
+    L.bl_batch_n_bases.restype = u64
+    L.bl_batch_n_bases.argtypes = [vp]
+    L.bl_batch_n_seqs.restype = u64
+    L.bl_batch_n_seqs.argtypes = [vp]
+    L.bl_batch_device_bases.restype = vp
+    L.bl_batch_device_bases.argtypes = [vp]
+    L.bl_batch_download.argtypes = [vp, u64, u64, vp]
+    L.bl_scan_kmers.argtypes = [vp, vp, u64, u64, u32, u64, u32, vp, vp, vp, C.POINTER(Result)]
+    L.bl_scan_minimizers.argtypes = [vp, vp, u64, u64, u32, u32, u64, u32, vp, vp, vp, u64, C.POINTER(Result)]
+    L.bl_scan_super_kmers.argtypes = [vp, vp, u64, u64, u32, u32, u64, u32, vp, vp, vp, vp, vp, u64, C.POINTER(Result)]
+    L.bl_scan_syncmers.argtypes = [vp, vp, u64, u64, u32, u32, u32, u32, u64, u32, vp, u64, C.POINTER(Result)]
+    L.bl_ctx_last_scan_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    L.bl_device_alloc.argtypes = [vp, u64, C.POINTER(vp)]
+    L.bl_device_free.argtypes = [vp, vp]
+    L.bl_copy_to_host.argtypes = [vp, vp, vp, u64]
+    L.bl_hash64_u64.restype = u64
+    L.bl_hash64_u64.argtypes = [u64, u64]
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != BL_OK:
+        raise BiolibError(rc, lib().bl_last_error().decode(errors="replace"))
+    return rc

@@ -1,0 +1,557 @@
+// bl_capi.hip — implementation of the C ABI declared in include/biolib_amd.h (host side).
+// Contexts own a HIP stream and a small device workspace; batches own (or borrow) the base buffer
+// plus a 1-bit-per-base sequence-start vector; scans enqueue  memset -> tile kernel -> digest fold
+// -> async copy of the 72-byte result into a pinned slot, all on the context's stream.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/biolib_amd.h"
+#include "bl_launch.hpp"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg)
+{
+    g_err = msg;
+    return code;
+}
+
+#define BL_HIP(call)                                                                                       \
+    do {                                                                                                   \
+        hipError_t e_ = (call);                                                                            \
+        if (e_ != hipSuccess)                                                                              \
+            return fail(e_ == hipErrorOutOfMemory ? BL_ERR_OOM : BL_ERR_HIP,                               \
+                        std::string(#call) + ": " + hipGetErrorString(e_));                                \
+    } while (0)
+
+constexpr int RESULT_WORDS = 16;   // device/pinned result record (u64 words)
+constexpr int RING = 64;           // pinned result slots
+constexpr size_t HDR_BYTES = 256;  // ticket, error
+constexpr size_t SHARD_BYTES = (size_t)bl::NSHARD * 8 * sizeof(unsigned long long);
+
+struct Pending {
+    bl_result* user;
+    int slot;
+    uint64_t capacity;
+    bool has_capacity;
+};
+
+}  // namespace
+
+struct bl_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    // workspace: [hdr 256 B][shards][result][status ...]
+    unsigned char* ws = nullptr;
+    size_t ws_bytes = 0;
+    uint64_t* last_buf = nullptr;  // super-k-mer scratch
+    size_t last_cap = 0;
+    unsigned long long* pinned = nullptr;  // RING * RESULT_WORDS
+    int next_slot = 0;
+    std::vector<Pending> pending;
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    bool timed = false;
+
+    unsigned int* ticket() const { return reinterpret_cast<unsigned int*>(ws); }
+    unsigned int* error() const { return reinterpret_cast<unsigned int*>(ws) + 1; }
+    unsigned long long* shards() const { return reinterpret_cast<unsigned long long*>(ws + HDR_BYTES); }
+    unsigned long long* result() const { return reinterpret_cast<unsigned long long*>(ws + HDR_BYTES + SHARD_BYTES); }
+    unsigned long long* status() const
+    {
+        return reinterpret_cast<unsigned long long*>(ws + HDR_BYTES + SHARD_BYTES + RESULT_WORDS * sizeof(unsigned long long));
+    }
+    static size_t fixed_bytes() { return HDR_BYTES + SHARD_BYTES + RESULT_WORDS * sizeof(unsigned long long); }
+};
+
+struct bl_batch {
+    bl_ctx* ctx = nullptr;
+    uint8_t* bases = nullptr;
+    bool owns_bases = false;
+    uint32_t* start_bits = nullptr;  // nullptr: single sequence
+    uint64_t n_bases = 0;
+    uint64_t n_seqs = 0;
+};
+
+namespace {
+
+int ensure_workspace(bl_ctx* c, size_t n_tiles)
+{
+    const size_t need = bl_ctx::fixed_bytes() + (n_tiles + 64) * sizeof(unsigned long long);
+    if (need <= c->ws_bytes) return BL_OK;
+    // the old workspace may still be in use by queued work on the stream
+    BL_HIP(hipStreamSynchronize(c->stream));
+    if (c->ws) BL_HIP(hipFree(c->ws));
+    c->ws = nullptr;
+    c->ws_bytes = 0;
+    const size_t bytes = need + need / 4;
+    BL_HIP(hipMalloc(&c->ws, bytes));
+    c->ws_bytes = bytes;
+    return BL_OK;
+}
+
+int flush_pending(bl_ctx* c)
+{
+    for (const Pending& p : c->pending) {
+        const unsigned long long* r = c->pinned + (size_t)p.slot * RESULT_WORDS;
+        bl_result out;
+        std::memset(&out, 0, sizeof(out));
+        out.count = r[0];
+        out.xor_value = r[1];
+        out.xor_hash = r[2];
+        out.xor_pos = r[3];
+        out.aux = r[4];
+        out.status = BL_OK;
+        if (r[8] != 0) out.status = BL_ERR_INTERNAL;
+        else if (p.has_capacity && r[0] > p.capacity) out.status = BL_ERR_CAPACITY;
+        if (p.user) *p.user = out;
+    }
+    c->pending.clear();
+    return BL_OK;
+}
+
+int sync_ctx(bl_ctx* c)
+{
+    BL_HIP(hipStreamSynchronize(c->stream));
+    return flush_pending(c);
+}
+
+// memset header + shards + result + status for n_tiles, record the start event
+int begin_scan(bl_ctx* c, size_t n_tiles)
+{
+    BL_HIP(hipSetDevice(c->device));
+    int rc = ensure_workspace(c, n_tiles);
+    if (rc != BL_OK) return rc;
+    BL_HIP(hipEventRecord(c->ev_start, c->stream));
+    BL_HIP(hipMemsetAsync(c->ws, 0, bl_ctx::fixed_bytes() + n_tiles * sizeof(unsigned long long), c->stream));
+    return BL_OK;
+}
+
+// fold the shards, copy the result record to a pinned slot, register the user's bl_result
+int end_scan(bl_ctx* c, uint32_t add_mask, bl_result* user, bool has_capacity, uint64_t capacity, uint32_t flags,
+             bool already_folded = false)
+{
+    if (!already_folded) {
+        hipError_t e = bl::launch_reduce_shards(c->shards(), c->result(), add_mask, c->error(), c->stream);
+        if (e != hipSuccess) return fail(BL_ERR_HIP, std::string("reduce_shards: ") + hipGetErrorString(e));
+    }
+    if ((int)c->pending.size() >= RING) {
+        int rc = sync_ctx(c);
+        if (rc != BL_OK) return rc;
+    }
+    const int slot = c->next_slot;
+    c->next_slot = (c->next_slot + 1) % RING;
+    BL_HIP(hipMemcpyAsync(c->pinned + (size_t)slot * RESULT_WORDS, c->result(), RESULT_WORDS * sizeof(unsigned long long),
+                          hipMemcpyDeviceToHost, c->stream));
+    BL_HIP(hipEventRecord(c->ev_stop, c->stream));
+    c->timed = true;
+    c->pending.push_back(Pending{user, slot, capacity, has_capacity});
+    if (flags & BL_FLAG_SYNC) {
+        int rc = sync_ctx(c);
+        if (rc != BL_OK) return rc;
+        if (user && user->status != BL_OK)
+            return fail(user->status, user->status == BL_ERR_CAPACITY ? "output capacity too small for the records found"
+                                                                       : "inter-tile protocol timed out");
+    }
+    return BL_OK;
+}
+
+int zero_result(bl_ctx* c, bl_result* user, uint32_t flags)
+{
+    if (user) std::memset(user, 0, sizeof(*user));
+    (void)c;
+    (void)flags;
+    return BL_OK;
+}
+
+int check_range(const bl_batch* b, uint64_t first, uint64_t n, uint64_t& end)
+{
+    if (first > b->n_bases) return fail(BL_ERR_INVALID, "range starts beyond the batch");
+    end = n == 0 ? b->n_bases : first + n;
+    if (end > b->n_bases) end = b->n_bases;
+    if (end - first > (1ull << 31)) return fail(BL_ERR_INVALID, "a scan range may hold at most 2^31 positions; split it");
+    return BL_OK;
+}
+
+int make_start_bits(bl_ctx* c, bl_batch* b, const uint64_t* offsets, uint64_t n_seqs, uint64_t read_len)
+{
+    const uint64_t n_words = (b->n_bases + 31) / 32 + 4;
+    if (!offsets && (read_len == 0 || read_len >= b->n_bases)) {
+        b->start_bits = nullptr;  // one sequence starting at 0
+        b->n_seqs = b->n_bases ? 1 : 0;
+        return BL_OK;
+    }
+    BL_HIP(hipMalloc(&b->start_bits, n_words * sizeof(uint32_t)));
+    BL_HIP(hipMemsetAsync(b->start_bits, 0, n_words * sizeof(uint32_t), c->stream));
+    if (offsets) {
+        for (uint64_t q = 0; q < n_seqs; ++q)
+            if (offsets[q] > offsets[q + 1]) return fail(BL_ERR_INVALID, "offsets must be non-decreasing");
+        if (offsets[0] != 0 || offsets[n_seqs] != b->n_bases) return fail(BL_ERR_INVALID, "offsets must span [0, n_bases]");
+        uint64_t* d_off = nullptr;
+        BL_HIP(hipMalloc(&d_off, (n_seqs + 1) * sizeof(uint64_t)));
+        BL_HIP(hipMemcpyAsync(d_off, offsets, (n_seqs + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+        hipError_t e = bl::launch_start_bits_offsets(b->start_bits, d_off, n_seqs, b->n_bases, c->stream);
+        if (e != hipSuccess) return fail(BL_ERR_HIP, std::string("start_bits_offsets: ") + hipGetErrorString(e));
+        BL_HIP(hipStreamSynchronize(c->stream));
+        BL_HIP(hipFree(d_off));
+        b->n_seqs = n_seqs;
+    } else {
+        hipError_t e = bl::launch_start_bits_fixed(b->start_bits, n_words, b->n_bases, read_len, c->stream);
+        if (e != hipSuccess) return fail(BL_ERR_HIP, std::string("start_bits_fixed: ") + hipGetErrorString(e));
+        b->n_seqs = (b->n_bases + read_len - 1) / read_len;
+    }
+    return BL_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* bl_last_error(void) { return g_err.c_str(); }
+int bl_version(void) { return BL_VERSION; }
+
+int bl_device_count(int* n)
+{
+    if (!n) return fail(BL_ERR_INVALID, "n is NULL");
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess) { *n = 0; return fail(BL_ERR_NO_DEVICE, std::string("hipGetDeviceCount: ") + hipGetErrorString(e)); }
+    *n = c;
+    return BL_OK;
+}
+
+int bl_ctx_create(int device, bl_ctx** out)
+{
+    if (!out) return fail(BL_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n == 0) return fail(BL_ERR_NO_DEVICE, "no HIP device visible: this library has no CPU fallback");
+    if (device < 0 || device >= n) return fail(BL_ERR_INVALID, "device index out of range");
+    hipDeviceProp_t prop;
+    BL_HIP(hipGetDeviceProperties(&prop, device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(BL_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", kernels are built for gfx950 (MI355X) only");
+    BL_HIP(hipSetDevice(device));
+    bl_ctx* c = new (std::nothrow) bl_ctx();
+    if (!c) return fail(BL_ERR_OOM, "host allocation failed");
+    c->device = device;
+    hipError_t e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreate(&c->ev_start);
+    if (e == hipSuccess) e = hipEventCreate(&c->ev_stop);
+    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&c->pinned), (size_t)RING * RESULT_WORDS * sizeof(unsigned long long), hipHostMallocDefault);
+    if (e != hipSuccess) {
+        bl_ctx_destroy(c);
+        return fail(BL_ERR_HIP, std::string("context setup: ") + hipGetErrorString(e));
+    }
+    c->stream = c->own_stream;
+    int rc = ensure_workspace(c, 1 << 16);
+    if (rc != BL_OK) { bl_ctx_destroy(c); return rc; }
+    *out = c;
+    return BL_OK;
+}
+
+int bl_ctx_destroy(bl_ctx* c)
+{
+    if (!c) return BL_OK;
+    hipSetDevice(c->device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    if (c->ws) hipFree(c->ws);
+    if (c->last_buf) hipFree(c->last_buf);
+    if (c->pinned) hipHostFree(c->pinned);
+    if (c->ev_start) hipEventDestroy(c->ev_start);
+    if (c->ev_stop) hipEventDestroy(c->ev_stop);
+    if (c->own_stream) hipStreamDestroy(c->own_stream);
+    delete c;
+    return BL_OK;
+}
+
+int bl_ctx_set_stream(bl_ctx* c, void* hip_stream)
+{
+    if (!c) return fail(BL_ERR_INVALID, "ctx is NULL");
+    int rc = sync_ctx(c);
+    if (rc != BL_OK) return rc;
+    c->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->own_stream;
+    return BL_OK;
+}
+
+int bl_ctx_sync(bl_ctx* c)
+{
+    if (!c) return fail(BL_ERR_INVALID, "ctx is NULL");
+    return sync_ctx(c);
+}
+
+int bl_ctx_last_scan_ms(bl_ctx* c, float* ms)
+{
+    if (!c || !ms) return fail(BL_ERR_INVALID, "NULL argument");
+    if (!c->timed) return fail(BL_ERR_INVALID, "no scan has been issued on this context");
+    BL_HIP(hipEventSynchronize(c->ev_stop));
+    BL_HIP(hipEventElapsedTime(ms, c->ev_start, c->ev_stop));
+    return BL_OK;
+}
+
+// ---------------------------------------------------------------------------------------- batches
+
+static int new_batch(bl_ctx* c, uint64_t n_bases, bl_batch** out, bl_batch*& b)
+{
+    if (!c || !out) return fail(BL_ERR_INVALID, "NULL argument");
+    *out = nullptr;
+    BL_HIP(hipSetDevice(c->device));
+    b = new (std::nothrow) bl_batch();
+    if (!b) return fail(BL_ERR_OOM, "host allocation failed");
+    b->ctx = c;
+    b->n_bases = n_bases;
+    return BL_OK;
+}
+
+int bl_batch_upload(bl_ctx* c, const char* bases, uint64_t n_bases, const uint64_t* offsets, uint64_t n_seqs, bl_batch** out)
+{
+    bl_batch* b = nullptr;
+    int rc = new_batch(c, n_bases, out, b);
+    if (rc != BL_OK) return rc;
+    if (n_bases && !bases) { delete b; return fail(BL_ERR_INVALID, "bases is NULL"); }
+    hipError_t e = hipMalloc(&b->bases, n_bases + 64);
+    if (e != hipSuccess) { delete b; return fail(BL_ERR_OOM, std::string("hipMalloc(bases): ") + hipGetErrorString(e)); }
+    b->owns_bases = true;
+    e = hipMemsetAsync(b->bases + (n_bases & ~15ull), 0, 64 + (n_bases & 15ull), c->stream);
+    if (e == hipSuccess && n_bases) e = hipMemcpyAsync(b->bases, bases, n_bases, hipMemcpyHostToDevice, c->stream);
+    if (e != hipSuccess) { bl_batch_destroy(b); return fail(BL_ERR_HIP, std::string("upload: ") + hipGetErrorString(e)); }
+    rc = make_start_bits(c, b, offsets, n_seqs, 0);
+    if (rc == BL_OK) {
+        e = hipStreamSynchronize(c->stream);  // the host buffer may go away after we return
+        if (e != hipSuccess) rc = fail(BL_ERR_HIP, std::string("upload sync: ") + hipGetErrorString(e));
+    }
+    if (rc != BL_OK) { bl_batch_destroy(b); return rc; }
+    *out = b;
+    return BL_OK;
+}
+
+int bl_batch_from_device(bl_ctx* c, const void* d_bases, uint64_t n_bases, const uint64_t* offsets, uint64_t n_seqs, uint64_t read_len,
+                         bl_batch** out)
+{
+    bl_batch* b = nullptr;
+    int rc = new_batch(c, n_bases, out, b);
+    if (rc != BL_OK) return rc;
+    if ((n_bases && !d_bases) || (reinterpret_cast<uintptr_t>(d_bases) & 15)) {
+        delete b;
+        return fail(BL_ERR_INVALID, "d_bases must be a non-NULL, 16-byte aligned device pointer");
+    }
+    b->bases = const_cast<uint8_t*>(static_cast<const uint8_t*>(d_bases));
+    b->owns_bases = false;
+    rc = make_start_bits(c, b, offsets, n_seqs, read_len);
+    if (rc != BL_OK) { bl_batch_destroy(b); return rc; }
+    *out = b;
+    return BL_OK;
+}
+
+int bl_batch_synth(bl_ctx* c, uint64_t seed, uint64_t n_bases, uint64_t read_len, bl_batch** out)
+{
+    bl_batch* b = nullptr;
+    int rc = new_batch(c, n_bases, out, b);
+    if (rc != BL_OK) return rc;
+    hipError_t e = hipMalloc(&b->bases, n_bases + 64);
+    if (e != hipSuccess) { delete b; return fail(BL_ERR_OOM, std::string("hipMalloc(bases): ") + hipGetErrorString(e)); }
+    b->owns_bases = true;
+    e = hipMemsetAsync(b->bases + (n_bases & ~15ull), 0, 64 + (n_bases & 15ull), c->stream);
+    if (e == hipSuccess) e = bl::launch_synth(b->bases, 0, n_bases, seed, c->stream);
+    if (e != hipSuccess) { bl_batch_destroy(b); return fail(BL_ERR_HIP, std::string("synth: ") + hipGetErrorString(e)); }
+    rc = make_start_bits(c, b, nullptr, 0, read_len);
+    if (rc != BL_OK) { bl_batch_destroy(b); return rc; }
+    *out = b;
+    return BL_OK;
+}
+
+int bl_batch_destroy(bl_batch* b)
+{
+    if (!b) return BL_OK;
+    if (b->ctx) {
+        hipSetDevice(b->ctx->device);
+        hipStreamSynchronize(b->ctx->stream);
+    }
+    if (b->owns_bases && b->bases) hipFree(b->bases);
+    if (b->start_bits) hipFree(b->start_bits);
+    delete b;
+    return BL_OK;
+}
+
+uint64_t bl_batch_n_bases(const bl_batch* b) { return b ? b->n_bases : 0; }
+uint64_t bl_batch_n_seqs(const bl_batch* b) { return b ? b->n_seqs : 0; }
+const void* bl_batch_device_bases(const bl_batch* b) { return b ? b->bases : nullptr; }
+
+int bl_batch_download(bl_batch* b, uint64_t first, uint64_t n, char* out)
+{
+    if (!b || (!out && n)) return fail(BL_ERR_INVALID, "NULL argument");
+    if (first + n > b->n_bases) return fail(BL_ERR_INVALID, "range beyond the batch");
+    BL_HIP(hipSetDevice(b->ctx->device));
+    BL_HIP(hipStreamSynchronize(b->ctx->stream));
+    if (n) BL_HIP(hipMemcpy(out, b->bases + first, n, hipMemcpyDeviceToHost));
+    return BL_OK;
+}
+
+// ---------------------------------------------------------------------------------------- scans
+
+int bl_scan_kmers(bl_ctx* c, const bl_batch* b, uint64_t first, uint64_t n, uint32_t k, uint64_t seed, uint32_t flags,
+                  uint64_t* d_values, uint64_t* d_hashes, uint8_t* d_valid, bl_result* result)
+{
+    if (!c || !b || b->ctx != c) return fail(BL_ERR_INVALID, "ctx/batch is NULL or the batch belongs to another context");
+    if (k < 1 || k > bl::MAX_UNIT) return fail(BL_ERR_INVALID, "k must be in [1, 32] (KmerType = uint64_t)");
+    uint64_t end;
+    int rc = check_range(b, first, n, end);
+    if (rc != BL_OK) return rc;
+    if (end <= first) return zero_result(c, result, flags);
+    bl::KmerParams p{};
+    p.bases = b->bases;
+    p.n_bases = (int64_t)b->n_bases;
+    p.start_bits = b->start_bits;
+    p.first = (int64_t)first;
+    p.end = (int64_t)end;
+    p.origin = bl::align_down16((int64_t)first);
+    p.n_tiles = (int32_t)(((int64_t)end - 1 - p.origin) / bl::H + 1);
+    p.unit = (int32_t)k;
+    p.seed = (uint32_t)seed;  // hash.hpp:16,50: the seed is truncated to 32 bits
+    p.canonical = (flags & BL_FLAG_CANONICAL) ? 1 : 0;
+    p.drop_last = (flags & BL_FLAG_DROP_LAST) ? 1 : 0;
+    p.out_value = d_values;
+    p.out_hash = d_hashes;
+    p.out_valid = d_valid;
+    rc = begin_scan(c, 0);
+    if (rc != BL_OK) return rc;
+    p.shards = c->shards();
+    const int n_blocks = p.n_tiles < 256 * 8 ? p.n_tiles : 256 * 8;
+    hipError_t e = bl::launch_kmers(p, n_blocks, c->stream);
+    if (e != hipSuccess) return fail(BL_ERR_HIP, std::string("kmer_kernel: ") + hipGetErrorString(e));
+    return end_scan(c, /*add_mask: count, sum*/ (1u << 0) | (1u << 3), result, false, 0, flags);
+}
+
+static int scan_windows(int mode, bl_ctx* c, const bl_batch* b, uint64_t first, uint64_t n, uint32_t unit, uint32_t w, uint64_t seed,
+                        uint32_t flags, bl::ScanParams& p, uint64_t capacity, bl_result* result)
+{
+    if (!c || !b || b->ctx != c) return fail(BL_ERR_INVALID, "ctx/batch is NULL or the batch belongs to another context");
+    if (unit < 1 || unit > bl::MAX_UNIT) return fail(BL_ERR_INVALID, "hashed unit length must be in [1, 32]");
+    if (w < 1 || w > bl::MAX_W) return fail(BL_ERR_INVALID, "window must be in [1, 64]");
+    uint64_t end;
+    int rc = check_range(b, first, n, end);
+    if (rc != BL_OK) return rc;
+    if (end <= first) return zero_result(c, result, flags);
+    p.bases = b->bases;
+    p.n_bases = (int64_t)b->n_bases;
+    p.start_bits = b->start_bits;
+    bl::plan_scan(mode, (int64_t)first, (int64_t)end, (int)w, p);
+    p.unit = (int32_t)unit;
+    p.w = (int32_t)w;
+    p.seed = (uint32_t)seed;
+    p.canonical = (flags & BL_FLAG_CANONICAL) ? 1 : 0;
+    p.drop_last = (flags & BL_FLAG_DROP_LAST) ? 1 : 0;
+    p.capacity = capacity;
+    rc = begin_scan(c, (size_t)p.n_tiles);
+    if (rc != BL_OK) return rc;
+    p.status = c->status();
+    p.ticket = c->ticket();
+    p.shards = c->shards();
+    p.error = c->error();
+    hipError_t e = bl::launch_scan(mode, p, c->stream);
+    if (e != hipSuccess) return fail(BL_ERR_HIP, std::string("scan_kernel: ") + hipGetErrorString(e));
+    return BL_OK;
+}
+
+int bl_scan_minimizers(bl_ctx* c, const bl_batch* b, uint64_t first, uint64_t n, uint32_t unit, uint32_t w, uint64_t seed, uint32_t flags,
+                       uint64_t* d_values, uint64_t* d_positions, uint64_t* d_hashes, uint64_t capacity, bl_result* result)
+{
+    bl::ScanParams p{};
+    p.out_value = d_values;
+    p.out_pos = d_positions;
+    p.out_hash = d_hashes;
+    const bool wants = d_values || d_positions || d_hashes;
+    int rc = scan_windows(bl::MODE_MINIMIZER, c, b, first, n, unit, w, seed, flags, p, wants ? capacity : 0, result);
+    if (rc != BL_OK || p.n_tiles == 0) return rc;
+    return end_scan(c, 1u << 0, result, wants, capacity, flags);
+}
+
+int bl_scan_super_kmers(bl_ctx* c, const bl_batch* b, uint64_t first, uint64_t n, uint32_t k, uint32_t m, uint64_t seed, uint32_t flags,
+                        uint64_t* d_minimizers, uint64_t* d_first_pos, uint8_t* d_mm_pos, uint8_t* d_sizes, uint64_t* d_hashes,
+                        uint64_t capacity, bl_result* result)
+{
+    if (m < 1 || k < m) return fail(BL_ERR_INVALID, "need 1 <= m <= k");
+    if (d_sizes && !d_first_pos) return fail(BL_ERR_INVALID, "d_first_pos is required when d_sizes is requested");
+    if (!c) return fail(BL_ERR_INVALID, "ctx is NULL");
+    bl::ScanParams p{};
+    p.out_value = d_minimizers;
+    p.out_first = d_first_pos;
+    p.out_mmpos = d_mm_pos;
+    p.out_hash = d_hashes;
+    const bool wants = d_minimizers || d_first_pos || d_mm_pos || d_sizes || d_hashes;
+    if (d_sizes && capacity) {
+        if (c->last_cap < capacity) {
+            BL_HIP(hipStreamSynchronize(c->stream));
+            if (c->last_buf) BL_HIP(hipFree(c->last_buf));
+            c->last_buf = nullptr;
+            c->last_cap = 0;
+            BL_HIP(hipMalloc(&c->last_buf, capacity * sizeof(uint64_t)));
+            c->last_cap = capacity;
+        }
+        p.out_last = c->last_buf;
+    }
+    int rc = scan_windows(bl::MODE_SUPERKMER, c, b, first, n, m, k - m + 1, seed, flags, p, wants ? capacity : 0, result);
+    if (rc != BL_OK || p.n_tiles == 0) return rc;
+    // fold first so that result[0] (the record count) is final on the device, then derive the sizes
+    hipError_t e = bl::launch_reduce_shards(c->shards(), c->result(), (1u << 0) | (1u << 4), c->error(), c->stream);
+    if (e != hipSuccess) return fail(BL_ERR_HIP, std::string("reduce_shards: ") + hipGetErrorString(e));
+    if (d_sizes && capacity) {
+        e = bl::launch_superkmer_size(d_first_pos, c->last_buf, d_sizes, c->result(), capacity, c->stream);
+        if (e != hipSuccess) return fail(BL_ERR_HIP, std::string("superkmer_size: ") + hipGetErrorString(e));
+    }
+    return end_scan(c, (1u << 0) | (1u << 4), result, wants, capacity, flags, /*already_folded=*/true);
+}
+
+int bl_scan_syncmers(bl_ctx* c, const bl_batch* b, uint64_t first, uint64_t n, uint32_t k, uint32_t s, uint32_t start_offset,
+                     uint32_t end_offset, uint64_t seed, uint32_t flags, uint64_t* d_positions, uint64_t capacity, bl_result* result)
+{
+    if (s < 1 || k < s || k > bl::MAX_UNIT) return fail(BL_ERR_INVALID, "need 1 <= s <= k <= 32");
+    bl::ScanParams p{};
+    p.out_pos = d_positions;
+    p.soff = (int32_t)start_offset;
+    p.eoff = (int32_t)end_offset;
+    int rc = scan_windows(bl::MODE_SYNCMER, c, b, first, n, s, k - s + 1, seed, flags, p, d_positions ? capacity : 0, result);
+    if (rc != BL_OK || p.n_tiles == 0) return rc;
+    return end_scan(c, 1u << 0, result, d_positions != nullptr, capacity, flags);
+}
+
+// ---------------------------------------------------------------------------------------- helpers
+
+int bl_device_alloc(bl_ctx* c, uint64_t bytes, void** d_ptr)
+{
+    if (!c || !d_ptr) return fail(BL_ERR_INVALID, "NULL argument");
+    BL_HIP(hipSetDevice(c->device));
+    *d_ptr = nullptr;
+    hipError_t e = hipMalloc(d_ptr, bytes ? bytes : 16);
+    if (e != hipSuccess) return fail(BL_ERR_OOM, std::string("hipMalloc: ") + hipGetErrorString(e));
+    return BL_OK;
+}
+
+int bl_device_free(bl_ctx* c, void* d_ptr)
+{
+    if (!c) return fail(BL_ERR_INVALID, "ctx is NULL");
+    BL_HIP(hipSetDevice(c->device));
+    BL_HIP(hipStreamSynchronize(c->stream));
+    if (d_ptr) BL_HIP(hipFree(d_ptr));
+    return BL_OK;
+}
+
+int bl_copy_to_host(bl_ctx* c, void* dst, const void* d_src, uint64_t bytes)
+{
+    if (!c || (bytes && (!dst || !d_src))) return fail(BL_ERR_INVALID, "NULL argument");
+    BL_HIP(hipSetDevice(c->device));
+    int rc = sync_ctx(c);
+    if (rc != BL_OK) return rc;
+    if (bytes) BL_HIP(hipMemcpy(dst, d_src, bytes, hipMemcpyDeviceToHost));
+    return BL_OK;
+}
+
+uint64_t bl_hash64_u64(uint64_t value, uint64_t seed) { return bl::murmur64(value, (uint32_t)seed); }
+
+}  // extern "C"

@@ -1,0 +1,305 @@
+// bl_scan_core.hpp — the per-thread building blocks of the fused k-mer / minimizer scan.
+//
+// Everything here is written once and compiled two ways:
+//   * by hipcc for gfx950 (bl_kernels.hip): BL_DEV = __device__ __forceinline__
+//   * by a host compiler for the CPU emulation harness under tests/emu/ (BL_CPU_EMU), where
+//     the same phase functions are run thread-by-thread under AddressSanitizer.  The harness
+//     is test infrastructure; the product path is the HIP build only.
+//
+// Reference semantics reproduced (file:line in /root/reference):
+//   constants.hpp:12-21            ASCII -> 2-bit code table (encode16)
+//   kmer_view.hpp:162-170,190-199  mask/shift, rolling forward / reverse-complement registers
+//   hash.hpp:50-59 + bundled/MurmurHash3.cpp:263-341  hash64 of an 8-byte key, 32-bit seed
+//   minimizer_view.hpp:283,374     strict '<'  => leftmost minimum wins ties
+//   kmer_view.hpp:266-283          syncmer predicate (rightmost tie when the reverse strand is canonical)
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__) && !defined(BL_CPU_EMU)
+#define BL_DEV __host__ __device__ __forceinline__
+#define BL_UNROLL _Pragma("unroll")
+#else
+#define BL_DEV static inline
+#define BL_UNROLL
+#endif
+
+namespace bl {
+
+constexpr int TPB = 256;            // threads per workgroup (4 wave64)
+constexpr int S = 16;               // window/unit start positions owned by one thread (= one 16-byte load)
+constexpr int H = TPB * S;          // positions hashed per tile
+constexpr int NCHUNK = H / 16 + 8;  // 16-base chunks staged per tile (halo of up to 128 bases)
+constexpr int MAX_UNIT = 32;        // KmerType = uint64_t only
+constexpr int MAX_W = 64;
+constexpr int NSHARD = 256;         // digest accumulator shards (one 64-byte line each)
+
+enum ScanMode { MODE_MINIMIZER = 0, MODE_SUPERKMER = 1, MODE_SYNCMER = 2 };
+
+struct ScanParams {
+    const uint8_t* bases;        // ASCII, 1 byte per base, 16-byte aligned
+    int64_t n_bases;
+    const uint32_t* start_bits;  // bit p set <=> p is the first base of a sequence (nullptr: one sequence)
+    int64_t win_first, win_end;  // only windows whose first base lies in [win_first, win_end) are reported
+    int64_t origin;              // first hashed position of tile 0 (multiple of 16, may be negative)
+    int32_t n_tiles;
+    int32_t stride;              // owned positions per tile (multiple of 16, <= H - w)
+    int32_t unit, w;
+    uint32_t seed;
+    int32_t canonical;
+    int32_t soff, eoff;          // syncmer offsets
+    int32_t drop_last;           // syncmer / k-mer scans: skip the k-mer that ends a sequence (quirk Q1)
+    // outputs (device pointers, nullable)
+    uint64_t* out_value;
+    uint64_t* out_pos;
+    uint64_t* out_hash;
+    uint64_t* out_first;         // super-k-mer: position of the first k-mer of the group
+    uint8_t* out_mmpos;          // super-k-mer: minimizer offset inside the first k-mer
+    uint64_t* out_last;          // super-k-mer: position of the last k-mer of the group (scratch)
+    uint64_t capacity;           // records the output arrays can hold
+    // inter-tile ordered compaction
+    unsigned long long* status;  // one word per tile: [63:62] flag, [61:31] ends, [30:0] starts
+    unsigned int* ticket;        // dynamic tile id
+    unsigned long long* shards;  // [NSHARD][8] digest accumulators
+    unsigned int* error;         // set non-zero on protocol timeout
+};
+
+// Tile plan shared by the C ABI (bl_capi.hip) and the emulation harness: which positions tile 0
+// starts at, how many positions a tile owns and how many tiles cover the range [first, end).
+BL_DEV int64_t align_down16(int64_t x) { return x >= 0 ? (x & ~15LL) : -(((-x) + 15) & ~15LL); }
+
+BL_DEV void plan_scan(int mode, int64_t first, int64_t end, int w, ScanParams& p)
+{
+    p.win_first = first;
+    p.win_end = end;
+    p.stride = H - 16 * ((w + 15) / 16);
+    // minimizer modes: the owner of position i decides window i+1, so tile 0 starts one position early
+    p.origin = align_down16(mode == MODE_SYNCMER ? first : first - 1);
+    p.n_tiles = end > first ? (int32_t)((end - 1 - p.origin) / p.stride + 1) : 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// MurmurHash3_x64_128 of one 8-byte little-endian key, low 64 bits (h1).  Closed form of
+// bundled/MurmurHash3.cpp:263-341 for len == 8: nblocks = 0, tail case 8 builds k1 = key.
+BL_DEV uint64_t rotl64(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
+
+BL_DEV uint64_t fmix64(uint64_t k)
+{
+    k ^= k >> 33;
+    k *= 0xff51afd7ed558ccdULL;
+    k ^= k >> 33;
+    k *= 0xc4ceb9fe1a85ec53ULL;
+    k ^= k >> 33;
+    return k;
+}
+
+BL_DEV uint64_t murmur64(uint64_t key, uint32_t seed)
+{
+    uint64_t k1 = key * 0x87c37b91114253d5ULL;
+    k1 = rotl64(k1, 31);
+    k1 *= 0x4cf5ad432745937fULL;
+    uint64_t h1 = (uint64_t)seed ^ k1;
+    uint64_t h2 = (uint64_t)seed;
+    h1 ^= 8; h2 ^= 8;
+    h1 += h2; h2 += h1;
+    h1 = fmix64(h1); h2 = fmix64(h2);
+    return h1 + h2;
+}
+
+// ------------------------------------------------------------------------------------------------
+// 16 ASCII bytes (4 little-endian dwords, first base in byte 0 of d[0]) ->
+//   code : 2 bits per base, FIRST base in the most significant pair (kmer_view.hpp:194 order)
+//   bad  : bit b set <=> base b is not one of ACGTUacgtu (constants.hpp:12-21 maps those to 4)
+BL_DEV uint32_t byte_perm(uint32_t hi, uint32_t lo, uint32_t sel)
+{
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(BL_CPU_EMU)
+    return __builtin_amdgcn_perm(hi, lo, sel);
+#else
+    uint64_t both = ((uint64_t)hi << 32) | lo;
+    uint32_t r = 0;
+    for (int i = 0; i < 4; ++i) {
+        uint32_t s = (sel >> (8 * i)) & 0xff;
+        uint32_t byte = s < 8 ? (uint32_t)((both >> (8 * s)) & 0xff) : 0;  // selectors >= 8 never used here
+        r |= byte << (8 * i);
+    }
+    return r;
+#endif
+}
+
+BL_DEV void encode4(uint32_t d, uint32_t& code8, uint32_t& bad4)
+{
+    // per byte: x = (c >> 1) & 3; x ^= x >> 1   -> A/a 0, C/c 1, G/g 2, T/t/U/u 3
+    uint32_t x = (d >> 1) & 0x03030303u;
+    x ^= (x >> 1) & 0x01010101u;
+    // validity: rebuild the lowercase letter the code stands for and compare with (c | 0x20);
+    // 'u' (0x75) differs from 't' (0x74) in bit 0 only, which is forgiven where code == 3
+    const uint32_t lut = 0x74676361u;  // bytes 0..3 = 'a','c','g','t'
+    uint32_t expect = byte_perm(lut, lut, x);
+    uint32_t diff = (d | 0x20202020u) ^ expect;
+    diff &= ~((x & (x >> 1)) & 0x01010101u);
+    uint32_t nz = (((diff & 0x7f7f7f7fu) + 0x7f7f7f7fu) | diff) & 0x80808080u;  // bit 7 of each non-zero byte
+    bad4 = ((nz >> 7) * 0x00204081u >> 21) & 0xfu;  // gather bits 0,8,16,24 -> bits 0..3 (byte 0 -> bit 0)
+    // gather the four 2-bit codes, byte 0 (first base) most significant
+    code8 = (x * 0x40100401u) >> 24;
+}
+
+BL_DEV void encode16(const uint32_t d[4], uint32_t& code, uint32_t& bad)
+{
+    uint32_t c0, c1, c2, c3, b0, b1, b2, b3;
+    encode4(d[0], c0, b0);
+    encode4(d[1], c1, b1);
+    encode4(d[2], c2, b2);
+    encode4(d[3], c3, b3);
+    code = (c0 << 24) | (c1 << 16) | (c2 << 8) | c3;
+    bad = b0 | (b1 << 4) | (b2 << 8) | (b3 << 12);
+}
+
+// reverse the order of the 32 two-bit pairs of x
+BL_DEV uint64_t pairrev64(uint64_t x)
+{
+    uint64_t r = __builtin_bitreverse64(x);
+    return ((r >> 1) & 0x5555555555555555ULL) | ((r & 0x5555555555555555ULL) << 1);
+}
+
+// ------------------------------------------------------------------------------------------------
+// The rolling state of kmer_view.hpp:190-199 for one thread, started from packed codes instead of
+// a warm-up loop.  c0:c1:c2 are the codes of the thread's 48 bases (big-endian pairs).
+struct Roller {
+    uint64_t fwd, rc, mask;
+    uint32_t next16;  // the 16 bases following the first unit-1, big-endian
+    int shift;
+};
+
+BL_DEV void roller_start(Roller& r, uint32_t c0, uint32_t c1, uint32_t c2, int unit)
+{
+    const uint64_t A = ((uint64_t)c0 << 32) | c1;  // bases 0..31
+    const uint64_t B = ((uint64_t)c1 << 32) | c2;  // bases 16..47
+    const int pre = unit - 1;                      // bases already inside the registers
+    r.mask = unit == 32 ? ~0ULL : ((1ULL << (2 * unit)) - 1);
+    r.shift = 2 * pre;
+    if (pre == 0) {
+        r.fwd = 0;
+        r.rc = 0;
+    } else {
+        r.fwd = A >> (64 - 2 * pre);
+        // reference state after `pre` bases: latest base at `shift`, older ones 2 bits lower each
+        uint64_t little = pairrev64(r.fwd) >> (64 - 2 * pre);        // base i at bit 2i
+        little ^= (pre == 32) ? ~0ULL : ((1ULL << (2 * pre)) - 1);   // complement (3 ^ c)
+        r.rc = little << 2;
+    }
+    r.next16 = pre < 16 ? (uint32_t)((A << (2 * pre)) >> 32) : (uint32_t)((B << (2 * (pre - 16))) >> 32);
+}
+
+BL_DEV void roller_step(Roller& r, int s)  // s = 0..15, compile-time after unrolling
+{
+    const uint64_t c = (r.next16 >> (30 - 2 * s)) & 3u;
+    r.fwd = ((r.fwd << 2) | c) & r.mask;                 // kmer_view.hpp:194
+    r.rc = (r.rc >> 2) | ((3ULL ^ c) << r.shift);        // kmer_view.hpp:195
+}
+
+// unit starting at tile-relative base `pos`, straight from the staged codes (used when a record is
+// materialised; not on the per-base path)
+BL_DEV uint64_t extract_unit(const uint32_t* codes, int pos, int unit, int canonical)
+{
+    const int ch = pos >> 4, off = pos & 15;
+    const uint64_t A = ((uint64_t)codes[ch] << 32) | codes[ch + 1];
+    const uint64_t B = ((uint64_t)codes[ch + 1] << 32) | codes[ch + 2];
+    // 96 bits of pairs starting at chunk ch; take `unit` pairs from pair offset `off`
+    uint64_t top = (A << (2 * off)) | (off ? (B << 32 >> (64 - 2 * off)) : 0);  // 32 bases from `off`
+    uint64_t fwd = unit == 32 ? top : (top >> (64 - 2 * unit));
+    if (!canonical) return fwd;
+    uint64_t rc = pairrev64(fwd) >> (64 - 2 * unit);
+    rc ^= unit == 32 ? ~0ULL : ((1ULL << (2 * unit)) - 1);
+    return rc < fwd ? rc : fwd;  // numeric min, kmer_view.hpp:196
+}
+
+// ------------------------------------------------------------------------------------------------
+// 128-bit bit-vectors for the validity masks (bit i = tile-relative position i0 + i)
+struct Bits128 {
+    uint64_t lo, hi;
+};
+BL_DEV Bits128 b128_shr(Bits128 a, int n)  // 0 <= n < 128
+{
+    Bits128 r;
+    if (n == 0) return a;
+    if (n >= 64) {
+        r.lo = a.hi >> (n - 64);
+        r.hi = 0;
+    } else {
+        r.lo = (a.lo >> n) | (a.hi << (64 - n));
+        r.hi = a.hi >> n;
+    }
+    return r;
+}
+BL_DEV Bits128 b128_and(Bits128 a, Bits128 b) { return Bits128{a.lo & b.lo, a.hi & b.hi}; }
+
+// bit i of result = AND of bits i .. i+len-1 of m   (len >= 1)
+BL_DEV Bits128 and_run(Bits128 m, int len)
+{
+    Bits128 r = m;
+    int have = 1;
+    while (have < len) {
+        int step = have < len - have ? have : len - have;
+        r = b128_and(r, b128_shr(r, step));
+        have += step;
+    }
+    return r;
+}
+
+// Window validity for the S+1 windows starting at the thread's positions 0..S:
+// a window of `span` bases starting at i is valid iff all its bases are good and no base except
+// the first is a sequence start.  good/start: bit i = base i0 + i.
+BL_DEV uint32_t window_valid_mask(Bits128 good, Bits128 start, int span)
+{
+    // link[i] = good[i] && !start[i+1]
+    Bits128 ns = b128_shr(start, 1);
+    Bits128 link{good.lo & ~ns.lo, good.hi & ~ns.hi};
+    Bits128 v = b128_shr(good, span - 1);
+    if (span > 1) v = b128_and(v, and_run(link, span - 1));
+    return (uint32_t)(v.lo & ((1u << (S + 1)) - 1));
+}
+
+// ------------------------------------------------------------------------------------------------
+// Sliding-window argmin over registers (van Herk / Gil-Werman inside one thread): NW windows of W
+// elements over e[0 .. NW+W-2]; a[i] = index of the minimum of e[i .. i+W-1].
+// LEFT = true : leftmost minimum wins ties (minimizer_view.hpp:283,374)
+// LEFT = false: rightmost minimum wins ties (reverse-strand syncmers)
+template <int NW, int W, bool LEFT>
+BL_DEV void window_argmin(const uint64_t* e, uint8_t* a)
+{
+    BL_UNROLL
+    for (int base = 0; base < NW; base += W) {
+        // suffix minima of block e[base .. base+W-1], right to left
+        uint64_t sv[W];
+        uint8_t si[W];
+        sv[W - 1] = e[base + W - 1];
+        si[W - 1] = (uint8_t)(base + W - 1);
+        BL_UNROLL
+        for (int i = W - 2; i >= 0; --i) {
+            const uint64_t x = e[base + i];
+            const bool take = LEFT ? (x <= sv[i + 1]) : (x < sv[i + 1]);
+            sv[i] = take ? x : sv[i + 1];
+            si[i] = take ? (uint8_t)(base + i) : si[i + 1];
+        }
+        a[base] = si[0];
+        // prefix minima of the following block, combined on the fly
+        uint64_t pv = 0;
+        uint8_t pi = 0;
+        BL_UNROLL
+        for (int i = 1; i < W; ++i) {
+            if (base + i >= NW) break;
+            const uint64_t x = e[base + W - 1 + i];
+            if (i == 1) {
+                pv = x;
+                pi = (uint8_t)(base + W);
+            } else {
+                const bool take = LEFT ? (x < pv) : (x <= pv);
+                pv = take ? x : pv;
+                pi = take ? (uint8_t)(base + W - 1 + i) : pi;
+            }
+            const bool right = LEFT ? (pv < sv[i]) : (pv <= sv[i]);
+            a[base + i] = right ? pi : si[i];
+        }
+    }
+}
+
+}  // namespace bl

@@ -1,0 +1,254 @@
+"""Host-side binding of the scan entry points (thin; all work happens in the HIP library).
+
+Device memory for outputs comes from torch (plumbing only): int64 CUDA tensors whose storage the
+kernels fill with uint64 records; `.view(np.uint64)` on the host copy restores the type.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+from .capi import FLAG_CANONICAL, FLAG_DROP_LAST, FLAG_SYNC, BiolibError, Result, check
+
+
+def hash64(value, seed=0):
+    """hash::hash64::hash<uint64_t>(value, seed) (include/hash.hpp:55-59), bit-exact, on the host."""
+    return int(capi.lib().bl_hash64_u64(int(value) & (2**64 - 1), int(seed) & (2**64 - 1)))
+
+
+def _flags(canonical=False, drop_last=False, sync=False):
+    return (FLAG_CANONICAL if canonical else 0) | (FLAG_DROP_LAST if drop_last else 0) | (FLAG_SYNC if sync else 0)
+
+
+class Context:
+    """One context per (process, GPU): owns the stream-ordered workspace of the scans."""
+
+    def __init__(self, device=0, torch_stream=True):
+        import torch
+
+        if not torch.cuda.is_available():
+            raise BiolibError(capi.BL_ERR_NO_DEVICE, "no GPU visible: biolib_amd has no CPU fallback")
+        self._lib = capi.lib()
+        self.device = int(device)
+        self.torch_device = torch.device("cuda", self.device)
+        h = C.c_void_p()
+        check(self._lib.bl_ctx_create(self.device, C.byref(h)))
+        self._h = h
+        if torch_stream:
+            # run on torch's current stream so torch.cuda.Event / torch allocations are ordered with the scans
+            with torch.cuda.device(self.device):
+                s = torch.cuda.current_stream(self.device).cuda_stream
+            check(self._lib.bl_ctx_set_stream(self._h, C.c_void_p(s)))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.bl_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self):
+        check(self._lib.bl_ctx_sync(self._h))
+
+    def last_scan_ms(self):
+        ms = C.c_float()
+        check(self._lib.bl_ctx_last_scan_ms(self._h, C.byref(ms)))
+        return float(ms.value)
+
+    # ---- batches
+    def upload(self, bases, offsets=None):
+        if isinstance(bases, str):
+            bases = bases.encode()
+        arr = np.frombuffer(bytes(bases), dtype=np.uint8) if isinstance(bases, (bytes, bytearray)) else np.ascontiguousarray(bases, dtype=np.uint8)
+        offs = None if offsets is None else np.ascontiguousarray(offsets, dtype=np.uint64)
+        h = C.c_void_p()
+        check(self._lib.bl_batch_upload(self._h, arr.ctypes.data_as(C.c_void_p) if arr.size else None, arr.size,
+                                        None if offs is None else offs.ctypes.data_as(C.c_void_p), 0 if offs is None else len(offs) - 1, C.byref(h)))
+        return Batch(self, h)
+
+    def synth(self, seed, n_bases, read_len=0):
+        h = C.c_void_p()
+        check(self._lib.bl_batch_synth(self._h, int(seed), int(n_bases), int(read_len), C.byref(h)))
+        return Batch(self, h)
+
+    def from_tensor(self, t, offsets=None, read_len=0):
+        """Wrap a uint8 CUDA tensor of ASCII bases (not copied; must stay alive)."""
+        assert t.is_cuda and t.dtype.itemsize == 1 and t.is_contiguous()
+        offs = None if offsets is None else np.ascontiguousarray(offsets, dtype=np.uint64)
+        h = C.c_void_p()
+        check(self._lib.bl_batch_from_device(self._h, C.c_void_p(t.data_ptr()), t.numel(),
+                                             None if offs is None else offs.ctypes.data_as(C.c_void_p), 0 if offs is None else len(offs) - 1,
+                                             int(read_len), C.byref(h)))
+        b = Batch(self, h)
+        b._keep = t
+        return b
+
+    # ---- device arrays (torch plumbing)
+    def empty_u64(self, n):
+        import torch
+
+        return torch.empty(max(int(n), 1), dtype=torch.int64, device=self.torch_device)
+
+    def empty_u8(self, n):
+        import torch
+
+        return torch.empty(max(int(n), 1), dtype=torch.uint8, device=self.torch_device)
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _host_u64(t, n):
+    return t[:n].cpu().numpy().view(np.uint64).copy()
+
+
+class Batch:
+    """Device-resident sequences (bl_batch)."""
+
+    def __init__(self, ctx, handle):
+        self.ctx = ctx
+        self._h = handle
+        self._lib = ctx._lib
+        self._keep = None
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.bl_batch_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def n_bases(self):
+        return int(self._lib.bl_batch_n_bases(self._h))
+
+    @property
+    def n_seqs(self):
+        return int(self._lib.bl_batch_n_seqs(self._h))
+
+    def download(self, first=0, n=None):
+        n = self.n_bases - first if n is None else n
+        out = np.empty(n, dtype=np.uint8)
+        check(self._lib.bl_batch_download(self._h, first, n, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    # ---- raw (asynchronous) entry points: device tensors in, Result filled after ctx.sync()
+    def kmers_raw(self, k, seed, flags, first=0, n=0, values=None, hashes=None, valid=None, result=None):
+        result = result if result is not None else Result()
+        check(self._lib.bl_scan_kmers(self.ctx._h, self._h, first, n, k, seed, flags, _ptr(values), _ptr(hashes), _ptr(valid), C.byref(result)))
+        return result
+
+    def minimizers_raw(self, unit, w, seed, flags, first=0, n=0, values=None, positions=None, hashes=None, capacity=0, result=None):
+        result = result if result is not None else Result()
+        check(self._lib.bl_scan_minimizers(self.ctx._h, self._h, first, n, unit, w, seed, flags, _ptr(values), _ptr(positions), _ptr(hashes),
+                                           capacity, C.byref(result)))
+        return result
+
+    def super_kmers_raw(self, k, m, seed, flags, first=0, n=0, minimizers=None, first_pos=None, mm_pos=None, sizes=None, hashes=None,
+                        capacity=0, result=None):
+        result = result if result is not None else Result()
+        check(self._lib.bl_scan_super_kmers(self.ctx._h, self._h, first, n, k, m, seed, flags, _ptr(minimizers), _ptr(first_pos), _ptr(mm_pos),
+                                            _ptr(sizes), _ptr(hashes), capacity, C.byref(result)))
+        return result
+
+    def syncmers_raw(self, k, s, soff, eoff, seed, flags, first=0, n=0, positions=None, capacity=0, result=None):
+        result = result if result is not None else Result()
+        check(self._lib.bl_scan_syncmers(self.ctx._h, self._h, first, n, k, s, soff, eoff, seed, flags, _ptr(positions), capacity, C.byref(result)))
+        return result
+
+    # ---- convenience wrappers returning host numpy arrays
+    def _span(self, first, n):
+        end = self.n_bases if not n else min(self.n_bases, first + n)
+        return max(end - first, 0)
+
+    def kmers(self, k, seed=0, canonical=False, drop_last=False, first=0, n=0, arrays=True):
+        span = self._span(first, n)
+        c = self.ctx
+        v = c.empty_u64(span) if arrays else None
+        h = c.empty_u64(span) if arrays else None
+        ok = c.empty_u8(span) if arrays else None
+        r = self.kmers_raw(k, seed, _flags(canonical, drop_last, True), first, n, v, h, ok)
+        out = r.as_dict()
+        out["sum_hash"] = out.pop("xor_pos")
+        if arrays:
+            out.update(values=_host_u64(v, span), hashes=_host_u64(h, span), valid=ok[:span].cpu().numpy().copy())
+        return out
+
+    def _with_capacity(self, guess, run):
+        cap = max(int(guess), 64)
+        while True:
+            try:
+                return run(cap)
+            except BiolibError as e:
+                if e.code != capi.BL_ERR_CAPACITY:
+                    raise
+                cap = int(self._last_count) + 64
+
+    def minimizers(self, unit, w, seed=0, canonical=False, first=0, n=0, capacity=None):
+        span = self._span(first, n)
+        guess = capacity if capacity is not None else int(span * 2.4 / (w + 1)) + 4096
+
+        def run(cap):
+            c = self.ctx
+            v, p, h = c.empty_u64(cap), c.empty_u64(cap), c.empty_u64(cap)
+            r = Result()
+            try:
+                self.minimizers_raw(unit, w, seed, _flags(canonical, False, True), first, n, v, p, h, cap, r)
+            finally:
+                self._last_count = r.count
+            cnt = int(r.count)
+            out = r.as_dict()
+            out.update(values=_host_u64(v, cnt), positions=_host_u64(p, cnt), hashes=_host_u64(h, cnt))
+            return out
+
+        return self._with_capacity(guess, run)
+
+    def super_kmers(self, k, m, seed=0, canonical=False, first=0, n=0, capacity=None):
+        span = self._span(first, n)
+        guess = capacity if capacity is not None else int(span * 2.4 / (k - m + 2)) + 4096
+
+        def run(cap):
+            c = self.ctx
+            mn, fp, hs = c.empty_u64(cap), c.empty_u64(cap), c.empty_u64(cap)
+            mp, sz = c.empty_u8(cap), c.empty_u8(cap)
+            r = Result()
+            try:
+                self.super_kmers_raw(k, m, seed, _flags(canonical, False, True), first, n, mn, fp, mp, sz, hs, cap, r)
+            finally:
+                self._last_count = r.count
+            cnt = int(r.count)
+            out = r.as_dict()
+            out.update(minimizers=_host_u64(mn, cnt), first_pos=_host_u64(fp, cnt), mm_pos=mp[:cnt].cpu().numpy().copy(),
+                       sizes=sz[:cnt].cpu().numpy().copy(), hashes=_host_u64(hs, cnt))
+            return out
+
+        return self._with_capacity(guess, run)
+
+    def syncmers(self, k, s, start_offset, end_offset, seed=0, canonical=False, drop_last=False, first=0, n=0, positions=True, capacity=None):
+        span = self._span(first, n)
+        if not positions:
+            r = self.syncmers_raw(k, s, start_offset, end_offset, seed, _flags(canonical, drop_last, True), first, n)
+            return r.as_dict()
+        guess = capacity if capacity is not None else int(span * 2.6 / (k - s + 1)) + 4096
+
+        def run(cap):
+            p = self.ctx.empty_u64(cap)
+            r = Result()
+            try:
+                self.syncmers_raw(k, s, start_offset, end_offset, seed, _flags(canonical, drop_last, True), first, n, p, cap, r)
+            finally:
+                self._last_count = r.count
+            out = r.as_dict()
+            out.update(positions=_host_u64(p, int(r.count)))
+            return out
+
+        return self._with_capacity(guess, run)

@@ -1,0 +1,161 @@
+/* biolib_amd.h — C ABI of the MI355X-native k-mer / minimizer streaming scan.
+ *
+ * This is the drop-in boundary.  The reference (yhhshb/biolib) has no FFI layer:
+ * its boundary is the header-only C++ template surface, so each entry point below names the
+ * reference template whose bulk result it produces, and include/compat/*.hpp re-exposes those
+ * templates (same names, signatures and iteration protocol) on top of these calls.
+ *
+ *   bl_scan_kmers        wrapper::kmer_view<uint64_t,It>                  include/kmer_view.hpp:25-83, 162-234
+ *                        + hash::hash64::hash(value, seed)                include/hash.hpp:50-59
+ *   bl_scan_minimizers   wrapper::minimizer_view<K,M,hash64,It>           include/minimizer_view.hpp:14-98 (intended semantics)
+ *                        sampler::minimizer_sampler<It,Hash>              include/minimizer_sampler.hpp:12-70
+ *   bl_scan_super_kmers  wrapper::super_kmer_view<K,M,hash64>             include/super_kmer_view.hpp:11-58, 121-135
+ *   bl_scan_syncmers     sampler::syncmer_sampler<It,minimizer_position_extractor>
+ *                                                                         include/syncmer_sampler.hpp:9-137, include/kmer_view.hpp:250-283
+ *   bl_hash64_u64        hash::hash64::hash<uint64_t>                     include/hash.hpp:55-59 (host-side convenience, bit-exact)
+ *
+ * Conventions
+ *   - Plain C: opaque handles, plain pointers and sizes.  Never throws; every call returns a status
+ *     (0 = BL_OK, negative = error) and bl_last_error() gives the message of the calling thread's
+ *     last failure.
+ *   - A batch is a set of sequences concatenated without separators; offsets[0..n_seqs] delimits
+ *     them.  All positions reported are 0-based indices into that concatenation ("global positions");
+ *     position - offsets[seq] is the reference's per-view position.
+ *   - Output arrays are DEVICE pointers supplied by the caller (any may be NULL = not wanted) and
+ *     hold `capacity` records; the scan always returns the full count, so a short buffer is
+ *     detected (BL_ERR_CAPACITY) and can be re-run.  Records are in increasing position order.
+ *   - All work is enqueued on the context's HIP stream.  Scans are asynchronous unless
+ *     BL_FLAG_SYNC is given; results (`bl_result`) are valid after bl_ctx_sync().
+ *   - One context per (host thread, device).  A context is not thread-safe; distinct contexts are
+ *     independent.
+ */
+#ifndef BIOLIB_AMD_H
+#define BIOLIB_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BL_VERSION 100 /* 0.1.0 */
+
+enum {
+    BL_OK = 0,
+    BL_ERR_INVALID = -1,     /* bad argument (k > 32, w > 64, NULL handle, misaligned pointer, ...) */
+    BL_ERR_HIP = -2,         /* a HIP runtime call failed */
+    BL_ERR_OOM = -3,         /* device or pinned-host allocation failed */
+    BL_ERR_CAPACITY = -4,    /* output arrays too small: result.count says how many records exist */
+    BL_ERR_NO_DEVICE = -5,   /* no gfx950 device visible */
+    BL_ERR_INTERNAL = -6     /* inter-tile protocol timed out (never expected; results invalid) */
+};
+
+enum {
+    BL_FLAG_CANONICAL = 1u << 0, /* numeric min(forward, reverse complement), kmer_view.hpp:196 */
+    BL_FLAG_DROP_LAST = 1u << 1, /* reproduce the `it != cend()` idiom: the k-mer that ends a sequence is skipped (quirk Q1) */
+    BL_FLAG_SYNC = 1u << 2       /* wait for completion and fill `result` before returning */
+};
+
+typedef struct bl_ctx bl_ctx;
+typedef struct bl_batch bl_batch;
+
+/* Filled asynchronously; read after bl_ctx_sync() (or immediately with BL_FLAG_SYNC). */
+typedef struct bl_result {
+    uint64_t count;      /* records found (k-mers / minimizer occurrences / super-k-mers / syncmers) */
+    uint64_t xor_value;  /* XOR of the 2-bit packed values of all records */
+    uint64_t xor_hash;   /* XOR of their 64-bit hashes */
+    uint64_t xor_pos;    /* XOR of their global positions (k-mer scan: wrapping SUM of hashes instead) */
+    uint64_t aux;        /* super-k-mers: number of group ends seen (== count when consistent) */
+    int32_t status;      /* BL_OK, BL_ERR_CAPACITY or BL_ERR_INTERNAL */
+    int32_t reserved;
+} bl_result;
+
+const char* bl_last_error(void);
+int bl_version(void);
+int bl_device_count(int* n);
+
+/* ---- contexts ---------------------------------------------------------------------------------- */
+int bl_ctx_create(int device, bl_ctx** out);
+int bl_ctx_destroy(bl_ctx* ctx);
+/* Borrow the caller's HIP stream (e.g. torch.cuda.current_stream().cuda_stream).  NULL = back to the
+ * context's own stream. */
+int bl_ctx_set_stream(bl_ctx* ctx, void* hip_stream);
+int bl_ctx_sync(bl_ctx* ctx);
+
+/* ---- batches (device-resident sequences) -------------------------------------------------------- */
+/* Copy host sequences to the device.  offsets has n_seqs+1 entries, offsets[0] = 0,
+ * offsets[n_seqs] = n_bases; NULL offsets = one sequence. */
+int bl_batch_upload(bl_ctx* ctx, const char* bases, uint64_t n_bases, const uint64_t* offsets, uint64_t n_seqs, bl_batch** out);
+/* Wrap bases already in device memory (16-byte aligned, not copied, must outlive the batch).
+ * Sequences are either given by host `offsets` (as above) or, if offsets is NULL and read_len > 0,
+ * consecutive slices of read_len bases (a shorter last read is kept); both NULL/0 = one sequence. */
+int bl_batch_from_device(bl_ctx* ctx, const void* d_bases, uint64_t n_bases, const uint64_t* offsets, uint64_t n_seqs,
+                         uint64_t read_len, bl_batch** out);
+/* Generate SURVEY.md §8d synthetic DNA on the device:
+ *   base[i] = "ACGT"[(splitmix64(seed + (i>>5)) >> (2*(i&31))) & 3], reads = consecutive read_len slices
+ * (read_len = 0: one sequence). */
+int bl_batch_synth(bl_ctx* ctx, uint64_t seed, uint64_t n_bases, uint64_t read_len, bl_batch** out);
+int bl_batch_destroy(bl_batch* batch);
+uint64_t bl_batch_n_bases(const bl_batch* batch);
+uint64_t bl_batch_n_seqs(const bl_batch* batch);
+const void* bl_batch_device_bases(const bl_batch* batch);
+/* Copy bases [first, first+n) back to the host (synchronous). */
+int bl_batch_download(bl_batch* batch, uint64_t first, uint64_t n, char* out);
+
+/* ---- scans ---------------------------------------------------------------------------------------
+ * Every scan works on the windows / k-mers whose FIRST base lies in [first, first+n) of the batch
+ * (n = 0 means "to the end"); bases beyond the range are read as needed, so the union of the results
+ * of consecutive ranges equals the result of one scan over their union.  A range may hold at most
+ * 2^31 positions. */
+
+/* k-mers (C2): for every position p in the range, dense arrays indexed by p - first:
+ *   d_values[p-first]  2-bit packed (canonical) k-mer, first base in the most significant pair
+ *   d_hashes[p-first]  hash64(value, seed) = low 64 bits of MurmurHash3_x64_128 of its 8 raw bytes
+ *   d_valid[p-first]   1 if a k-mer starts at p (no break inside, not crossing a sequence end), else 0
+ * result: count, xor_value, xor_hash, xor_pos := wrapping sum of hashes.  1 <= k <= 32. */
+int bl_scan_kmers(bl_ctx* ctx, const bl_batch* batch, uint64_t first, uint64_t n, uint32_t k, uint64_t seed, uint32_t flags,
+                  uint64_t* d_values, uint64_t* d_hashes, uint8_t* d_valid, bl_result* result);
+
+/* minimizers (C3): hashed unit = (canonical) `unit`-mer, window = w consecutive units inside one
+ * sequence and one break-free run, leftmost minimum hash; one record each time the minimizer
+ * occurrence changes (or a run begins):
+ *   d_values[r] unit value, d_positions[r] global start position of the unit, d_hashes[r] its hash.
+ * In biolib's naming this is minimizer_view(k = unit + w - 1, m = unit).  1 <= unit <= 32, 1 <= w <= 64. */
+int bl_scan_minimizers(bl_ctx* ctx, const bl_batch* batch, uint64_t first, uint64_t n, uint32_t unit, uint32_t w, uint64_t seed,
+                       uint32_t flags, uint64_t* d_values, uint64_t* d_positions, uint64_t* d_hashes, uint64_t capacity,
+                       bl_result* result);
+
+/* super-k-mers (C4): maximal groups of consecutive k-mers sharing one minimizer occurrence
+ * (m-mer, w = k - m + 1):
+ *   d_minimizers[r] m-mer value, d_first_pos[r] global position of the group's first k-mer,
+ *   d_mm_pos[r] minimizer offset inside that k-mer, d_sizes[r] number of k-mers (<= w),
+ *   d_hashes[r] hash of the minimizer.  d_first_pos is required when d_sizes is wanted. */
+int bl_scan_super_kmers(bl_ctx* ctx, const bl_batch* batch, uint64_t first, uint64_t n, uint32_t k, uint32_t m, uint64_t seed,
+                        uint32_t flags, uint64_t* d_minimizers, uint64_t* d_first_pos, uint8_t* d_mm_pos, uint8_t* d_sizes,
+                        uint64_t* d_hashes, uint64_t capacity, bl_result* result);
+
+/* syncmers (C5): k-mers whose minimum-hash s-mer (leftmost in the canonical k-mer, hash seed `seed`,
+ * 0 in the reference) sits at offset start_offset or end_offset:
+ *   d_positions[r] global position of the k-mer (may be NULL: count only).
+ * result: count, xor_pos. */
+int bl_scan_syncmers(bl_ctx* ctx, const bl_batch* batch, uint64_t first, uint64_t n, uint32_t k, uint32_t s, uint32_t start_offset,
+                     uint32_t end_offset, uint64_t seed, uint32_t flags, uint64_t* d_positions, uint64_t capacity,
+                     bl_result* result);
+
+/* Elapsed GPU time of the most recent scan call on this context, from HIP events recorded on the
+ * context's stream around its kernels (milliseconds).  Synchronises. */
+int bl_ctx_last_scan_ms(bl_ctx* ctx, float* ms);
+
+/* ---- device memory helpers (for callers without their own allocator) ----------------------------- */
+int bl_device_alloc(bl_ctx* ctx, uint64_t bytes, void** d_ptr);
+int bl_device_free(bl_ctx* ctx, void* d_ptr);
+int bl_copy_to_host(bl_ctx* ctx, void* dst, const void* d_src, uint64_t bytes); /* synchronous */
+
+/* ---- host-side scalar helper (bit-exact with the device hash) ------------------------------------- */
+uint64_t bl_hash64_u64(uint64_t value, uint64_t seed);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BIOLIB_AMD_H */

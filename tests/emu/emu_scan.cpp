@@ -1,0 +1,221 @@
+// TEST INFRASTRUCTURE — CPU emulation of the HIP tile pipeline.
+//
+// Compiles biolib_amd/csrc/bl_scan_phases.hpp (the very functions the gfx950 kernels are made of)
+// for the host with BL_CPU_EMU and runs them thread by thread, tile by tile, with the barriers of
+// bl_kernels.hip replaced by loop boundaries.  Built with -fsanitize=address,undefined by
+// tests/emu/Makefile so that indexing mistakes in the kernel logic are caught here, on the CPU,
+// and not as a GPU fault.  This is NOT a product path and not a CPU fallback: nothing in
+// biolib_amd/ loads it; only tests/test_emu_*.py does.
+#define BL_CPU_EMU 1
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../biolib_amd/csrc/bl_scan_phases.hpp"
+
+using namespace bl;
+
+namespace {
+
+std::vector<uint32_t> make_start_bits(uint64_t n_bases, const uint64_t* offsets, uint64_t n_seqs, uint64_t read_len)
+{
+    std::vector<uint32_t> bits((n_bases + 31) / 32 + 4, 0u);
+    if (offsets) {
+        for (uint64_t q = 0; q < n_seqs; ++q) {
+            const uint64_t p = offsets[q];
+            if (p < n_bases && offsets[q + 1] > p) bits[p >> 5] |= 1u << (p & 31);
+        }
+    } else if (read_len) {
+        for (uint64_t p = 0; p < n_bases; p += read_len) bits[p >> 5] |= 1u << (p & 31);
+    } else if (n_bases) {
+        bits[0] |= 1u;
+    }
+    return bits;
+}
+
+template <int MODE, int W>
+void run_tiles(const ScanParams& p, unsigned long long* result)
+{
+    auto* sh = new TileShared<MODE>();
+    std::vector<ThreadState> st(TPB);
+    std::vector<uint32_t> packed(TPB), excl(TPB);
+    uint64_t base_s = 0, base_e = 0;
+    Digest dg{0, 0, 0};
+    for (int tile = 0; tile < p.n_tiles; ++tile) {
+        std::memset(sh, 0xA5, sizeof(*sh));  // poison: nothing may depend on stale LDS contents
+        const int64_t q0 = p.origin + (int64_t)tile * p.stride;
+        for (int tid = 0; tid < TPB; ++tid) phase_load<MODE>(p, *sh, tid, q0);
+        for (int tid = 0; tid < TPB; ++tid) phase_hash<MODE>(p, *sh, tid, st[tid]);
+        if (MODE == MODE_SYNCMER) {
+            for (int tid = 0; tid < TPB; ++tid) phase_sync_fwd<MODE, W>(p, *sh, tid, st[tid]);
+            if (p.canonical)
+                for (int tid = 0; tid < TPB; ++tid) phase_publish_h2<MODE>(*sh, tid, st[tid]);
+            for (int tid = 0; tid < TPB; ++tid) packed[tid] = phase_sync_rev<MODE, W>(p, *sh, tid, q0, st[tid]);
+        } else {
+            for (int tid = 0; tid < TPB; ++tid) packed[tid] = phase_window<MODE, W>(p, *sh, tid, q0, st[tid]);
+        }
+        uint32_t run = 0;
+        for (int tid = 0; tid < TPB; ++tid) {
+            excl[tid] = run;
+            run += packed[tid];
+        }
+        const uint32_t n_s = run & 0xffffu, n_e = run >> 16;
+        for (int tid = 0; tid < TPB; ++tid) phase_list<MODE>(*sh, tid, st[tid], excl[tid] & 0xffffu, excl[tid] >> 16);
+        for (int tid = 0; tid < TPB; ++tid) phase_emit<MODE>(p, *sh, tid, q0, n_s, n_e, base_s, base_e, dg);
+        base_s += n_s;
+        base_e += n_e;
+    }
+    result[0] = base_s;
+    result[1] = dg.xv;
+    result[2] = dg.xh;
+    result[3] = dg.xp;
+    result[4] = base_e;
+    delete sh;
+}
+
+template <int MODE>
+void run_mode(const ScanParams& p, unsigned long long* result)
+{
+    switch (p.w) {
+        case 11: run_tiles<MODE, 11>(p, result); break;
+        case 17: run_tiles<MODE, 17>(p, result); break;
+        case 21: run_tiles<MODE, 21>(p, result); break;
+        default: run_tiles<MODE, 0>(p, result); break;
+    }
+}
+
+void fill_common(ScanParams& p, const uint8_t* bases, uint64_t n_bases, const uint32_t* bits, int mode, uint64_t first, uint64_t n,
+                 unsigned unit, unsigned w, uint64_t seed, unsigned flags)
+{
+    uint64_t end = n == 0 ? n_bases : first + n;
+    if (end > n_bases) end = n_bases;
+    p.bases = bases;
+    p.n_bases = (int64_t)n_bases;
+    p.start_bits = bits;
+    plan_scan(mode, (int64_t)first, (int64_t)end, (int)w, p);
+    p.unit = (int)unit;
+    p.w = (int)w;
+    p.seed = (uint32_t)seed;
+    p.canonical = (flags & 1) ? 1 : 0;
+    p.drop_last = (flags & 2) ? 1 : 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+// The `bases` buffer must be readable for n_bases bytes only — the harness copies it into a
+// 16-byte aligned buffer of exactly the size the product allocates (n + 64) so ASan sees the
+// same bounds the device has.
+struct EmuBatch {
+    uint8_t* bases;  // exactly n_bases bytes, 16-byte aligned: ASan sees the bounds the kernel must respect
+    uint64_t n_bases;
+    std::vector<uint32_t> bits;
+    bool single;
+};
+
+EmuBatch* emu_batch(const uint8_t* bases, uint64_t n_bases, const uint64_t* offsets, uint64_t n_seqs, uint64_t read_len)
+{
+    auto* b = new EmuBatch();
+    void* mem = nullptr;
+    if (posix_memalign(&mem, 16, n_bases ? n_bases : 1) != 0) return nullptr;
+    b->bases = static_cast<uint8_t*>(mem);
+    if (n_bases) std::memcpy(b->bases, bases, n_bases);
+    b->n_bases = n_bases;
+    b->single = !offsets && (read_len == 0 || read_len >= n_bases);
+    if (!b->single) b->bits = make_start_bits(n_bases, offsets, n_seqs, read_len);
+    return b;
+}
+
+void emu_batch_free(EmuBatch* b)
+{
+    if (b) free(b->bases);
+    delete b;
+}
+
+void emu_minimizers(const EmuBatch* b, uint64_t first, uint64_t n, unsigned unit, unsigned w, uint64_t seed, unsigned flags,
+                    uint64_t* out_value, uint64_t* out_pos, uint64_t* out_hash, uint64_t capacity, unsigned long long* result)
+{
+    ScanParams p{};
+    fill_common(p, b->bases, b->n_bases, b->single ? nullptr : b->bits.data(), MODE_MINIMIZER, first, n, unit, w, seed, flags);
+    p.out_value = out_value;
+    p.out_pos = out_pos;
+    p.out_hash = out_hash;
+    p.capacity = capacity;
+    std::memset(result, 0, 8 * sizeof(unsigned long long));
+    run_mode<MODE_MINIMIZER>(p, result);
+}
+
+void emu_super_kmers(const EmuBatch* b, uint64_t first, uint64_t n, unsigned k, unsigned m, uint64_t seed, unsigned flags,
+                     uint64_t* out_min, uint64_t* out_first, uint8_t* out_mmpos, uint8_t* out_size, uint64_t* out_hash, uint64_t capacity,
+                     unsigned long long* result)
+{
+    ScanParams p{};
+    fill_common(p, b->bases, b->n_bases, b->single ? nullptr : b->bits.data(), MODE_SUPERKMER, first, n, m, k - m + 1, seed, flags);
+    std::vector<uint64_t> last(capacity ? capacity : 1);
+    p.out_value = out_min;
+    p.out_first = out_first;
+    p.out_mmpos = out_mmpos;
+    p.out_hash = out_hash;
+    p.out_last = last.data();
+    p.capacity = capacity;
+    std::memset(result, 0, 8 * sizeof(unsigned long long));
+    run_mode<MODE_SUPERKMER>(p, result);
+    const uint64_t cnt = result[0] < capacity ? result[0] : capacity;
+    for (uint64_t i = 0; i < cnt; ++i) out_size[i] = (uint8_t)(last[i] - out_first[i] + 1);  // superkmer_size_kernel
+}
+
+void emu_syncmers(const EmuBatch* b, uint64_t first, uint64_t n, unsigned k, unsigned s, unsigned soff, unsigned eoff, uint64_t seed,
+                  unsigned flags, uint64_t* out_pos, uint64_t capacity, unsigned long long* result)
+{
+    ScanParams p{};
+    fill_common(p, b->bases, b->n_bases, b->single ? nullptr : b->bits.data(), MODE_SYNCMER, first, n, s, k - s + 1, seed, flags);
+    p.soff = (int)soff;
+    p.eoff = (int)eoff;
+    p.out_pos = out_pos;
+    p.capacity = capacity;
+    std::memset(result, 0, 8 * sizeof(unsigned long long));
+    run_mode<MODE_SYNCMER>(p, result);
+}
+
+void emu_kmers(const EmuBatch* b, uint64_t first, uint64_t n, unsigned k, uint64_t seed, unsigned flags, uint64_t* out_value,
+               uint64_t* out_hash, uint8_t* out_valid, unsigned long long* result)
+{
+    uint64_t end = n == 0 ? b->n_bases : first + n;
+    if (end > b->n_bases) end = b->n_bases;
+    KmerParams p{};
+    p.bases = b->bases;
+    p.n_bases = (int64_t)b->n_bases;
+    p.start_bits = b->single ? nullptr : b->bits.data();
+    p.first = (int64_t)first;
+    p.end = (int64_t)end;
+    p.origin = align_down16((int64_t)first);
+    p.n_tiles = end > first ? (int32_t)(((int64_t)end - 1 - p.origin) / H + 1) : 0;
+    p.unit = (int)k;
+    p.seed = (uint32_t)seed;
+    p.canonical = (flags & 1) ? 1 : 0;
+    p.drop_last = (flags & 2) ? 1 : 0;
+    p.out_value = out_value;
+    p.out_hash = out_hash;
+    p.out_valid = out_valid;
+    ScanParams lp{};
+    lp.bases = p.bases;
+    lp.n_bases = p.n_bases;
+    lp.start_bits = p.start_bits;
+    KmerAcc acc{0, 0, 0, 0};
+    std::vector<uint32_t> codes(NCHUNK), flg(NCHUNK);
+    for (int tile = 0; tile < p.n_tiles; ++tile) {
+        const int64_t q0 = p.origin + (int64_t)tile * H;
+        for (int c = 0; c < NCHUNK; ++c) stage_chunk(lp, codes.data(), flg.data(), c, q0);
+        for (int tid = 0; tid < TPB; ++tid) kmer_thread(p, codes.data(), flg.data(), tid, q0, acc);
+    }
+    result[0] = acc.cnt;
+    result[1] = acc.xv;
+    result[2] = acc.xh;
+    result[3] = acc.sh;
+}
+
+uint64_t emu_hash64(uint64_t v, uint64_t seed) { return murmur64(v, (uint32_t)seed); }
+
+}  // extern "C"

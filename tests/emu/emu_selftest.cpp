@@ -1,0 +1,221 @@
+// TEST INFRASTRUCTURE — sanitizer self-test: the emulated HIP tile pipeline (emu_scan.cpp, built
+// with -fsanitize=address,undefined) against the C oracle (oracle/bl_oracle.c) on randomised
+// batches: breaks, ragged / empty / short sequences, fixed-length reads, sub-ranges, tie-heavy
+// low-complexity DNA, sizes straddling tile boundaries.  Exit code 0 = all equal.
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+#include <string>
+#include <vector>
+
+#include "../../oracle/bl_oracle.h"
+
+struct EmuBatch;
+extern "C" {
+EmuBatch* emu_batch(const uint8_t* bases, uint64_t n_bases, const uint64_t* offsets, uint64_t n_seqs, uint64_t read_len);
+void emu_batch_free(EmuBatch* b);
+void emu_minimizers(const EmuBatch* b, uint64_t first, uint64_t n, unsigned unit, unsigned w, uint64_t seed, unsigned flags,
+                    uint64_t* out_value, uint64_t* out_pos, uint64_t* out_hash, uint64_t capacity, unsigned long long* result);
+void emu_super_kmers(const EmuBatch* b, uint64_t first, uint64_t n, unsigned k, unsigned m, uint64_t seed, unsigned flags,
+                     uint64_t* out_min, uint64_t* out_first, uint8_t* out_mmpos, uint8_t* out_size, uint64_t* out_hash, uint64_t capacity,
+                     unsigned long long* result);
+void emu_syncmers(const EmuBatch* b, uint64_t first, uint64_t n, unsigned k, unsigned s, unsigned soff, unsigned eoff, uint64_t seed,
+                  unsigned flags, uint64_t* out_pos, uint64_t capacity, unsigned long long* result);
+void emu_kmers(const EmuBatch* b, uint64_t first, uint64_t n, unsigned k, uint64_t seed, unsigned flags, uint64_t* out_value,
+               uint64_t* out_hash, uint8_t* out_valid, unsigned long long* result);
+uint64_t emu_hash64(uint64_t v, uint64_t seed);
+}
+
+static int g_fail = 0;
+#define CHECK(cond, ...)                                   \
+    do {                                                   \
+        if (!(cond)) {                                     \
+            if (g_fail < 20) { std::printf("FAIL %s:%d: ", __FILE__, __LINE__); std::printf(__VA_ARGS__); std::printf("\n"); } \
+            ++g_fail;                                      \
+        }                                                  \
+    } while (0)
+
+struct Case {
+    std::vector<uint8_t> seq;
+    std::vector<uint64_t> offsets;  // always materialised for the oracle
+    uint64_t read_len;              // != 0: emu gets read_len instead of offsets
+    bool single;                    // emu gets neither (one sequence)
+    std::string name;
+};
+
+static std::vector<uint64_t> fixed_offsets(uint64_t n, uint64_t L)
+{
+    std::vector<uint64_t> o;
+    for (uint64_t p = 0; p < n; p += L) o.push_back(p);
+    o.push_back(n);
+    if (n == 0) o = {0, 0};
+    return o;
+}
+
+static void check_case(const Case& c, std::mt19937_64& rng)
+{
+    const uint64_t n = c.seq.size();
+    const size_t n_seqs = c.offsets.size() - 1;
+    EmuBatch* b = c.single ? emu_batch(c.seq.data(), n, nullptr, 0, 0)
+                  : c.read_len ? emu_batch(c.seq.data(), n, nullptr, 0, c.read_len)
+                               : emu_batch(c.seq.data(), n, c.offsets.data(), n_seqs, 0);
+    const char* s = reinterpret_cast<const char*>(c.seq.data());
+    const uint64_t cap = n + 2;
+    std::vector<uint64_t> ov(cap), op(cap), oh(cap), ev(cap), ep(cap), eh(cap), of(cap), ef(cap);
+    std::vector<uint8_t> om(cap), os(cap), em(cap), es(cap);
+    unsigned long long res[8];
+
+    struct MM { unsigned unit, w; uint64_t seed; int canon; };
+    const MM mms[] = {{31, 11, 42, 1}, {15, 17, 42, 1}, {11, 21, 0, 0}, {5, 4, 1, 1}, {32, 2, 9, 1}, {8, 1, 3, 0}, {1, 1, 0, 1},
+                      {32, 64, 5, 1}, {21, 33, 6, 0}, {3, 16, 7, 1}, {16, 17, 8, 0}};
+    for (const MM& m : mms) {
+        // whole batch
+        size_t cnt = blo_minimizers(s, c.offsets.data(), n_seqs, m.unit, m.w, m.seed, m.canon, 1, ov.data(), op.data(), oh.data(), cap);
+        emu_minimizers(b, 0, 0, m.unit, m.w, m.seed, m.canon ? 1 : 0, ev.data(), ep.data(), eh.data(), cap, res);
+        CHECK(res[0] == cnt, "%s mm(%u,%u) count %llu vs %zu", c.name.c_str(), m.unit, m.w, res[0], cnt);
+        if (res[0] == cnt) {
+            uint64_t xv = 0, xh = 0, xp = 0;
+            for (size_t i = 0; i < cnt; ++i) {
+                CHECK(ev[i] == ov[i] && ep[i] == op[i] && eh[i] == oh[i], "%s mm(%u,%u) record %zu: pos %llu vs %llu", c.name.c_str(), m.unit,
+                      m.w, i, (unsigned long long)ep[i], (unsigned long long)op[i]);
+                xv ^= ov[i]; xh ^= oh[i]; xp ^= op[i];
+            }
+            CHECK(res[1] == xv && res[2] == xh && res[3] == xp, "%s mm(%u,%u) digest", c.name.c_str(), m.unit, m.w);
+        }
+        // a random sub-range: the union rule says its records are exactly the whole-batch records whose
+        // WINDOW starts in the range; check via two adjacent ranges that together give the whole
+        if (n > 40) {
+            const uint64_t cut = 1 + rng() % (n - 1);
+            unsigned long long r1[8], r2[8];
+            emu_minimizers(b, 0, cut, m.unit, m.w, m.seed, m.canon ? 1 : 0, ev.data(), ep.data(), eh.data(), cap, r1);
+            const uint64_t c1 = r1[0];
+            emu_minimizers(b, cut, 0, m.unit, m.w, m.seed, m.canon ? 1 : 0, ev.data() + c1, ep.data() + c1, eh.data() + c1, cap - c1, r2);
+            CHECK(c1 + r2[0] == cnt, "%s mm(%u,%u) split at %llu: %llu + %llu vs %zu", c.name.c_str(), m.unit, m.w, (unsigned long long)cut,
+                  (unsigned long long)c1, r2[0], cnt);
+            if (c1 + r2[0] == cnt)
+                for (size_t i = 0; i < cnt; ++i)
+                    CHECK(ev[i] == ov[i] && ep[i] == op[i] && eh[i] == oh[i], "%s mm(%u,%u) split record %zu", c.name.c_str(), m.unit, m.w, i);
+        }
+    }
+
+    struct SK { unsigned k, m; uint64_t seed; int canon; };
+    const SK sks[] = {{31, 15, 42, 1}, {21, 8, 0, 0}, {31, 31, 5, 1}, {31, 21, 1, 1}, {21, 11, 2, 0}, {32, 1, 3, 1}, {40, 9, 4, 1}};
+    for (const SK& k : sks) {
+        size_t cnt = blo_super_kmers(s, c.offsets.data(), n_seqs, k.k, k.m, k.seed, k.canon, ov.data(), of.data(), om.data(), os.data(),
+                                     oh.data(), cap);
+        emu_super_kmers(b, 0, 0, k.k, k.m, k.seed, k.canon ? 1 : 0, ev.data(), ef.data(), em.data(), es.data(), eh.data(), cap, res);
+        CHECK(res[0] == cnt && res[4] == cnt, "%s sk(%u,%u) count %llu/%llu vs %zu", c.name.c_str(), k.k, k.m, res[0], res[4], cnt);
+        if (res[0] == cnt)
+            for (size_t i = 0; i < cnt; ++i)
+                CHECK(ev[i] == ov[i] && ef[i] == of[i] && em[i] == om[i] && es[i] == os[i] && eh[i] == oh[i],
+                      "%s sk(%u,%u) group %zu: first %llu vs %llu size %u vs %u", c.name.c_str(), k.k, k.m, i, (unsigned long long)ef[i],
+                      (unsigned long long)of[i], es[i], os[i]);
+    }
+
+    struct SY { unsigned k, s, a, b; int canon; };
+    const SY sys[] = {{31, 11, 0, 20, 1}, {31, 11, 0, 20, 0}, {21, 8, 0, 13, 1}, {7, 4, 0, 3, 1}, {15, 15, 0, 0, 1}, {31, 15, 0, 16, 1},
+                      {32, 12, 3, 9, 1}, {9, 1, 0, 8, 0}, {28, 12, 5, 5, 1}};
+    for (const SY& y : sys) {
+        for (int drop = 0; drop < 2; ++drop) {
+            size_t cnt = blo_syncmers(s, c.offsets.data(), n_seqs, y.k, y.s, y.a, y.b, y.canon, drop, 1, op.data(), cap);
+            emu_syncmers(b, 0, 0, y.k, y.s, y.a, y.b, 0, (y.canon ? 1u : 0u) | (drop ? 2u : 0u), ep.data(), cap, res);
+            CHECK(res[0] == cnt, "%s sync(%u,%u,%u,%u,c%d,d%d) count %llu vs %zu", c.name.c_str(), y.k, y.s, y.a, y.b, y.canon, drop, res[0], cnt);
+            if (res[0] == cnt)
+                for (size_t i = 0; i < cnt; ++i)
+                    CHECK(ep[i] == op[i], "%s sync(%u,%u) pos %zu: %llu vs %llu", c.name.c_str(), y.k, y.s, i, (unsigned long long)ep[i],
+                          (unsigned long long)op[i]);
+        }
+    }
+
+    std::vector<uint64_t> uv(n + 1), kv(n + 1), kh(n + 1);
+    std::vector<uint8_t> uok(n + 1), kok(n + 1);
+    for (unsigned k : {1u, 2u, 5u, 15u, 16u, 17u, 21u, 31u, 32u}) {
+        for (int canon = 0; canon < 2; ++canon) {
+            blo_units(s, c.offsets.data(), n_seqs, k, canon, uv.data(), uok.data());
+            emu_kmers(b, 0, 0, k, 77, canon ? 1u : 0u, kv.data(), kh.data(), kok.data(), res);
+            uint64_t cnt = 0;
+            for (uint64_t p = 0; p < n; ++p) {
+                CHECK(kok[p] == uok[p], "%s kmers k%u c%d valid @%llu: %u vs %u", c.name.c_str(), k, canon, (unsigned long long)p, kok[p], uok[p]);
+                if (uok[p] && kok[p]) {
+                    CHECK(kv[p] == uv[p], "%s kmers k%u c%d value @%llu", c.name.c_str(), k, canon, (unsigned long long)p);
+                    CHECK(kh[p] == blo_hash64_u64(uv[p], 77), "%s kmers k%u c%d hash @%llu", c.name.c_str(), k, canon, (unsigned long long)p);
+                }
+                cnt += uok[p];
+            }
+            CHECK(res[0] == cnt, "%s kmers k%u count", c.name.c_str(), k);
+            uint64_t dg[4];
+            blo_kmer_digest(s, c.offsets.data(), n_seqs, k, canon, 77, 1, 1, dg);
+            emu_kmers(b, 0, 0, k, 77, (canon ? 1u : 0u) | 2u, nullptr, nullptr, nullptr, res);
+            CHECK(res[0] == dg[0] && res[1] == dg[1] && res[2] == dg[2] && res[3] == dg[3], "%s kmers k%u c%d drop_last digest %llu vs %llu",
+                  c.name.c_str(), k, canon, res[0], (unsigned long long)dg[0]);
+        }
+    }
+    emu_batch_free(b);
+}
+
+int main(int argc, char** argv)
+{
+    const int rounds = argc > 1 ? std::atoi(argv[1]) : 3;
+    std::mt19937_64 rng(12345);
+    // hash spot check
+    for (int i = 0; i < 1000; ++i) {
+        uint64_t v = rng(), sd = rng();
+        CHECK(emu_hash64(v, sd) == blo_hash64_u64(v, sd), "hash64");
+    }
+    const char alphabet_breaks[] = "NnRYK-*X\x80\xff@`bBfF";
+    for (int round = 0; round < rounds; ++round) {
+        const uint64_t sizes[] = {0, 1, 15, 16, 17, 31, 40, 41, 42, 150, 1000, 4064, 4079, 4080, 4081, 4095, 4096, 4097, 8160, 8161, 9000, 12345};
+        for (uint64_t n : sizes) {
+            for (int flavour = 0; flavour < 6; ++flavour) {
+                Case c;
+                c.seq.resize(n);
+                c.read_len = 0;
+                c.single = false;
+                if (flavour == 4) {  // tie-heavy low-complexity DNA
+                    const char* motifs[] = {"A", "AC", "ACG", "AAAT", "ACGTT", "GATTACA"};
+                    const std::string mo = motifs[rng() % 6];
+                    for (uint64_t i = 0; i < n; ++i) c.seq[i] = (uint8_t)mo[i % mo.size()];
+                    for (uint64_t i = 0; i + 1 < n; i += 97 + rng() % 300) c.seq[i] = "ACGT"[rng() % 4];
+                } else {
+                    blo_synth(1000 * round + n + flavour, 0, n, reinterpret_cast<char*>(c.seq.data()));
+                    if (flavour == 5)
+                        for (uint64_t i = 0; i < n; ++i)
+                            if (rng() % 3 == 0) c.seq[i] = (uint8_t)"acgtuU"[rng() % 6];  // case / U handling
+                }
+                if ((flavour == 1 || flavour == 3) && n)  // breaks, any position incl. first/last
+                    for (uint64_t j = 0, nb = 1 + n / 200; j < nb; ++j) c.seq[rng() % n] = (uint8_t)alphabet_breaks[rng() % (sizeof(alphabet_breaks) - 1)];
+                if (flavour == 0 || flavour == 1 || flavour == 4 || flavour == 5) {
+                    if (rng() % 2) { c.offsets = {0, n}; c.single = true; c.name = "single"; }
+                    else {
+                        const uint64_t L = (const uint64_t[]){150, 41, 64, 10000, 1, 33}[rng() % 6];
+                        c.offsets = fixed_offsets(n, L);
+                        c.read_len = L;
+                        c.name = "reads" + std::to_string(L);
+                        if (L >= n) { c.single = true; c.read_len = 0; c.offsets = {0, n}; }
+                    }
+                } else {  // ragged, with empty and tiny sequences
+                    c.offsets.push_back(0);
+                    uint64_t p = 0;
+                    while (p < n) {
+                        const uint64_t kind = rng() % 6;
+                        const uint64_t len = kind == 0 ? 0 : kind == 1 ? 1 + rng() % 40 : kind == 2 ? 41 + rng() % 200 : 1 + rng() % 3000;
+                        p = p + len > n ? n : p + len;
+                        c.offsets.push_back(p);
+                    }
+                    if (c.offsets.size() == 1) c.offsets.push_back(0);
+                    c.name = "ragged";
+                }
+                c.name += "/n" + std::to_string(n) + "/f" + std::to_string(flavour) + "/r" + std::to_string(round);
+                check_case(c, rng);
+            }
+        }
+    }
+    if (g_fail) {
+        std::printf("emu_selftest: %d mismatches\n", g_fail);
+        return 1;
+    }
+    std::printf("emu_selftest: OK\n");
+    return 0;
+}
