@@ -18,7 +18,7 @@ SYMBOLS = [
     "bl_last_error", "bl_version", "bl_device_count", "bl_ctx_create", "bl_ctx_destroy", "bl_ctx_set_stream", "bl_ctx_sync",
     "bl_batch_upload", "bl_batch_from_device", "bl_batch_synth", "bl_batch_destroy", "bl_batch_n_bases", "bl_batch_n_seqs",
     "bl_batch_device_bases", "bl_batch_download", "bl_scan_kmers", "bl_scan_minimizers", "bl_scan_super_kmers", "bl_scan_syncmers",
-    "bl_ctx_last_scan_ms", "bl_device_alloc", "bl_device_free", "bl_copy_to_host", "bl_hash64_u64",
+    "bl_ctx_last_scan_ms", "bl_ctx_kernel_timing", "bl_ctx_kernel_time", "bl_device_alloc", "bl_device_free", "bl_copy_to_host", "bl_hash64_u64",
 ]
 
 
@@ -48,6 +48,11 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise ImportError(f"{LIB_PATH} is missing: build the HIP extension first (__graft_entry__.build()); "
                           "biolib_amd has no CPU fallback")
+    # torch's ROCm wheel bundles its own libamdhip64/libhsa-runtime64 (same SONAMEs as /opt/rocm's).
+    # Import torch first so that ONE HIP runtime serves both torch (device memory, streams, RCCL) and
+    # this library; loading ours first brings in a second runtime and device enumeration then fails.
+    import torch  # noqa: F401
+
     L = C.CDLL(LIB_PATH)
     vp, u64, u32 = C.c_void_p, C.c_uint64, C.c_uint32
     L.bl_last_error.restype = C.c_char_p
@@ -73,6 +78,8 @@ def lib():
     L.bl_scan_super_kmers.argtypes = [vp, vp, u64, u64, u32, u32, u64, u32, vp, vp, vp, vp, vp, u64, C.POINTER(Result)]
     L.bl_scan_syncmers.argtypes = [vp, vp, u64, u64, u32, u32, u32, u32, u64, u32, vp, u64, C.POINTER(Result)]
     L.bl_ctx_last_scan_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    L.bl_ctx_kernel_timing.argtypes = [vp, C.c_int]
+    L.bl_ctx_kernel_time.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(u64)]
     L.bl_device_alloc.argtypes = [vp, u64, C.POINTER(vp)]
     L.bl_device_free.argtypes = [vp, vp]
     L.bl_copy_to_host.argtypes = [vp, vp, vp, u64]

@@ -7,6 +7,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/biolib_amd.h"
@@ -58,6 +59,13 @@ struct bl_ctx {
     std::vector<Pending> pending;
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     bool timed = false;
+    // optional per-launch timing of the main scan kernel alone (bl_ctx_kernel_timing)
+    bool ktiming = false;
+    std::vector<hipEvent_t> ev_pool;                       // free events
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_open;  // recorded, not yet read
+    double kernel_ms = 0.0;
+    uint64_t kernel_launches = 0;
+    std::vector<bl_batch*> batches;  // live batches: destroyed with the context if the caller did not
 
     unsigned int* ticket() const { return reinterpret_cast<unsigned int*>(ws); }
     unsigned int* error() const { return reinterpret_cast<unsigned int*>(ws) + 1; }
@@ -116,10 +124,44 @@ int flush_pending(bl_ctx* c)
     return BL_OK;
 }
 
+int flush_kernel_events(bl_ctx* c)
+{
+    for (auto& pr : c->ev_open) {
+        float ms = 0.f;
+        BL_HIP(hipEventElapsedTime(&ms, pr.first, pr.second));
+        c->kernel_ms += ms;
+        c->kernel_launches += 1;
+        c->ev_pool.push_back(pr.first);
+        c->ev_pool.push_back(pr.second);
+    }
+    c->ev_open.clear();
+    return BL_OK;
+}
+
 int sync_ctx(bl_ctx* c)
 {
     BL_HIP(hipStreamSynchronize(c->stream));
+    int rc = flush_kernel_events(c);
+    if (rc != BL_OK) return rc;
     return flush_pending(c);
+}
+
+// event pair around the main kernel of one scan (only when kernel timing is on)
+int kernel_event(bl_ctx* c, bool start)
+{
+    if (!c->ktiming) return BL_OK;
+    if (start) {
+        hipEvent_t ev[2];
+        for (int i = 0; i < 2; ++i) {
+            if (!c->ev_pool.empty()) { ev[i] = c->ev_pool.back(); c->ev_pool.pop_back(); }
+            else BL_HIP(hipEventCreate(&ev[i]));
+        }
+        c->ev_open.emplace_back(ev[0], ev[1]);
+        BL_HIP(hipEventRecord(ev[0], c->stream));
+    } else {
+        BL_HIP(hipEventRecord(c->ev_open.back().second, c->stream));
+    }
+    return BL_OK;
 }
 
 // memset header + shards + result + status for n_tiles, record the start event
@@ -259,14 +301,17 @@ int bl_ctx_create(int device, bl_ctx** out)
 int bl_ctx_destroy(bl_ctx* c)
 {
     if (!c) return BL_OK;
-    hipSetDevice(c->device);
-    if (c->stream) hipStreamSynchronize(c->stream);
-    if (c->ws) hipFree(c->ws);
-    if (c->last_buf) hipFree(c->last_buf);
-    if (c->pinned) hipHostFree(c->pinned);
-    if (c->ev_start) hipEventDestroy(c->ev_start);
-    if (c->ev_stop) hipEventDestroy(c->ev_stop);
-    if (c->own_stream) hipStreamDestroy(c->own_stream);
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    while (!c->batches.empty()) bl_batch_destroy(c->batches.back());  // handles of leftover batches become invalid
+    if (c->ws) (void)hipFree(c->ws);
+    if (c->last_buf) (void)hipFree(c->last_buf);
+    if (c->pinned) (void)hipHostFree(c->pinned);
+    for (auto& pr : c->ev_open) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+    for (hipEvent_t ev : c->ev_pool) (void)hipEventDestroy(ev);
+    if (c->ev_start) (void)hipEventDestroy(c->ev_start);
+    if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
     return BL_OK;
 }
@@ -295,6 +340,27 @@ int bl_ctx_last_scan_ms(bl_ctx* c, float* ms)
     return BL_OK;
 }
 
+int bl_ctx_kernel_timing(bl_ctx* c, int enable)
+{
+    if (!c) return fail(BL_ERR_INVALID, "ctx is NULL");
+    int rc = sync_ctx(c);
+    if (rc != BL_OK) return rc;
+    c->ktiming = enable != 0;
+    c->kernel_ms = 0.0;
+    c->kernel_launches = 0;
+    return BL_OK;
+}
+
+int bl_ctx_kernel_time(bl_ctx* c, double* total_ms, uint64_t* launches)
+{
+    if (!c || !total_ms || !launches) return fail(BL_ERR_INVALID, "NULL argument");
+    int rc = sync_ctx(c);
+    if (rc != BL_OK) return rc;
+    *total_ms = c->kernel_ms;
+    *launches = c->kernel_launches;
+    return BL_OK;
+}
+
 // ---------------------------------------------------------------------------------------- batches
 
 static int new_batch(bl_ctx* c, uint64_t n_bases, bl_batch** out, bl_batch*& b)
@@ -306,6 +372,7 @@ static int new_batch(bl_ctx* c, uint64_t n_bases, bl_batch** out, bl_batch*& b)
     if (!b) return fail(BL_ERR_OOM, "host allocation failed");
     b->ctx = c;
     b->n_bases = n_bases;
+    c->batches.push_back(b);
     return BL_OK;
 }
 
@@ -314,9 +381,9 @@ int bl_batch_upload(bl_ctx* c, const char* bases, uint64_t n_bases, const uint64
     bl_batch* b = nullptr;
     int rc = new_batch(c, n_bases, out, b);
     if (rc != BL_OK) return rc;
-    if (n_bases && !bases) { delete b; return fail(BL_ERR_INVALID, "bases is NULL"); }
+    if (n_bases && !bases) { bl_batch_destroy(b); return fail(BL_ERR_INVALID, "bases is NULL"); }
     hipError_t e = hipMalloc(&b->bases, n_bases + 64);
-    if (e != hipSuccess) { delete b; return fail(BL_ERR_OOM, std::string("hipMalloc(bases): ") + hipGetErrorString(e)); }
+    if (e != hipSuccess) { bl_batch_destroy(b); return fail(BL_ERR_OOM, std::string("hipMalloc(bases): ") + hipGetErrorString(e)); }
     b->owns_bases = true;
     e = hipMemsetAsync(b->bases + (n_bases & ~15ull), 0, 64 + (n_bases & 15ull), c->stream);
     if (e == hipSuccess && n_bases) e = hipMemcpyAsync(b->bases, bases, n_bases, hipMemcpyHostToDevice, c->stream);
@@ -338,7 +405,7 @@ int bl_batch_from_device(bl_ctx* c, const void* d_bases, uint64_t n_bases, const
     int rc = new_batch(c, n_bases, out, b);
     if (rc != BL_OK) return rc;
     if ((n_bases && !d_bases) || (reinterpret_cast<uintptr_t>(d_bases) & 15)) {
-        delete b;
+        bl_batch_destroy(b);
         return fail(BL_ERR_INVALID, "d_bases must be a non-NULL, 16-byte aligned device pointer");
     }
     b->bases = const_cast<uint8_t*>(static_cast<const uint8_t*>(d_bases));
@@ -355,7 +422,7 @@ int bl_batch_synth(bl_ctx* c, uint64_t seed, uint64_t n_bases, uint64_t read_len
     int rc = new_batch(c, n_bases, out, b);
     if (rc != BL_OK) return rc;
     hipError_t e = hipMalloc(&b->bases, n_bases + 64);
-    if (e != hipSuccess) { delete b; return fail(BL_ERR_OOM, std::string("hipMalloc(bases): ") + hipGetErrorString(e)); }
+    if (e != hipSuccess) { bl_batch_destroy(b); return fail(BL_ERR_OOM, std::string("hipMalloc(bases): ") + hipGetErrorString(e)); }
     b->owns_bases = true;
     e = hipMemsetAsync(b->bases + (n_bases & ~15ull), 0, 64 + (n_bases & 15ull), c->stream);
     if (e == hipSuccess) e = bl::launch_synth(b->bases, 0, n_bases, seed, c->stream);
@@ -370,11 +437,14 @@ int bl_batch_destroy(bl_batch* b)
 {
     if (!b) return BL_OK;
     if (b->ctx) {
-        hipSetDevice(b->ctx->device);
-        hipStreamSynchronize(b->ctx->stream);
+        (void)hipSetDevice(b->ctx->device);
+        (void)hipStreamSynchronize(b->ctx->stream);
+        auto& v = b->ctx->batches;
+        for (size_t i = 0; i < v.size(); ++i)
+            if (v[i] == b) { v[i] = v.back(); v.pop_back(); break; }
     }
-    if (b->owns_bases && b->bases) hipFree(b->bases);
-    if (b->start_bits) hipFree(b->start_bits);
+    if (b->owns_bases && b->bases) (void)hipFree(b->bases);
+    if (b->start_bits) (void)hipFree(b->start_bits);
     delete b;
     return BL_OK;
 }
@@ -423,8 +493,12 @@ int bl_scan_kmers(bl_ctx* c, const bl_batch* b, uint64_t first, uint64_t n, uint
     if (rc != BL_OK) return rc;
     p.shards = c->shards();
     const int n_blocks = p.n_tiles < 256 * 8 ? p.n_tiles : 256 * 8;
+    rc = kernel_event(c, true);
+    if (rc != BL_OK) return rc;
     hipError_t e = bl::launch_kmers(p, n_blocks, c->stream);
     if (e != hipSuccess) return fail(BL_ERR_HIP, std::string("kmer_kernel: ") + hipGetErrorString(e));
+    rc = kernel_event(c, false);
+    if (rc != BL_OK) return rc;
     return end_scan(c, /*add_mask: count, sum*/ (1u << 0) | (1u << 3), result, false, 0, flags);
 }
 
@@ -454,9 +528,11 @@ static int scan_windows(int mode, bl_ctx* c, const bl_batch* b, uint64_t first, 
     p.ticket = c->ticket();
     p.shards = c->shards();
     p.error = c->error();
+    rc = kernel_event(c, true);
+    if (rc != BL_OK) return rc;
     hipError_t e = bl::launch_scan(mode, p, c->stream);
     if (e != hipSuccess) return fail(BL_ERR_HIP, std::string("scan_kernel: ") + hipGetErrorString(e));
-    return BL_OK;
+    return kernel_event(c, false);
 }
 
 int bl_scan_minimizers(bl_ctx* c, const bl_batch* b, uint64_t first, uint64_t n, uint32_t unit, uint32_t w, uint64_t seed, uint32_t flags,

@@ -4,6 +4,7 @@ Device memory for outputs comes from torch (plumbing only): int64 CUDA tensors w
 kernels fill with uint64 records; `.view(np.uint64)` on the host copy restores the type.
 """
 import ctypes as C
+import weakref
 
 import numpy as np
 
@@ -34,6 +35,7 @@ class Context:
         h = C.c_void_p()
         check(self._lib.bl_ctx_create(self.device, C.byref(h)))
         self._h = h
+        self._batches = weakref.WeakSet()
         if torch_stream:
             # run on torch's current stream so torch.cuda.Event / torch allocations are ordered with the scans
             with torch.cuda.device(self.device):
@@ -42,6 +44,8 @@ class Context:
 
     def close(self):
         if getattr(self, "_h", None):
+            for b in list(self._batches):
+                b.close()
             self._lib.bl_ctx_destroy(self._h)
             self._h = None
 
@@ -58,6 +62,15 @@ class Context:
         ms = C.c_float()
         check(self._lib.bl_ctx_last_scan_ms(self._h, C.byref(ms)))
         return float(ms.value)
+
+    def kernel_timing(self, enable=True):
+        check(self._lib.bl_ctx_kernel_timing(self._h, 1 if enable else 0))
+
+    def kernel_time(self):
+        """(total ms, launches) of the scan kernels alone since kernel_timing(True)."""
+        ms, n = C.c_double(), C.c_uint64()
+        check(self._lib.bl_ctx_kernel_time(self._h, C.byref(ms), C.byref(n)))
+        return float(ms.value), int(n.value)
 
     # ---- batches
     def upload(self, bases, offsets=None):
@@ -115,10 +128,12 @@ class Batch:
         self._h = handle
         self._lib = ctx._lib
         self._keep = None
+        ctx._batches.add(self)
 
     def close(self):
         if getattr(self, "_h", None):
-            self._lib.bl_batch_destroy(self._h)
+            if getattr(self.ctx, "_h", None):  # a closed context has already destroyed its batches
+                self._lib.bl_batch_destroy(self._h)
             self._h = None
 
     def __del__(self):

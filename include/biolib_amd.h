@@ -2,10 +2,10 @@
  *
  * This is the drop-in boundary.  The reference (yhhshb/biolib) has no FFI layer:
  * its boundary is the header-only C++ template surface, so each entry point below names the
- * reference template whose bulk result it produces, and include/compat/*.hpp re-exposes those
+ * reference template whose bulk result it produces, and the headers under include/compat/ re-expose those
  * templates (same names, signatures and iteration protocol) on top of these calls.
  *
- *   bl_scan_kmers        wrapper::kmer_view<uint64_t,It>                  include/kmer_view.hpp:25-83, 162-234
+ *   bl_scan_kmers        wrapper::kmer_view<uint64_t,It>                  include/kmer_view.hpp:25-83 and 162-234
  *                        + hash::hash64::hash(value, seed)                include/hash.hpp:50-59
  *   bl_scan_minimizers   wrapper::minimizer_view<K,M,hash64,It>           include/minimizer_view.hpp:14-98 (intended semantics)
  *                        sampler::minimizer_sampler<It,Hash>              include/minimizer_sampler.hpp:12-70
@@ -77,6 +77,8 @@ int bl_device_count(int* n);
 
 /* ---- contexts ---------------------------------------------------------------------------------- */
 int bl_ctx_create(int device, bl_ctx** out);
+/* Destroying a context also destroys the batches created on it that are still alive (their handles
+ * become invalid). */
 int bl_ctx_destroy(bl_ctx* ctx);
 /* Borrow the caller's HIP stream (e.g. torch.cuda.current_stream().cuda_stream).  NULL = back to the
  * context's own stream. */
@@ -146,6 +148,12 @@ int bl_scan_syncmers(bl_ctx* ctx, const bl_batch* batch, uint64_t first, uint64_
 /* Elapsed GPU time of the most recent scan call on this context, from HIP events recorded on the
  * context's stream around its kernels (milliseconds).  Synchronises. */
 int bl_ctx_last_scan_ms(bl_ctx* ctx, float* ms);
+/* Per-launch timing of the main scan kernel alone: after bl_ctx_kernel_timing(ctx, 1) every scan
+ * brackets its tile kernel with a HIP event pair on the context's stream; bl_ctx_kernel_time
+ * synchronises and returns the summed kernel time and the number of launches since timing was
+ * switched on (switching it on or off resets both). */
+int bl_ctx_kernel_timing(bl_ctx* ctx, int enable);
+int bl_ctx_kernel_time(bl_ctx* ctx, double* total_ms, uint64_t* launches);
 
 /* ---- device memory helpers (for callers without their own allocator) ----------------------------- */
 int bl_device_alloc(bl_ctx* ctx, uint64_t bytes, void** d_ptr);

@@ -1,0 +1,258 @@
+"""GPU parity tests (run with -m gpu on an MI355X): every scan of the C ABI against
+  (1) the golden fixtures the unmodified reference produced (tests/golden/),
+  (2) the CPU oracle on seeded inputs with breaks, ragged / empty / short sequences and fixed reads,
+  (3) size-independent properties at sizes the oracle cannot finish quickly (range unions,
+      sortedness, digest-of-digests).
+Bit-exact everywhere: integer / index work has no tolerance."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import biolib_amd
+
+    c = biolib_amd.Context(0)
+    yield c
+    c.close()
+
+
+MM_CASES = ((31, 11, 42, 1), (15, 17, 42, 1), (11, 21, 0, 0), (5, 4, 1, 1), (32, 2, 9, 1), (8, 1, 3, 0))
+SK_CASES = ((31, 15, 42, 1), (21, 8, 0, 0), (31, 31, 5, 1))
+
+
+def _golden_batch(ctx, A, name):
+    seq = A["small_clean" if name.startswith("clean") else "small_broken"]
+    kind = name.split("_", 1)[1]
+    if kind == "ragged":
+        return seq, ctx.upload(seq, A["ragged_offsets"])
+    if kind == "reads150":
+        return seq, ctx.upload(seq, np.arange(0, len(seq) + 1, 150, dtype=np.uint64))
+    return seq, ctx.upload(seq)
+
+
+def test_library_loaded_is_the_hip_build():
+    import biolib_amd
+
+    assert biolib_amd.lib().bl_version() == 100
+    with open("/proc/self/maps") as f:
+        assert "libbiolib_amd.so" in f.read()
+
+
+def test_device_synth_matches_generator(ctx, golden_kats):
+    b = ctx.synth(42, 100_003, 150)
+    got = b.download()
+    assert bytes(got[:32]).decode() == golden_kats["synth_seed42_first32"]
+    assert np.array_equal(got, O.synth(42, 100_003))
+    assert b.n_seqs == (100_003 + 149) // 150
+
+
+def test_hash_kats_on_device(ctx, golden_kats):
+    # a 1-mer .. 32-mer scan exposes the device hash of arbitrary packed values; here: the KAT values as 32-mers
+    import biolib_amd
+
+    for v, s, h in golden_kats["hash64_u64"]:
+        assert biolib_amd.hash64(v, s) == h
+    vals = [v for v, s, h in golden_kats["hash64_u64"] if s == 42]
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    for v in vals:
+        seq = acgt[[(v >> (62 - 2 * i)) & 3 for i in range(32)]]
+        out = ctx.upload(seq).kmers(32, seed=42, canonical=False)
+        assert out["count"] == 1 and int(out["values"][0]) == v
+        assert int(out["hashes"][0]) == O.oracle().blo_hash64_u64(v, 42)
+
+
+@pytest.mark.parametrize("name", ["clean", "broken"])
+def test_kmers_dense_vs_reference_arrays(ctx, golden_arrays, name):
+    A = golden_arrays
+    seq = A[f"small_{name}"]
+    b = ctx.upload(seq)
+    for k in (5, 15, 21, 31, 32):
+        for canon in (0, 1):
+            out = b.kmers(k, seed=7, canonical=bool(canon))
+            ok = A[f"units_{name}_k{k}_c{canon}_ok"]
+            val = A[f"units_{name}_k{k}_c{canon}_val"]
+            assert np.array_equal(out["valid"], ok)
+            assert np.array_equal(out["values"], val)
+            exp_h = np.array([O.oracle().blo_hash64_u64(int(v), 7) if o else 0 for v, o in zip(val, ok)], np.uint64)
+            assert np.array_equal(out["hashes"], exp_h)
+            assert out["count"] == int(ok.sum()) and out["xor_hash"] == O.xor_reduce(exp_h)
+
+
+@pytest.mark.parametrize("name", ["clean_one", "broken_one", "clean_reads150", "broken_reads150", "clean_ragged", "broken_ragged"])
+def test_minimizers_and_super_kmers_vs_golden(ctx, golden_arrays, name):
+    A = golden_arrays
+    seq, b = _golden_batch(ctx, A, name)
+    for (unit, w, seed, canon) in MM_CASES:
+        exp = A[f"mm_{name}_u{unit}_w{w}_s{seed}_c{canon}"]
+        got = b.minimizers(unit, w, seed=seed, canonical=bool(canon))
+        assert got["count"] == len(exp), (name, unit, w)
+        assert np.array_equal(got["values"], exp[:, 0]) and np.array_equal(got["positions"], exp[:, 1]) and np.array_equal(got["hashes"], exp[:, 2])
+        assert got["xor_hash"] == O.xor_reduce(exp[:, 2]) and got["xor_pos"] == O.xor_reduce(exp[:, 1]) and got["xor_value"] == O.xor_reduce(exp[:, 0])
+    for (k, m, seed, canon) in SK_CASES:
+        exp = A[f"sk_{name}_k{k}_m{m}_s{seed}_c{canon}"]
+        got = b.super_kmers(k, m, seed=seed, canonical=bool(canon))
+        assert got["count"] == len(exp) and got["aux"] == len(exp)
+        assert np.array_equal(got["minimizers"], exp[:, 0]) and np.array_equal(got["first_pos"], exp[:, 1])
+        assert np.array_equal(got["mm_pos"].astype(np.uint64), exp[:, 2]) and np.array_equal(got["sizes"].astype(np.uint64), exp[:, 3])
+        assert np.array_equal(got["hashes"], exp[:, 4])
+
+
+def test_one_mib_reference_digests(ctx, golden_kats):
+    D = golden_kats["digests_1MiB_seed42"]
+    n = 1 << 20
+    b = ctx.synth(42, n)
+    for canon in (0, 1):
+        d = b.kmers(21, canonical=bool(canon), drop_last=True, arrays=False)
+        assert (d["count"], d["xor_value"]) == (D[f"k21_canon{canon}_idiom"]["count"], D[f"k21_canon{canon}_idiom"]["xor_value"])
+    for key, drop in (("k31_canon1_complete_seed0", False), ("k31_canon1_idiom_seed0", True)):
+        d = b.kmers(31, seed=0, canonical=True, drop_last=drop, arrays=False)
+        assert (d["count"], d["xor_value"], d["xor_hash"], d["sum_hash"]) == (D[key]["count"], D[key]["xor_value"], D[key]["xor_hash"], D[key]["sum_hash"])
+    assert b.syncmers(31, 11, 0, 20, canonical=True, drop_last=True, positions=False)["count"] == D["syncmer_k31_s11_0_20_canon1_idiom"]
+    assert b.syncmers(31, 11, 0, 20, canonical=False, drop_last=True, positions=False)["count"] == D["syncmer_k31_s11_0_20_canon0_idiom"]
+    assert b.syncmers(21, 8, 0, 13, canonical=True, drop_last=True, positions=False)["count"] == D["syncmer_k21_s8_0_13_canon1_idiom"]
+    c3 = D["C3_like_reads150_unit31_w11_seed42"]
+    r = ctx.synth(42, c3["n_bases"], 150).minimizers(31, 11, seed=42, canonical=True)
+    assert (r["count"], r["xor_value"], r["xor_hash"], r["xor_pos"]) == (c3["count"], c3["xor_value"], c3["xor_hash"], c3["xor_pos"])
+    c4 = D["C4_like_reads10k_k31_m15_seed42"]
+    g = ctx.synth(42, c4["n_bases"], 10000).super_kmers(31, 15, seed=42, canonical=True)
+    assert (g["count"], g["xor_value"], g["xor_hash"], int(g["sizes"].sum(dtype=np.uint64)), O.xor_reduce(g["first_pos"])) == (
+        c4["count"], c4["xor_minimizer"], c4["xor_hash"], c4["sum_size"], c4["xor_first_pos"])
+
+
+def _random_case(rng, n, flavour):
+    seq = O.synth(int(rng.integers(1, 10**6)), n)
+    if flavour == "lowcomplexity":
+        motif = np.frombuffer([b"A", b"AC", b"AAAT", b"GATTACA"][int(rng.integers(4))], np.uint8)
+        seq = np.resize(motif, n).copy()
+        for p in rng.integers(0, max(n, 1), n // 300 + 1):
+            if n:
+                seq[p] = ord("ACGT"[int(rng.integers(4))])
+    if flavour in ("breaks", "ragged_breaks") and n:
+        for p in rng.integers(0, n, n // 150 + 1):
+            seq[p] = ord("NnRY-"[int(rng.integers(5))])
+    if flavour == "case" and n:
+        idx = rng.integers(0, n, n // 3)
+        seq[idx] = np.frombuffer(b"acgtuU", np.uint8)[rng.integers(0, 6, len(idx))]
+    if flavour.startswith("ragged"):
+        cuts = np.unique(np.concatenate([[0, n], rng.integers(0, n + 1, n // 400 + 3)]))
+        offs = np.sort(np.concatenate([cuts, cuts[1:3]])).astype(np.uint64)  # a few empty sequences too
+    elif flavour == "reads":
+        offs = O.fixed_offsets(n, int(rng.choice([150, 41, 250, 1000])))
+    else:
+        offs = np.array([0, n], np.uint64)
+    return seq, offs
+
+
+@pytest.mark.parametrize("flavour", ["plain", "breaks", "ragged", "ragged_breaks", "reads", "lowcomplexity", "case"])
+def test_all_scans_vs_oracle_random(ctx, flavour):
+    import zlib
+    rng = np.random.default_rng(zlib.crc32(flavour.encode()))
+    for n in (0, 1, 40, 41, 4079, 4081, 20_000, 131_072 + 17):
+        seq, offs = _random_case(rng, n, flavour)
+        b = ctx.upload(seq, offs)
+        for (unit, w, seed, canon) in ((31, 11, 42, 1), (15, 17, 1, 0), (11, 21, 0, 1), (20, 7, 5, 1), (32, 64, 2, 1), (4, 1, 3, 0)):
+            v, p, h = O.minimizers(seq, offs, unit, w, seed, canon, brute=False)
+            got = b.minimizers(unit, w, seed=seed, canonical=bool(canon))
+            assert got["count"] == len(v), (flavour, n, unit, w)
+            assert np.array_equal(got["values"], v) and np.array_equal(got["positions"], p) and np.array_equal(got["hashes"], h)
+        for (k, m, seed, canon) in ((31, 15, 42, 1), (21, 8, 0, 0), (40, 9, 4, 1)):
+            mn, fp, mp, sz, hs = O.super_kmers(seq, offs, k, m, seed, canon)
+            got = b.super_kmers(k, m, seed=seed, canonical=bool(canon))
+            assert got["count"] == len(mn) == got["aux"], (flavour, n, k, m)
+            assert np.array_equal(got["minimizers"], mn) and np.array_equal(got["first_pos"], fp) and np.array_equal(got["hashes"], hs)
+            assert np.array_equal(got["mm_pos"], mp) and np.array_equal(got["sizes"], sz)
+        for (k, s, a, e, canon) in ((31, 11, 0, 20, 1), (31, 11, 0, 20, 0), (21, 8, 0, 13, 1), (15, 15, 0, 0, 1), (32, 12, 3, 9, 1)):
+            for drop in (False, True):
+                cnt, pos = O.syncmers(seq, offs, k, s, a, e, canon, drop_last=drop)
+                got = b.syncmers(k, s, a, e, canonical=bool(canon), drop_last=drop)
+                assert got["count"] == cnt, (flavour, n, k, s, drop)
+                assert np.array_equal(got["positions"], pos) and got["xor_pos"] == O.xor_reduce(pos)
+        for k in (1, 16, 21, 31, 32):
+            val, ok = O.units(seq, offs, k, 1)
+            got = b.kmers(k, seed=9, canonical=True)
+            assert np.array_equal(got["valid"], ok) and np.array_equal(got["values"], val)
+            d = O.kmer_digest(seq, offs, k, True, 9, drop_last=True)
+            g2 = b.kmers(k, seed=9, canonical=True, drop_last=True, arrays=False)
+            assert (g2["count"], g2["xor_value"], g2["xor_hash"], g2["sum_hash"]) == (d["count"], d["xor_value"], d["xor_hash"], d["sum_hash"])
+
+
+def test_capacity_error_reports_the_count(ctx):
+    import biolib_amd
+
+    b = ctx.synth(3, 50_000, 150)
+    full = b.minimizers(31, 11, seed=1, canonical=True)
+    r = biolib_amd.Result()
+    small = ctx.empty_u64(100)
+    with pytest.raises(biolib_amd.BiolibError) as e:
+        b.minimizers_raw(31, 11, 1, biolib_amd.FLAG_CANONICAL | biolib_amd.FLAG_SYNC, values=small, positions=None, hashes=None, capacity=100, result=r)
+    assert e.value.code == -4 and r.count == full["count"]
+    # the first 100 records were still written, in order
+    assert np.array_equal(small.cpu().numpy().view(np.uint64)[:100], full["values"][:100])
+    # invalid arguments fail loudly
+    with pytest.raises(biolib_amd.BiolibError):
+        b.minimizers(33, 11)
+    with pytest.raises(biolib_amd.BiolibError):
+        b.minimizers(31, 65)
+    with pytest.raises(biolib_amd.BiolibError):
+        b.syncmers(33, 11, 0, 22)
+
+
+def test_range_union_equals_whole(ctx):
+    n = 3_000_000
+    b = ctx.synth(11, n, 150)
+    whole = b.minimizers(31, 11, seed=42, canonical=True)
+    rng = np.random.default_rng(5)
+    cuts = [0] + sorted(int(x) for x in rng.integers(1, n, 5)) + [n]
+    parts = [b.minimizers(31, 11, seed=42, canonical=True, first=a, n=e - a) for a, e in zip(cuts[:-1], cuts[1:])]
+    assert sum(p["count"] for p in parts) == whole["count"]
+    assert np.array_equal(np.concatenate([p["positions"] for p in parts]), whole["positions"])
+    assert np.array_equal(np.concatenate([p["hashes"] for p in parts]), whole["hashes"])
+    x = 0
+    for p in parts:
+        x ^= p["xor_hash"]
+    assert x == whole["xor_hash"]
+    sw = b.syncmers(31, 11, 0, 20, canonical=True)
+    sp = [b.syncmers(31, 11, 0, 20, canonical=True, first=a, n=e - a) for a, e in zip(cuts[:-1], cuts[1:])]
+    assert np.array_equal(np.concatenate([p["positions"] for p in sp]), sw["positions"])
+
+
+def test_large_batch_properties_and_oracle_digest(ctx):
+    """64 Mbp of 150-bp reads (>15,000 tiles: exercises the inter-tile look-back): ordered output,
+    per-read structure, digest equal to the multi-threaded CPU oracle."""
+    n, L = 64_000_050, 150
+    b = ctx.synth(42, n, L)
+    got = b.minimizers(31, 11, seed=42, canonical=True)
+    pos = got["positions"].astype(np.int64)
+    assert np.all(np.diff(pos) > 0), "records must be strictly position-ordered"
+    # every read of 150 bp has 110 windows, hence at least one record, and all units lie inside their read
+    reads = pos // L
+    assert np.array_equal(np.unique(reads), np.arange(n // L))
+    assert np.all(pos % L <= L - 31)
+    # hashes are the hashes of the values
+    import biolib_amd
+    idx = np.random.default_rng(0).integers(0, got["count"], 2000)
+    for i in idx:
+        assert biolib_amd.hash64(int(got["values"][i]), 42) == int(got["hashes"][i])
+    seq = b.download()
+    d = O.minimizer_digest(seq, O.fixed_offsets(n, L), 31, 11, 42, True, threads=16)
+    assert (got["count"], got["xor_value"], got["xor_hash"], got["xor_pos"]) == (d["count"], d["xor_value"], d["xor_hash"], d["xor_pos"])
+    # digest-only run (no output arrays) agrees
+    import biolib_amd as B
+    r = b.minimizers_raw(31, 11, 42, B.FLAG_CANONICAL | B.FLAG_SYNC)
+    assert (r.count, r.xor_hash) == (got["count"], got["xor_hash"])
+    # super-k-mers: sizes sum to the number of valid k-mers (every k-mer belongs to exactly one group)
+    b2 = ctx.synth(43, 20_000_000, 10_000)
+    g = b2.super_kmers(31, 15, seed=42, canonical=True)
+    assert int(g["sizes"].sum(dtype=np.uint64)) == (20_000_000 // 10_000) * (10_000 - 30)
+    assert g["aux"] == g["count"] and np.all(np.diff(g["first_pos"].astype(np.int64)) > 0)
+    assert np.all(g["mm_pos"] <= 16) and np.all(g["sizes"] >= 1) and np.all(g["sizes"] <= 17)
+    sy = b2.syncmers(31, 11, 0, 20, canonical=True, positions=False)
+    seq2 = b2.download()
+    cnt, _ = O.syncmers(seq2[:2_000_000], O.fixed_offsets(2_000_000, 10_000), 31, 11, 0, 20, True, threads=16, positions=False)
+    part = b2.syncmers(31, 11, 0, 20, canonical=True, positions=False, first=0, n=2_000_000)
+    assert part["count"] == cnt and sy["count"] > cnt
