@@ -4,6 +4,7 @@
 // -> async copy of the 72-byte result into a pinned slot, all on the context's stream.
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -528,6 +529,7 @@ static int scan_windows(int mode, bl_ctx* c, const bl_batch* b, uint64_t first, 
     p.ticket = c->ticket();
     p.shards = c->shards();
     p.error = c->error();
+    if (const char* ab = std::getenv("BL_ABLATE")) p.ablate = (uint32_t)std::atoi(ab);  // profiling only
     rc = kernel_event(c, true);
     if (rc != BL_OK) return rc;
     hipError_t e = bl::launch_scan(mode, p, c->stream);

@@ -66,7 +66,12 @@ __device__ __forceinline__ unsigned long long pack_status(unsigned long long fla
     return flag | ((unsigned long long)e << 31) | s;
 }
 
-// called by the whole first wave; returns the exclusive prefix (starts, ends) of tile `tile`
+// called by the whole first wave; returns the exclusive prefix (starts, ends) of tile `tile`.
+// One hop inspects LB_DEPTH x 64 predecessors (LB_DEPTH independent loads per lane in flight), so the
+// number of tiles whose prefix is still unknown when a tile arrives — tile rate x visibility latency —
+// is covered in one or two hops even at several hundred tiles per microsecond.
+constexpr int LB_DEPTH = 4;
+
 __device__ __forceinline__ void lookback(const ScanParams& p, uint32_t tile, uint32_t agg_s, uint32_t agg_e, int lane,
                                          uint32_t& excl_s, uint32_t& excl_e)
 {
@@ -80,26 +85,32 @@ __device__ __forceinline__ void lookback(const ScanParams& p, uint32_t tile, uin
     int64_t pos = (int64_t)tile - 1;
     bool done = false;
     for (int hop = 0; hop < (1 << 20) && !done; ++hop) {
-        const int64_t idx = pos - lane;
-        unsigned long long w = FLAG_INC;  // before tile 0: an inclusive prefix of zero
-        unsigned spins = 0;
-        if (idx >= 0) {
-            w = __hip_atomic_load(&p.status[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            while ((w & FLAG_MASK) == 0) {
-                if (++spins > (1u << 22)) { atomicOr(p.error, 1u); break; }
-                __builtin_amdgcn_s_sleep(2);
-                w = __hip_atomic_load(&p.status[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
+        unsigned long long w[LB_DEPTH];
+#pragma unroll
+        for (int j = 0; j < LB_DEPTH; ++j) {  // issue all loads first
+            const int64_t idx = pos - lane - 64 * j;
+            w[j] = idx >= 0 ? __hip_atomic_load(&p.status[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : FLAG_INC;  // before tile 0: prefix 0
         }
-        const unsigned long long inc_mask = __ballot((w & FLAG_MASK) == FLAG_INC);
-        // lanes closer than the first inclusive prefix contribute their aggregate, that lane its prefix
-        const int first_inc = inc_mask ? __builtin_ctzll(inc_mask) : 64;
-        const bool use = lane <= first_inc && (w & FLAG_MASK) != 0;
-        run_s += wave_sum_u64(use ? (w & CNT_MASK) : 0);
-        run_e += wave_sum_u64(use ? ((w >> 31) & CNT_MASK) : 0);
-        if (inc_mask) done = true;
-        else pos -= 64;
-        if (__ballot((w & FLAG_MASK) == 0)) done = true;  // timed out: error flag is set, leave
+#pragma unroll
+        for (int j = 0; j < LB_DEPTH; ++j) {  // nearest 64 predecessors first
+            if (done) break;
+            const int64_t idx = pos - lane - 64 * j;
+            unsigned spins = 0;
+            while ((w[j] & FLAG_MASK) == 0) {
+                if (++spins > (1u << 22)) { atomicOr(p.error, 1u); break; }
+                __builtin_amdgcn_s_sleep(1);
+                w[j] = __hip_atomic_load(&p.status[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            const unsigned long long inc_mask = __ballot((w[j] & FLAG_MASK) == FLAG_INC);
+            // lanes closer than the first inclusive prefix contribute their aggregate, that lane its prefix
+            const int first_inc = inc_mask ? __builtin_ctzll(inc_mask) : 64;
+            const bool use = lane <= first_inc && (w[j] & FLAG_MASK) != 0;
+            run_s += wave_sum_u64(use ? (w[j] & CNT_MASK) : 0);
+            run_e += wave_sum_u64(use ? ((w[j] >> 31) & CNT_MASK) : 0);
+            if (inc_mask) done = true;
+            if (__ballot((w[j] & FLAG_MASK) == 0)) done = true;  // timed out: error flag is set, leave
+        }
+        pos -= 64 * LB_DEPTH;
     }
     excl_s = (uint32_t)run_s;
     excl_e = (uint32_t)run_e;
@@ -110,51 +121,77 @@ __device__ __forceinline__ void lookback(const ScanParams& p, uint32_t tile, uin
 // ------------------------------------------------------------------------------------------------
 // The fused scan kernel: one workgroup per tile.
 template <int MODE, int W>
-__global__ __launch_bounds__(TPB) void scan_kernel(const ScanParams p)
+__global__ __launch_bounds__(TPB, (MODE == MODE_SYNCMER ? 2 : (W != 0 && W <= 11 ? 6 : 4))) void scan_kernel(const ScanParams p)
 {
-    __shared__ TileShared<MODE> sh;
+    __shared__ TileShared<MODE, W> sh;
     const int tid = threadIdx.x;
-    if (tid == 0) sh.tile = atomicAdd(p.ticket, 1u);
+    if (tid == 0) sh.tile = (p.ablate & 1) ? blockIdx.x : atomicAdd(p.ticket, 1u);
     if (tid < 4) sh.dig[tid] = 0;
     __syncthreads();
     const uint32_t tile = sh.tile;
     const int64_t q0 = p.origin + (int64_t)tile * p.stride;
 
-    phase_load<MODE>(p, sh, tid, q0);
+    phase_load<MODE, W>(p, sh, tid, q0);
     __syncthreads();
 
     ThreadState st;
-    phase_hash<MODE>(p, sh, tid, st);
-    __syncthreads();
+    phase_hash<MODE, W>(p, sh, tid, st);
+    if (W == 0) __syncthreads();  // runtime-w fallback exchanges hashes through LDS
+    if (p.ablate & 32) return;
 
     uint32_t packed;
     if (MODE == MODE_SYNCMER) {
-        phase_sync_fwd<MODE, W>(p, sh, tid, st);
-        if (p.canonical) {
+        uint8_t af[S + 1];
+        phase_sync_fwd<MODE, W>(p, sh, tid, st, nullptr, af);
+        if (W == 0 && p.canonical) {
             __syncthreads();
-            phase_publish_h2<MODE>(sh, tid, st);
+            phase_publish_h2<MODE, W>(sh, tid, st);
             __syncthreads();
         }
-        packed = phase_sync_rev<MODE, W>(p, sh, tid, q0, st);
+        packed = phase_sync_rev<MODE, W>(p, sh, tid, q0, st, nullptr, af);
     } else {
-        packed = phase_window<MODE, W>(p, sh, tid, q0, st);
+        packed = phase_window<MODE, W>(p, sh, tid, q0, st, nullptr);
     }
 
+    if (p.ablate & 16) return;
     uint32_t total;
     const uint32_t excl = block_excl_scan(packed, sh.wave_tot, tid, total);
     const uint32_t n_s = total & 0xffffu, n_e = total >> 16;
-    // note: a tile owns at most H-1 positions, so the counters fit 16 bits with room to spare
+    // note: a tile owns fewer than H positions, so the counters fit 16 bits
 
-    phase_list<MODE>(sh, tid, st, excl & 0xffffu, excl >> 16);
+    phase_list<MODE, W>(sh, tid, st, excl & 0xffffu, excl >> 16);
+    __syncthreads();  // lists complete
+
+    // wave 0 resolves the tile's global offset while the other waves already rebuild their records
     if (tid < 64) {
         uint32_t bs, be;
-        lookback(p, tile, n_s, n_e, tid, bs, be);
+        if (p.ablate & 2) { bs = 0; be = 0; }
+        else lookback(p, tile, n_s, n_e, tid, bs, be);
         if (tid == 0) { sh.base_s = bs; sh.base_e = be; }
     }
-    __syncthreads();
-
     Digest dg{0, 0, 0};
-    phase_emit<MODE>(p, sh, tid, q0, n_s, n_e, sh.base_s, sh.base_e, dg);
+    constexpr int PRE = 3;  // records prepared in registers per thread before the offset is known
+    Record rec[PRE];
+#pragma unroll
+    for (int k = 0; k < PRE; ++k) {
+        const uint32_t r = tid + k * TPB;
+        if (r < n_s && !(p.ablate & 4)) rec[k] = emit_prepare<MODE, W>(p, sh, q0, r, dg);
+    }
+    __syncthreads();  // offset known
+    const uint64_t base_s = sh.base_s, base_e = sh.base_e;
+    if (!(p.ablate & 4)) {
+#pragma unroll
+        for (int k = 0; k < PRE; ++k) {
+            const uint32_t r = tid + k * TPB;
+            if (r < n_s) emit_store<MODE>(p, rec[k], base_s + r);
+        }
+        for (uint32_t r = tid + PRE * TPB; r < n_s; r += TPB) {  // denser than 3 records per thread: rare
+            const Record x = emit_prepare<MODE, W>(p, sh, q0, r, dg);
+            emit_store<MODE>(p, x, base_s + r);
+        }
+        emit_ends<MODE, W>(p, sh, tid, q0, n_e, base_e);
+    }
+    if (p.ablate & 8) return;
 
     // digest: wave reduce -> LDS -> one set of atomics per tile into a shard line
     const unsigned long long xv = wave_xor_u64(dg.xv), xh = wave_xor_u64(dg.xh), xp = wave_xor_u64(dg.xp);

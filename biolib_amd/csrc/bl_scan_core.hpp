@@ -25,7 +25,7 @@
 
 namespace bl {
 
-constexpr int TPB = 256;            // threads per workgroup (4 wave64)
+constexpr int TPB = 512;            // threads per workgroup (8 wave64): one ticket / status word per 8 wave tiles
 constexpr int S = 16;               // window/unit start positions owned by one thread (= one 16-byte load)
 constexpr int H = TPB * S;          // positions hashed per tile
 constexpr int NCHUNK = H / 16 + 8;  // 16-base chunks staged per tile (halo of up to 128 bases)
@@ -40,9 +40,9 @@ struct ScanParams {
     int64_t n_bases;
     const uint32_t* start_bits;  // bit p set <=> p is the first base of a sequence (nullptr: one sequence)
     int64_t win_first, win_end;  // only windows whose first base lies in [win_first, win_end) are reported
-    int64_t origin;              // first hashed position of tile 0 (multiple of 16, may be negative)
+    int64_t origin;              // first hashed position of wave 0 of tile 0 (multiple of 16, may be negative)
     int32_t n_tiles;
-    int32_t stride;              // owned positions per tile (multiple of 16, <= H - w)
+    int32_t stride;              // owned positions per workgroup tile = NWAVE * (1024 - 16*ceil(w/16))
     int32_t unit, w;
     uint32_t seed;
     int32_t canonical;
@@ -61,6 +61,7 @@ struct ScanParams {
     unsigned int* ticket;        // dynamic tile id
     unsigned long long* shards;  // [NSHARD][8] digest accumulators
     unsigned int* error;         // set non-zero on protocol timeout
+    uint32_t ablate;             // profiling only (env BL_ABLATE): bit mask of pipeline stages to skip; 0 in production
 };
 
 // Tile plan shared by the C ABI (bl_capi.hip) and the emulation harness: which positions tile 0
@@ -71,7 +72,7 @@ BL_DEV void plan_scan(int mode, int64_t first, int64_t end, int w, ScanParams& p
 {
     p.win_first = first;
     p.win_end = end;
-    p.stride = H - 16 * ((w + 15) / 16);
+    p.stride = (TPB / 64) * (64 * S - 16 * ((w + 15) / 16));  // NWAVE wave tiles, each owning 1024 - halo positions
     // minimizer modes: the owner of position i decides window i+1, so tile 0 starts one position early
     p.origin = align_down16(mode == MODE_SYNCMER ? first : first - 1);
     p.n_tiles = end > first ? (int32_t)((end - 1 - p.origin) / p.stride + 1) : 0;
@@ -81,6 +82,18 @@ BL_DEV void plan_scan(int mode, int64_t first, int64_t end, int w, ScanParams& p
 // MurmurHash3_x64_128 of one 8-byte little-endian key, low 64 bits (h1).  Closed form of
 // bundled/MurmurHash3.cpp:263-341 for len == 8: nblocks = 0, tail case 8 builds k1 = key.
 BL_DEV uint64_t rotl64(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
+
+// rotl64(x, 31) as two v_alignbit_b32 (the generic form costs two 64-bit shifts and two ORs)
+BL_DEV uint64_t rotl64_31(uint64_t x)
+{
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(BL_CPU_EMU)
+    const uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
+    const uint32_t nh = __builtin_amdgcn_alignbit(hi, lo, 1), nl = __builtin_amdgcn_alignbit(lo, hi, 1);
+    return ((uint64_t)nh << 32) | nl;
+#else
+    return rotl64(x, 31);
+#endif
+}
 
 BL_DEV uint64_t fmix64(uint64_t k)
 {
@@ -95,7 +108,7 @@ BL_DEV uint64_t fmix64(uint64_t k)
 BL_DEV uint64_t murmur64(uint64_t key, uint32_t seed)
 {
     uint64_t k1 = key * 0x87c37b91114253d5ULL;
-    k1 = rotl64(k1, 31);
+    k1 = rotl64_31(k1);
     k1 *= 0x4cf5ad432745937fULL;
     uint64_t h1 = (uint64_t)seed ^ k1;
     uint64_t h2 = (uint64_t)seed;
@@ -250,7 +263,22 @@ BL_DEV Bits128 and_run(Bits128 m, int len)
 // the first is a sequence start.  good/start: bit i = base i0 + i.
 BL_DEV uint32_t window_valid_mask(Bits128 good, Bits128 start, int span)
 {
-    // link[i] = good[i] && !start[i+1]
+    if (span + S <= 63) {  // every bit we look at lives in the low words (k=31,w=11: 57 bits)
+        const uint64_t link = good.lo & ~(start.lo >> 1);  // link[i] = good[i] && !start[i+1]
+        uint64_t v = good.lo >> (span - 1);
+        if (span > 1) {
+            uint64_t r = link;  // r: AND of `have` consecutive link bits
+            int have = 1;
+            const int len = span - 1;
+            while (have < len) {
+                const int step = have < len - have ? have : len - have;
+                r &= r >> step;
+                have += step;
+            }
+            v &= r;
+        }
+        return (uint32_t)v & ((1u << (S + 1)) - 1);
+    }
     Bits128 ns = b128_shr(start, 1);
     Bits128 link{good.lo & ~ns.lo, good.hi & ~ns.hi};
     Bits128 v = b128_shr(good, span - 1);

@@ -1,44 +1,52 @@
-// bl_scan_phases.hpp — the tile pipeline of the fused scan, one function per barrier-delimited
-// phase.  The HIP kernels (bl_kernels.hip) call these with __syncthreads() in between; the CPU
-// emulation harness (tests/emu/) calls the very same functions thread by thread.
+// bl_scan_phases.hpp — the tile pipeline of the fused scan, one function per phase.  The HIP kernels
+// (bl_kernels.hip) call these with barriers in between; the CPU emulation harness (tests/emu/)
+// calls the very same functions thread by thread.
 //
 // Tile geometry (all positions are indices into the batch's base buffer):
-//   tile t hashes the H = 4096 unit start positions [q0, q0+H), q0 = origin + t*stride, 16-aligned.
-//   thread `tid` owns the S = 16 positions i0 .. i0+15, i0 = 16*tid (tile-relative) — exactly the
-//   bases of one coalesced 16-byte load.
-//   minimizer / super-k-mer modes: the thread that owns position i decides, from the argmins of
+//   A workgroup tile is NWAVE independent WAVE TILES.  Wave `wv` of tile t hashes the WH = 1024 unit
+//   start positions [wq0, wq0+1024), wq0 = origin + t*stride + wv*wstride (16-aligned); lane `l`
+//   owns the S = 16 positions 16*l .. 16*l+15 of it — exactly the bases of one coalesced 16-byte load.
+//   Only the first wstride = 1024 - 16*ceil(w/16) positions of a wave tile are OWNED (their records
+//   are reported by this wave); the rest is halo that the next wave tile hashes again (1.6 % extra
+//   work at w = 11), which makes a wave self-sufficient: hashes never leave registers, the halo a
+//   lane needs comes from lanes l+1, l+2 by DPP wave shifts, and no barrier is needed until the
+//   per-wave record counts are combined.
+//   minimizer / super-k-mer modes: the lane that owns position i decides, from the argmins of
 //   windows i and i+1, whether window i+1 starts a new minimizer occurrence and whether window i
-//   ends one.  Only the first `stride` positions of a tile are owned (stride <= H - w), so every
-//   decision sees all the hashes it needs without a second pass over the neighbouring tile.
+//   ends one.
 #pragma once
 #include "bl_scan_core.hpp"
 
 namespace bl {
 
-template <int MODE>
+constexpr int NWAVE = TPB / 64;
+constexpr int WH = 64 * S;      // positions hashed per wave tile
+constexpr int WCHUNK = 64 + 8;  // 16-base chunks staged per wave tile (halo of up to 128 bases)
+
+template <int MODE, int W>
 struct TileShared {
-    uint32_t codes[NCHUNK];        // 2-bit codes, 16 bases per dword, first base most significant
-    uint32_t flags[NCHUNK];        // [15:0] good-base bits, [31:16] sequence-start bits (bit b = base b)
-    uint64_t hash[S][TPB];         // hash[s][t] = hash of the unit at tile position 16*t + s (bank-conflict-free)
-    uint16_t list_a[H];            // compacted: argmin position (minimizer modes) / window position (syncmer)
+    // staged once per workgroup tile, flat over the tile: wave wv's chunk c is entry wv*(wstride/16) + c
+    // (consecutive wave tiles overlap by their halo, so the halo of a wave is the next wave's data)
+    uint32_t codes[NCHUNK];         // 2-bit codes, 16 bases per dword, first base most significant
+    uint32_t flags[NCHUNK];         // [15:0] good-base bits, [31:16] sequence-start bits (bit b = base b)
+    uint64_t hash[W == 0 ? S : 1][W == 0 ? TPB : 1];  // runtime-w fallback only: hash[s][tid]
+    uint16_t list_a[H];             // compacted records: (wave << 12) | wave-relative argmin position
+                                    // (syncmer mode: the k-mer's own position)
     uint16_t list_j[MODE == MODE_SUPERKMER ? H : 1];  // compacted: first window of the occurrence
     uint16_t list_e[MODE == MODE_SUPERKMER ? H : 1];  // compacted: last window of the occurrence
-    uint32_t wave_tot[TPB / 64];
+    uint32_t wave_tot[NWAVE];
     unsigned long long dig[4];
     uint32_t tile;
-    uint32_t base_s, base_e;       // global record offsets of this tile (from the look-back)
+    uint32_t base_s, base_e;        // global record offsets of this tile (from the look-back)
 };
 
 struct ThreadState {
     uint64_t h[S];    // hashes of the owned positions (forward strand for syncmers)
     uint64_t h2[S];   // syncmer: reverse-strand s-mer hashes
-    uint32_t valid;   // bit s: window starting at owned position s is valid (bits 0..S)
     uint32_t emit;    // bit s: a record starts at window s+1 (minimizer modes) / window s is a syncmer
     uint32_t endm;    // bit s: an occurrence ends at window s (super-k-mer mode)
     uint32_t strand;  // syncmer: bit s set <=> reverse strand is canonical for the k-mer at s
-    uint32_t lastk;   // syncmer: bit s set <=> the k-mer at s ends its sequence
-    uint64_t apk[2];  // minimizer modes: argmin (thread-relative element index) of window s+1 in byte s (8 per word)
-    uint8_t a[S];     // syncmer: offset of the forward-strand minimum inside k-mer s (compile-time indexed only)
+    uint64_t apk0, apk1;  // minimizer modes: argmin (lane-relative element index) of window s+1 in byte s (8 per word)
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -46,6 +54,7 @@ struct ThreadState {
 struct alignas(16) Vec16 {
     uint32_t x, y, z, w;
 };
+
 BL_DEV void stage_chunk(const ScanParams& p, uint32_t* codes, uint32_t* flags, int c, int64_t q0)
 {
     const int64_t g = q0 + 16 * (int64_t)c;
@@ -71,20 +80,27 @@ BL_DEV void stage_chunk(const ScanParams& p, uint32_t* codes, uint32_t* flags, i
     flags[c] = (~bad & 0xffffu) | (start << 16);
 }
 
-template <int MODE>
-BL_DEV void phase_load(const ScanParams& p, TileShared<MODE>& sh, int tid, int64_t q0)
+// global position of the first hashed position of wave `wv` of the tile that starts at q0
+BL_DEV int64_t wave_origin(const ScanParams& p, int64_t q0, int wv) { return q0 + (int64_t)wv * (p.stride / NWAVE); }
+
+// first staged chunk of wave `wv` inside the flat per-tile arrays
+BL_DEV int wave_chunk0(const ScanParams& p, int wv) { return wv * (p.stride / NWAVE / 16); }
+
+template <int MODE, int W>
+BL_DEV void phase_load(const ScanParams& p, TileShared<MODE, W>& sh, int tid, int64_t q0)
 {
-    stage_chunk(p, sh.codes, sh.flags, tid, q0);
-    if (tid < NCHUNK - TPB) stage_chunk(p, sh.codes, sh.flags, TPB + tid, q0);
+    const int needed = wave_chunk0(p, NWAVE - 1) + WCHUNK;  // <= NCHUNK; the last wave's halo ends the tile
+    if (tid < needed) stage_chunk(p, sh.codes, sh.flags, tid, q0);
+    if (TPB + tid < needed) stage_chunk(p, sh.codes, sh.flags, TPB + tid, q0);  // a few lanes of wave 0 only
 }
 
-// good / start bit-vectors for the thread's positions i0 .. i0+127
-BL_DEV void gather_flags(const uint32_t* flags, int tid, Bits128& good, Bits128& start)
+// good / start bit-vectors for the lane's positions i0 .. i0+127 (bit i = wave position 16*lane + i)
+BL_DEV void gather_flags(const uint32_t* flags, int lane, Bits128& good, Bits128& start)
 {
     uint64_t g[2] = {0, 0}, s[2] = {0, 0};
     BL_UNROLL
     for (int c = 0; c < 8; ++c) {
-        const uint32_t f = flags[tid + c];  // tid + 7 <= 262 < NCHUNK
+        const uint32_t f = flags[lane + c];  // lane + 7 <= 70 < WCHUNK
         g[c >> 2] |= (uint64_t)(f & 0xffffu) << (16 * (c & 3));
         s[c >> 2] |= (uint64_t)(f >> 16) << (16 * (c & 3));
     }
@@ -93,11 +109,13 @@ BL_DEV void gather_flags(const uint32_t* flags, int tid, Bits128& good, Bits128&
 }
 
 // ------------------------------------------------------------------------------------------------
-// Phase 2: roll the owned 16 units in registers, hash them, publish the hashes to LDS.
-template <int MODE>
-BL_DEV void phase_hash(const ScanParams& p, TileShared<MODE>& sh, int tid, ThreadState& st)
+// Phase 2: roll the owned 16 units in registers and hash them.
+template <int MODE, int W>
+BL_DEV void phase_hash(const ScanParams& p, TileShared<MODE, W>& sh, int tid, ThreadState& st)
 {
-    const uint32_t c0 = sh.codes[tid], c1 = sh.codes[tid + 1], c2 = sh.codes[tid + 2];
+    const int wv = tid >> 6, lane = tid & 63;
+    const uint32_t* wcodes = sh.codes + wave_chunk0(p, wv);
+    const uint32_t c0 = wcodes[lane], c1 = wcodes[lane + 1], c2 = wcodes[lane + 2];
     Roller r;
     roller_start(r, c0, c1, c2, p.unit);
     if (MODE == MODE_SYNCMER) {
@@ -123,28 +141,75 @@ BL_DEV void phase_hash(const ScanParams& p, TileShared<MODE>& sh, int tid, Threa
             st.h[s] = murmur64(v, p.seed);
         }
     }
-    BL_UNROLL
-    for (int s = 0; s < S; ++s) sh.hash[s][tid] = st.h[s];
+    if (W == 0) {  // runtime-w fallback keeps the hashes in LDS
+        BL_UNROLL
+        for (int s = 0; s < S; ++s) sh.hash[s][tid] = st.h[s];
+    }
 }
 
-// syncmer mode, second pass over the same LDS array
-template <int MODE>
-BL_DEV void phase_publish_h2(TileShared<MODE>& sh, int tid, const ThreadState& st)
+// runtime-w fallback, syncmer mode: second pass over the same LDS array
+template <int MODE, int W>
+BL_DEV void phase_publish_h2(TileShared<MODE, W>& sh, int tid, const ThreadState& st)
 {
     BL_UNROLL
     for (int s = 0; s < S; ++s) sh.hash[s][tid] = st.h2[s];
 }
 
-// elements S .. S+NE-1 of the thread's window input come from the following threads' hashes
-template <int MODE, int NE>
-BL_DEV void gather_halo(const TileShared<MODE>& sh, int tid, uint64_t* e)
+// ------------------------------------------------------------------------------------------------
+// Halo exchange: elements S .. S+NE-1 of a lane's window input are the first hashes of the lanes
+// that follow it in the wave.  On the GPU this is a DPP wave shift (v_mov_b32_dpp wave_shl:1 —
+// lane l reads lane l+1, lane 63 keeps its own value); the emulation reads the neighbour's state.
+// The last ceil(NE/16) lanes of a wave receive garbage: they own no window (stride <= 1024 - w).
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(BL_CPU_EMU)
+BL_DEV uint64_t lane_next(uint64_t v)
 {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, 0x130, 0xf, 0xf, false);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(v >> 32), 0x130, 0xf, 0xf, false);
+    return ((uint64_t)hi << 32) | lo;
+}
+#endif
+
+template <int NE, bool SECOND>
+BL_DEV void gather_halo(const ThreadState* all, int tid, const ThreadState& st, uint64_t* e)
+{
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(BL_CPU_EMU)
+    (void)all;
+    (void)tid;
+    uint64_t n1[S];
     BL_UNROLL
-    for (int x = 0; x < NE; ++x) {
-        int t = tid + 1 + (x >> 4);
-        t = t < TPB ? t : TPB - 1;  // beyond the tile: never owned, any value will do
-        e[S + x] = sh.hash[x & 15][t];
+    for (int x = 0; x < S; ++x) {
+        if (x < NE || x < NE - 16 || x < NE - 32 || x < NE - 48) n1[x] = lane_next(SECOND ? st.h2[x] : st.h[x]);
+        if (x < NE) e[S + x] = n1[x];
     }
+    if (NE > 16) {
+        uint64_t n2[S];
+        BL_UNROLL
+        for (int x = 0; x < S; ++x) {
+            if (x < NE - 16 || x < NE - 32 || x < NE - 48) n2[x] = lane_next(n1[x]);
+            if (x < NE - 16) e[2 * S + x] = n2[x];
+        }
+        if (NE > 32) {
+            uint64_t n3[S];
+            BL_UNROLL
+            for (int x = 0; x < S; ++x) {
+                if (x < NE - 32 || x < NE - 48) n3[x] = lane_next(n2[x]);
+                if (x < NE - 32) e[3 * S + x] = n3[x];
+            }
+            if (NE > 48) {
+                BL_UNROLL
+                for (int x = 0; x < S; ++x)
+                    if (x < NE - 48) e[4 * S + x] = lane_next(n3[x]);
+            }
+        }
+    }
+#else
+    const int lane = tid & 63;
+    for (int x = 0; x < NE; ++x) {
+        const int nb = lane + 1 + (x >> 4);
+        e[S + x] = nb < 64 ? (SECOND ? all[tid + 1 + (x >> 4)].h2[x & 15] : all[tid + 1 + (x >> 4)].h[x & 15]) : 0xDEADBEEFDEADBEEFull;
+    }
+    (void)st;
+#endif
 }
 
 // bit s set <=> lo <= s < hi, for s in 0..S
@@ -156,16 +221,17 @@ BL_DEV uint32_t range_mask(int64_t lo, int64_t hi)
 }
 
 // runtime-w fallback: argmin by direct scan of the LDS hashes (slow path for unlisted window sizes)
-template <int MODE, bool LEFT>
-BL_DEV void window_argmin_lds(const TileShared<MODE>& sh, int tid, int w, int nw, uint8_t* a)
+template <int MODE, int W, bool LEFT>
+BL_DEV void window_argmin_lds(const TileShared<MODE, W>& sh, int tid, int w, int nw, uint8_t* a)
 {
+    const int wbase = tid & ~63;  // first thread of this wave
     for (int i = 0; i < nw; ++i) {
         uint64_t best = 0;
         int arg = 0;
         for (int x = 0; x < w; ++x) {
-            int pos = 16 * tid + i + x;
-            pos = pos < H ? pos : H - 1;
-            const uint64_t v = sh.hash[pos & 15][pos >> 4];
+            int pos = 16 * (tid & 63) + i + x;  // wave-relative position
+            pos = pos < WH ? pos : WH - 1;      // beyond the wave tile: never owned
+            const uint64_t v = sh.hash[pos & 15][wbase + (pos >> 4)];
             const bool take = x == 0 || (LEFT ? v < best : v <= best);
             if (take) { best = v; arg = i + x; }
         }
@@ -173,74 +239,77 @@ BL_DEV void window_argmin_lds(const TileShared<MODE>& sh, int tid, int w, int nw
     }
 }
 
+// bit s: lane owns wave position 16*lane + s
+BL_DEV uint32_t owned_mask(const ScanParams& p, int lane)
+{
+    const int own = p.stride / NWAVE - 16 * lane;
+    return own >= S ? 0xffffu : (own > 0 ? (1u << own) - 1 : 0u);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Phase 3 (minimizer / super-k-mer): window argmins, validity, start/end decisions.
 // Returns the packed per-thread counts: starts | ends << 16.
 template <int MODE, int W>
-BL_DEV uint32_t phase_window(const ScanParams& p, const TileShared<MODE>& sh, int tid, int64_t q0, ThreadState& st)
+BL_DEV uint32_t phase_window(const ScanParams& p, const TileShared<MODE, W>& sh, int tid, int64_t q0, ThreadState& st,
+                             const ThreadState* all)
 {
+    const int wv = tid >> 6, lane = tid & 63;
     const int w = W ? W : p.w;
     uint8_t a[S + 1];
     if (W) {
         uint64_t e[S + (W ? W : 1)];
         BL_UNROLL
         for (int s = 0; s < S; ++s) e[s] = st.h[s];
-        gather_halo<MODE, (W ? W : 1)>(sh, tid, e);
+        gather_halo<(W ? W : 1), false>(all, tid, st, e);
         window_argmin<S + 1, (W ? W : 1), true>(e, a);
     } else {
-        window_argmin_lds<MODE, true>(sh, tid, w, S + 1, a);
+        window_argmin_lds<MODE, W, true>(sh, tid, w, S + 1, a);
     }
     Bits128 good, start;
-    gather_flags(sh.flags, tid, good, start);
+    gather_flags(sh.flags + wave_chunk0(p, wv), lane, good, start);
     uint32_t valid = window_valid_mask(good, start, p.unit + w - 1);
     // windows outside the requested range: never reported; in super-k-mer mode they also cut groups
-    const int64_t j0 = q0 + 16 * (int64_t)tid;  // global position of the thread's window 0
+    const int64_t j0 = wave_origin(p, q0, wv) + 16 * (int64_t)lane;  // global position of the lane's window 0
     const uint32_t inrange = range_mask(p.win_first - j0, p.win_end - j0);
     if (MODE == MODE_SUPERKMER) valid &= inrange;
     uint32_t differ = 0;  // bit s: argmin of window s+1 is a different occurrence than window s
-    uint64_t apk0 = 0, apk1 = 0;
+    uint32_t apk[4] = {0, 0, 0, 0};
     BL_UNROLL
     for (int s = 0; s < S; ++s) {
         if (a[s + 1] != a[s]) differ |= 1u << s;
-        if (s < 8) apk0 |= (uint64_t)a[s + 1] << (8 * s);
-        else apk1 |= (uint64_t)a[s + 1] << (8 * (s - 8));
+        apk[s >> 2] |= (uint32_t)a[s + 1] << (8 * (s & 3));
     }
-    st.apk[0] = apk0;
-    st.apk[1] = apk1;
+    st.apk0 = ((uint64_t)apk[1] << 32) | apk[0];  // register pairs: no data movement
+    st.apk1 = ((uint64_t)apk[3] << 32) | apk[2];
     const uint32_t v0 = valid & 0xffffu, v1 = (valid >> 1) & 0xffffu;
-    uint32_t owned = 0;
-    const int own = p.stride - 16 * tid;  // owned positions of this thread: s < own
-    if (own >= S) owned = 0xffffu;
-    else if (own > 0) owned = (1u << own) - 1;
-    st.valid = valid;
+    const uint32_t owned = owned_mask(p, lane);
     st.emit = v1 & (~v0 | differ) & owned & ((inrange >> 1) & 0xffffu);  // window s+1 starts an occurrence
     st.endm = MODE == MODE_SUPERKMER ? (v0 & (~v1 | differ) & owned) : 0;  // window s ends one
     return (uint32_t)__builtin_popcount(st.emit) | ((uint32_t)__builtin_popcount(st.endm) << 16);
 }
 
-// Phase 3 (syncmer), two sub-phases around the republish of the reverse-strand hashes.
+// Phase 3 (syncmer): leftmost minimum over the forward s-mer hashes, rightmost over the reverse ones.
+// `pass` is only used by the runtime-w fallback, which republishes the LDS hashes between the two.
 template <int MODE, int W>
-BL_DEV void phase_sync_fwd(const ScanParams& p, const TileShared<MODE>& sh, int tid, ThreadState& st)
+BL_DEV void phase_sync_fwd(const ScanParams& p, const TileShared<MODE, W>& sh, int tid, ThreadState& st, const ThreadState* all,
+                           uint8_t* af)
 {
     if (W) {
         uint64_t e[S + (W ? W : 1)];
         BL_UNROLL
         for (int s = 0; s < S; ++s) e[s] = st.h[s];
-        gather_halo<MODE, (W ? W : 1)>(sh, tid, e);
-        uint8_t a[S + 1];
-        window_argmin<S, (W ? W : 1), true>(e, a);
-        BL_UNROLL
-        for (int s = 0; s < S; ++s) st.a[s] = (uint8_t)(a[s] - s);  // offset of the leftmost forward minimum
+        gather_halo<(W ? W : 1), false>(all, tid, st, e);
+        window_argmin<S, (W ? W : 1), true>(e, af);
     } else {
-        uint8_t a[S + 1];
-        window_argmin_lds<MODE, true>(sh, tid, p.w, S, a);
-        for (int s = 0; s < S; ++s) st.a[s] = (uint8_t)(a[s] - s);
+        window_argmin_lds<MODE, W, true>(sh, tid, p.w, S, af);
     }
 }
 
 template <int MODE, int W>
-BL_DEV uint32_t phase_sync_rev(const ScanParams& p, const TileShared<MODE>& sh, int tid, int64_t q0, ThreadState& st)
+BL_DEV uint32_t phase_sync_rev(const ScanParams& p, const TileShared<MODE, W>& sh, int tid, int64_t q0, ThreadState& st,
+                               const ThreadState* all, const uint8_t* af)
 {
+    const int wv = tid >> 6, lane = tid & 63;
     const int w = W ? W : p.w;
     const int k = p.unit + w - 1;
     uint8_t ar[S + 1];
@@ -249,34 +318,33 @@ BL_DEV uint32_t phase_sync_rev(const ScanParams& p, const TileShared<MODE>& sh, 
             uint64_t e[S + (W ? W : 1)];
             BL_UNROLL
             for (int s = 0; s < S; ++s) e[s] = st.h2[s];
-            gather_halo<MODE, (W ? W : 1)>(sh, tid, e);
+            gather_halo<(W ? W : 1), true>(all, tid, st, e);
             window_argmin<S, (W ? W : 1), false>(e, ar);
         } else {
-            window_argmin_lds<MODE, false>(sh, tid, w, S, ar);
+            window_argmin_lds<MODE, W, false>(sh, tid, w, S, ar);
         }
     }
     Bits128 good, start;
-    gather_flags(sh.flags, tid, good, start);
+    gather_flags(sh.flags + wave_chunk0(p, wv), lane, good, start);
     const uint32_t valid = window_valid_mask(good, start, k) & 0xffffu;
-    const int64_t j0 = q0 + 16 * (int64_t)tid;
+    const int64_t j0 = wave_origin(p, q0, wv) + 16 * (int64_t)lane;
+    const uint32_t keepable = valid & owned_mask(p, lane) & range_mask(p.win_first - j0, p.win_end - j0);
     uint32_t emit = 0;
     BL_UNROLL
     for (int s = 0; s < S; ++s) {
         // canonical k-mer on the reverse strand: its j-th m-mer from the left is the reverse complement
         // of the forward m-mer at W-1-j, and "leftmost" becomes "rightmost" 
-        int off = st.a[s];
+        int off = af[s] - s;
         if (p.canonical && ((st.strand >> s) & 1)) off = (w - 1) - (ar[s] - s);
         const bool hit = off == p.soff || off == p.eoff;  // syncmer_sampler.hpp:130-137
-        const int64_t j = j0 + s;
-        bool keep = hit && ((valid >> s) & 1) && 16 * tid + s < p.stride && j >= p.win_first && j < p.win_end;
+        bool keep = hit && ((keepable >> s) & 1);
         if (keep && p.drop_last) {  // the k-mer that ends its sequence is never examined by the idiom (Q1)
             const int nxt = s + k;  // < 128
             const bool seq_end = (nxt < 64 ? (start.lo >> nxt) : (start.hi >> (nxt - 64))) & 1;
-            keep = !(seq_end || j + k >= p.n_bases);
+            keep = !(seq_end || j0 + s + k >= p.n_bases);
         }
         if (keep) emit |= 1u << s;
     }
-    st.valid = valid;
     st.emit = emit;
     st.endm = 0;
     return (uint32_t)__builtin_popcount(emit);
@@ -284,20 +352,22 @@ BL_DEV uint32_t phase_sync_rev(const ScanParams& p, const TileShared<MODE>& sh, 
 
 // ------------------------------------------------------------------------------------------------
 // Phase 4: tile-local compaction into LDS lists (position-ordered: rank = exclusive prefix + local index)
-template <int MODE>
-BL_DEV void phase_list(TileShared<MODE>& sh, int tid, const ThreadState& st, uint32_t excl_s, uint32_t excl_e)
+template <int MODE, int W>
+BL_DEV void phase_list(TileShared<MODE, W>& sh, int tid, const ThreadState& st, uint32_t excl_s, uint32_t excl_e)
 {
+    const int wv = tid >> 6, lane = tid & 63;
+    const uint32_t tag = (uint32_t)wv << 12;  // which wave's staged codes the record refers to
     uint32_t m = st.emit;
     uint32_t r = excl_s;
     while (m) {
         const int s = __builtin_ctz(m);
         m &= m - 1;
         if (MODE == MODE_SYNCMER) {
-            sh.list_a[r] = (uint16_t)(16 * tid + s);
+            sh.list_a[r] = (uint16_t)(tag | (uint32_t)(16 * lane + s));
         } else {
-            const uint32_t arel = (uint32_t)((s < 8 ? st.apk[0] : st.apk[1]) >> (8 * (s & 7))) & 0xffu;
-            sh.list_a[r] = (uint16_t)(16 * tid + arel);
-            if (MODE == MODE_SUPERKMER) sh.list_j[r] = (uint16_t)(16 * tid + s + 1);
+            const uint32_t arel = (uint32_t)((s < 8 ? st.apk0 : st.apk1) >> (8 * (s & 7))) & 0xffu;
+            sh.list_a[r] = (uint16_t)(tag | (16 * lane + arel));
+            if (MODE == MODE_SUPERKMER) sh.list_j[r] = (uint16_t)(tag | (uint32_t)(16 * lane + s + 1));
         }
         ++r;
     }
@@ -307,7 +377,7 @@ BL_DEV void phase_list(TileShared<MODE>& sh, int tid, const ThreadState& st, uin
         while (m) {
             const int s = __builtin_ctz(m);
             m &= m - 1;
-            sh.list_e[r] = (uint16_t)(16 * tid + s);
+            sh.list_e[r] = (uint16_t)(tag | (uint32_t)(16 * lane + s));
             ++r;
         }
     }
@@ -315,46 +385,82 @@ BL_DEV void phase_list(TileShared<MODE>& sh, int tid, const ThreadState& st, uin
 
 // ------------------------------------------------------------------------------------------------
 // Phase 5: materialise the records densely (thread r handles record r, r+TPB, ...) with coalesced
-// stores, and fold them into the thread's digest accumulators.
+// stores: the unit is re-extracted from the staged codes and re-hashed (0.13 records per base — cheaper
+// than keeping 8 bytes of hash per position in LDS), and folded into the thread's digest accumulators.
 struct Digest {
     unsigned long long xv, xh, xp;
 };
 
-template <int MODE>
-BL_DEV void phase_emit(const ScanParams& p, const TileShared<MODE>& sh, int tid, int64_t q0, uint32_t n_s, uint32_t n_e,
-                       uint64_t base_s, uint64_t base_e, Digest& dg)
+// One record, ready to be stored once the tile's global offset is known.
+struct Record {
+    uint64_t v, h, pos, first;
+    uint32_t mmpos;
+};
+
+// 5a: everything that does not need the global offset (runs while wave 0 is still in the look-back)
+template <int MODE, int W>
+BL_DEV Record emit_prepare(const ScanParams& p, const TileShared<MODE, W>& sh, int64_t q0, uint32_t r, Digest& dg)
 {
-    for (uint32_t r = tid; r < n_s; r += TPB) {
-        const int ap = sh.list_a[r];
-        const uint64_t g = base_s + r;
-        const uint64_t pos = (uint64_t)(q0 + ap);
-        if (MODE == MODE_SYNCMER) {
-            dg.xp ^= pos;
-            if (p.out_pos && g < p.capacity) p.out_pos[g] = pos;
-        } else {
-            const uint64_t h = sh.hash[ap & 15][ap >> 4];
-            const uint64_t v = extract_unit(sh.codes, ap, p.unit, p.canonical);
-            dg.xv ^= v; dg.xh ^= h; dg.xp ^= pos;
-            if (g < p.capacity) {
-                if (p.out_value) p.out_value[g] = v;
-                if (p.out_hash) p.out_hash[g] = h;
-                if (MODE == MODE_SUPERKMER) {
-                    const int j = sh.list_j[r];
-                    if (p.out_first) p.out_first[g] = (uint64_t)(q0 + j);
-                    if (p.out_mmpos) p.out_mmpos[g] = (uint8_t)(ap - j);  // super_kmer_view.hpp:132
-                    if (p.out_pos) p.out_pos[g] = pos;
-                } else if (p.out_pos) {
-                    p.out_pos[g] = pos;
-                }
-            }
+    Record rec{0, 0, 0, 0, 0};
+    const uint32_t ent = sh.list_a[r];
+    const int wv = ent >> 12, ap = ent & 0xfff;
+    const int64_t wq0 = wave_origin(p, q0, wv);
+    rec.pos = (uint64_t)(wq0 + ap);
+    dg.xp ^= rec.pos;
+    if (MODE != MODE_SYNCMER) {
+        rec.v = extract_unit(sh.codes + wave_chunk0(p, wv), ap, p.unit, p.canonical);
+        rec.h = murmur64(rec.v, p.seed);
+        dg.xv ^= rec.v;
+        dg.xh ^= rec.h;
+        if (MODE == MODE_SUPERKMER) {
+            const int j = sh.list_j[r] & 0xfff;
+            rec.first = (uint64_t)(wq0 + j);
+            rec.mmpos = (uint32_t)(ap - j);  // super_kmer_view.hpp:132
         }
     }
+    return rec;
+}
+
+// 5b: coalesced stores (thread r writes record r)
+template <int MODE>
+BL_DEV void emit_store(const ScanParams& p, const Record& rec, uint64_t g)
+{
+    if (g >= p.capacity) return;
+    if (MODE == MODE_SYNCMER) {
+        if (p.out_pos) p.out_pos[g] = rec.pos;
+        return;
+    }
+    if (p.out_value) p.out_value[g] = rec.v;
+    if (p.out_hash) p.out_hash[g] = rec.h;
+    if (p.out_pos) p.out_pos[g] = rec.pos;
+    if (MODE == MODE_SUPERKMER) {
+        if (p.out_first) p.out_first[g] = rec.first;
+        if (p.out_mmpos) p.out_mmpos[g] = (uint8_t)rec.mmpos;
+    }
+}
+
+template <int MODE, int W>
+BL_DEV void emit_ends(const ScanParams& p, const TileShared<MODE, W>& sh, int tid, int64_t q0, uint32_t n_e, uint64_t base_e)
+{
     if (MODE == MODE_SUPERKMER) {
         for (uint32_t r = tid; r < n_e; r += TPB) {
             const uint64_t g = base_e + r;
-            if (p.out_last && g < p.capacity) p.out_last[g] = (uint64_t)(q0 + sh.list_e[r]);
+            const uint32_t ent = sh.list_e[r];
+            if (p.out_last && g < p.capacity) p.out_last[g] = (uint64_t)(wave_origin(p, q0, ent >> 12) + (ent & 0xfff));
         }
     }
+}
+
+// whole phase in one go (emulation harness; the kernel interleaves 5a with the look-back)
+template <int MODE, int W>
+BL_DEV void phase_emit(const ScanParams& p, const TileShared<MODE, W>& sh, int tid, int64_t q0, uint32_t n_s, uint32_t n_e,
+                       uint64_t base_s, uint64_t base_e, Digest& dg)
+{
+    for (uint32_t r = tid; r < n_s; r += TPB) {
+        const Record rec = emit_prepare<MODE, W>(p, sh, q0, r, dg);
+        emit_store<MODE>(p, rec, base_s + r);
+    }
+    emit_ends<MODE, W>(p, sh, tid, q0, n_e, base_e);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -37,23 +37,25 @@ std::vector<uint32_t> make_start_bits(uint64_t n_bases, const uint64_t* offsets,
 template <int MODE, int W>
 void run_tiles(const ScanParams& p, unsigned long long* result)
 {
-    auto* sh = new TileShared<MODE>();
+    auto* sh = new TileShared<MODE, W>();
     std::vector<ThreadState> st(TPB);
     std::vector<uint32_t> packed(TPB), excl(TPB);
+    std::vector<uint8_t> af(TPB * (S + 1));
     uint64_t base_s = 0, base_e = 0;
     Digest dg{0, 0, 0};
     for (int tile = 0; tile < p.n_tiles; ++tile) {
         std::memset(sh, 0xA5, sizeof(*sh));  // poison: nothing may depend on stale LDS contents
+        std::memset(st.data(), 0x5A, st.size() * sizeof(ThreadState));
         const int64_t q0 = p.origin + (int64_t)tile * p.stride;
-        for (int tid = 0; tid < TPB; ++tid) phase_load<MODE>(p, *sh, tid, q0);
-        for (int tid = 0; tid < TPB; ++tid) phase_hash<MODE>(p, *sh, tid, st[tid]);
+        for (int tid = 0; tid < TPB; ++tid) phase_load<MODE, W>(p, *sh, tid, q0);
+        for (int tid = 0; tid < TPB; ++tid) phase_hash<MODE, W>(p, *sh, tid, st[tid]);
         if (MODE == MODE_SYNCMER) {
-            for (int tid = 0; tid < TPB; ++tid) phase_sync_fwd<MODE, W>(p, *sh, tid, st[tid]);
-            if (p.canonical)
-                for (int tid = 0; tid < TPB; ++tid) phase_publish_h2<MODE>(*sh, tid, st[tid]);
-            for (int tid = 0; tid < TPB; ++tid) packed[tid] = phase_sync_rev<MODE, W>(p, *sh, tid, q0, st[tid]);
+            for (int tid = 0; tid < TPB; ++tid) phase_sync_fwd<MODE, W>(p, *sh, tid, st[tid], st.data(), &af[tid * (S + 1)]);
+            if (W == 0 && p.canonical)
+                for (int tid = 0; tid < TPB; ++tid) phase_publish_h2<MODE, W>(*sh, tid, st[tid]);
+            for (int tid = 0; tid < TPB; ++tid) packed[tid] = phase_sync_rev<MODE, W>(p, *sh, tid, q0, st[tid], st.data(), &af[tid * (S + 1)]);
         } else {
-            for (int tid = 0; tid < TPB; ++tid) packed[tid] = phase_window<MODE, W>(p, *sh, tid, q0, st[tid]);
+            for (int tid = 0; tid < TPB; ++tid) packed[tid] = phase_window<MODE, W>(p, *sh, tid, q0, st[tid], st.data());
         }
         uint32_t run = 0;
         for (int tid = 0; tid < TPB; ++tid) {
@@ -61,8 +63,8 @@ void run_tiles(const ScanParams& p, unsigned long long* result)
             run += packed[tid];
         }
         const uint32_t n_s = run & 0xffffu, n_e = run >> 16;
-        for (int tid = 0; tid < TPB; ++tid) phase_list<MODE>(*sh, tid, st[tid], excl[tid] & 0xffffu, excl[tid] >> 16);
-        for (int tid = 0; tid < TPB; ++tid) phase_emit<MODE>(p, *sh, tid, q0, n_s, n_e, base_s, base_e, dg);
+        for (int tid = 0; tid < TPB; ++tid) phase_list<MODE, W>(*sh, tid, st[tid], excl[tid] & 0xffffu, excl[tid] >> 16);
+        for (int tid = 0; tid < TPB; ++tid) phase_emit<MODE, W>(p, *sh, tid, q0, n_s, n_e, base_s, base_e, dg);
         base_s += n_s;
         base_e += n_e;
     }

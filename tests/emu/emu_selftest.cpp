@@ -166,7 +166,7 @@ int main(int argc, char** argv)
     }
     const char alphabet_breaks[] = "NnRYK-*X\x80\xff@`bBfF";
     for (int round = 0; round < rounds; ++round) {
-        const uint64_t sizes[] = {0, 1, 15, 16, 17, 31, 40, 41, 42, 150, 1000, 4064, 4079, 4080, 4081, 4095, 4096, 4097, 8160, 8161, 9000, 12345};
+        const uint64_t sizes[] = {0, 1, 15, 16, 17, 31, 40, 41, 42, 150, 1000, 1007, 1008, 1009, 1024, 2016, 4079, 4080, 4081, 4096, 8063, 8064, 8065, 8160, 9000, 12345, 16129, 17000};
         for (uint64_t n : sizes) {
             for (int flavour = 0; flavour < 6; ++flavour) {
                 Case c;

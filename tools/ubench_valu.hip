@@ -45,6 +45,19 @@ constexpr int UNROLL = 16;
 
 KERNEL32(k_add_u32, "v_add_u32 %0, %0, %1")
 KERNEL32(k_xor_b32, "v_xor_b32 %0, %0, %1")
+KERNEL32(k_fma_f32, "v_fma_f32 %0, %0, %1, %0")
+KERNEL32(k_fmac_f32, "v_fmac_f32 %0, %1, %1")
+KERNEL32(k_add_f32, "v_add_f32 %0, %0, %1")
+KERNEL32(k_and_b32, "v_and_b32 %0, %0, %1")
+KERNEL32(k_lshlrev_b32, "v_lshlrev_b32 %0, 3, %0")
+KERNEL32(k_lshrrev_b32, "v_lshrrev_b32 %0, 3, %0")
+KERNEL32(k_cndmask, "v_cndmask_b32 %0, %0, %1, vcc")
+KERNEL32(k_min_u32, "v_min_u32 %0, %0, %1")
+KERNEL32(k_sub_u32, "v_sub_u32 %0, %0, %1")
+KERNEL32(k_mov, "v_mov_b32 %0, %1")
+KERNEL32(k_add_u32_e64, "v_add_u32_e64 %0, %0, %1")
+KERNEL32(k_cmp_lt_u32, "v_cmp_lt_u32 vcc, %0, %1")
+KERNEL32(k_bitop3, "v_bitop3_b32 %0, %0, %1, %1 bitop3:0x96")
 KERNEL32(k_mul_lo_u32, "v_mul_lo_u32 %0, %0, %1")
 KERNEL32(k_mul_hi_u32, "v_mul_hi_u32 %0, %0, %1")
 KERNEL32(k_mul_u32_u24, "v_mul_u32_u24 %0, %0, %1")
@@ -103,7 +116,10 @@ int main()
     uint32_t* d;
     CHECK(hipMalloc(&d, 256));
     K ks[] = {
-        {"v_add_u32", k_add_u32, 1}, {"v_xor_b32", k_xor_b32, 1}, {"v_mul_lo_u32", k_mul_lo_u32, 1}, {"v_mul_hi_u32", k_mul_hi_u32, 1},
+        {"v_add_u32", k_add_u32, 1}, {"v_xor_b32", k_xor_b32, 1}, {"v_fma_f32", k_fma_f32, 1}, {"v_fmac_f32", k_fmac_f32, 1},
+        {"v_add_f32", k_add_f32, 1}, {"v_and_b32", k_and_b32, 1}, {"v_lshlrev_b32", k_lshlrev_b32, 1}, {"v_lshrrev_b32", k_lshrrev_b32, 1},
+        {"v_cndmask_b32", k_cndmask, 1}, {"v_min_u32", k_min_u32, 1}, {"v_sub_u32", k_sub_u32, 1}, {"v_mov_b32", k_mov, 1},
+        {"v_add_u32_e64", k_add_u32_e64, 1}, {"v_cmp_lt_u32", k_cmp_lt_u32, 1}, {"v_bitop3_b32 (xor3)", k_bitop3, 1}, {"v_mul_lo_u32", k_mul_lo_u32, 1}, {"v_mul_hi_u32", k_mul_hi_u32, 1},
         {"v_mul_u32_u24", k_mul_u32_u24, 1}, {"v_mul_hi_u32_u24", k_mul_hi_u32_u24, 1}, {"v_mad_u32_u24", k_mad_u32_u24, 1},
         {"v_mad_u32_u16", k_mad_u32_u16, 1}, {"v_alignbit_b32", k_alignbit, 1}, {"v_perm_b32", k_perm, 1}, {"v_bfe_u32", k_bfe, 1},
         {"v_lshl_or_b32", k_lshl_or, 1}, {"v_and_or_b32", k_and_or, 1}, {"v_xad_u32", k_xad, 1}, {"v_add3_u32", k_add3, 1},
