@@ -59,7 +59,7 @@ def main():
 
     dev = local_rank if world > 1 else 0
     torch.cuda.set_device(dev)
-    ctx = biolib_amd.Context(dev)
+    ctx = biolib_amd.Context(dev, torch_stream=False)  # own streams: consecutive scans alternate between two lanes and overlap
 
     n_reads = int(args.gbp * 1e9) // READ_LEN
     n_bases = n_reads * READ_LEN

@@ -46,19 +46,35 @@ struct Pending {
 
 }  // namespace
 
-struct bl_ctx {
-    int device = 0;
-    hipStream_t own_stream = nullptr;
-    hipStream_t stream = nullptr;
-    // workspace: [hdr 256 B][shards][result][status ...]
-    unsigned char* ws = nullptr;
+// One execution lane: a stream plus the scratch its scans use.  With the context's own streams,
+// consecutive asynchronous scans alternate between two lanes, so the HBM-bound record pass of one
+// scan overlaps the ALU-bound hashing pass of the next; a borrowed caller stream uses lane 0 only.
+struct Lane {
+    hipStream_t own = nullptr;
+    unsigned char* ws = nullptr;  // [hdr 256 B][shards][result]
     size_t ws_bytes = 0;
+    unsigned char* tile_buf = nullptr;  // tile counts / prefixes
+    size_t tile_buf_bytes = 0;
+    uint16_t* slot_buf = nullptr;  // per-tile u16 record lists
+    size_t slot_buf_bytes = 0;
     uint64_t* last_buf = nullptr;  // super-k-mer scratch
     size_t last_cap = 0;
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+
+    unsigned long long* shards() const { return reinterpret_cast<unsigned long long*>(ws + HDR_BYTES); }
+    unsigned long long* result() const { return reinterpret_cast<unsigned long long*>(ws + HDR_BYTES + SHARD_BYTES); }
+};
+
+struct bl_ctx {
+    int device = 0;
+    Lane lanes[2];
+    Lane* cur = nullptr;               // lane of the scan being issued / issued last
+    int next_lane = 0;
+    hipStream_t user_stream = nullptr; // borrowed (bl_ctx_set_stream)
+    hipStream_t stream = nullptr;      // stream of `cur`
     unsigned long long* pinned = nullptr;  // RING * RESULT_WORDS
     int next_slot = 0;
     std::vector<Pending> pending;
-    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     bool timed = false;
     // optional per-launch timing of the main scan kernel alone (bl_ctx_kernel_timing)
     bool ktiming = false;
@@ -68,14 +84,8 @@ struct bl_ctx {
     uint64_t kernel_launches = 0;
     std::vector<bl_batch*> batches;  // live batches: destroyed with the context if the caller did not
 
-    unsigned int* ticket() const { return reinterpret_cast<unsigned int*>(ws); }
-    unsigned int* error() const { return reinterpret_cast<unsigned int*>(ws) + 1; }
-    unsigned long long* shards() const { return reinterpret_cast<unsigned long long*>(ws + HDR_BYTES); }
-    unsigned long long* result() const { return reinterpret_cast<unsigned long long*>(ws + HDR_BYTES + SHARD_BYTES); }
-    unsigned long long* status() const
-    {
-        return reinterpret_cast<unsigned long long*>(ws + HDR_BYTES + SHARD_BYTES + RESULT_WORDS * sizeof(unsigned long long));
-    }
+    unsigned long long* shards() const { return cur->shards(); }
+    unsigned long long* result() const { return cur->result(); }
     static size_t fixed_bytes() { return HDR_BYTES + SHARD_BYTES + RESULT_WORDS * sizeof(unsigned long long); }
 };
 
@@ -90,19 +100,36 @@ struct bl_batch {
 
 namespace {
 
-int ensure_workspace(bl_ctx* c, size_t n_tiles)
+int grow(bl_ctx* c, void** buf, size_t* have, size_t need)
 {
-    const size_t need = bl_ctx::fixed_bytes() + (n_tiles + 64) * sizeof(unsigned long long);
-    if (need <= c->ws_bytes) return BL_OK;
-    // the old workspace may still be in use by queued work on the stream
-    BL_HIP(hipStreamSynchronize(c->stream));
-    if (c->ws) BL_HIP(hipFree(c->ws));
-    c->ws = nullptr;
-    c->ws_bytes = 0;
-    const size_t bytes = need + need / 4;
-    BL_HIP(hipMalloc(&c->ws, bytes));
-    c->ws_bytes = bytes;
+    if (need <= *have) return BL_OK;
+    BL_HIP(hipStreamSynchronize(c->stream));  // the old buffer may still be in use by queued work
+    if (*buf) BL_HIP(hipFree(*buf));
+    *buf = nullptr;
+    *have = 0;
+    const size_t bytes = need + need / 8;
+    hipError_t e = hipMalloc(buf, bytes);
+    if (e != hipSuccess) return fail(BL_ERR_OOM, std::string("hipMalloc(scan scratch): ") + hipGetErrorString(e));
+    *have = bytes;
     return BL_OK;
+}
+
+int ensure_workspace(bl_ctx* c)
+{
+    return grow(c, reinterpret_cast<void**>(&c->cur->ws), &c->cur->ws_bytes, bl_ctx::fixed_bytes());
+}
+
+// pick the lane (and stream) of the next scan
+void select_lane(bl_ctx* c)
+{
+    if (c->user_stream) {
+        c->cur = &c->lanes[0];
+        c->stream = c->user_stream;
+    } else {
+        c->cur = &c->lanes[c->next_lane];
+        c->next_lane ^= 1;
+        c->stream = c->cur->own;
+    }
 }
 
 int flush_pending(bl_ctx* c)
@@ -117,8 +144,7 @@ int flush_pending(bl_ctx* c)
         out.xor_pos = r[3];
         out.aux = r[4];
         out.status = BL_OK;
-        if (r[8] != 0) out.status = BL_ERR_INTERNAL;
-        else if (p.has_capacity && r[0] > p.capacity) out.status = BL_ERR_CAPACITY;
+        if (p.has_capacity && r[0] > p.capacity) out.status = BL_ERR_CAPACITY;
         if (p.user) *p.user = out;
     }
     c->pending.clear();
@@ -141,7 +167,8 @@ int flush_kernel_events(bl_ctx* c)
 
 int sync_ctx(bl_ctx* c)
 {
-    BL_HIP(hipStreamSynchronize(c->stream));
+    for (Lane& l : c->lanes) BL_HIP(hipStreamSynchronize(l.own));
+    if (c->user_stream) BL_HIP(hipStreamSynchronize(c->user_stream));
     int rc = flush_kernel_events(c);
     if (rc != BL_OK) return rc;
     return flush_pending(c);
@@ -165,14 +192,15 @@ int kernel_event(bl_ctx* c, bool start)
     return BL_OK;
 }
 
-// memset header + shards + result + status for n_tiles, record the start event
-int begin_scan(bl_ctx* c, size_t n_tiles)
+// clear the digest shards, record the start event
+int begin_scan(bl_ctx* c)
 {
     BL_HIP(hipSetDevice(c->device));
-    int rc = ensure_workspace(c, n_tiles);
+    select_lane(c);
+    int rc = ensure_workspace(c);
     if (rc != BL_OK) return rc;
-    BL_HIP(hipEventRecord(c->ev_start, c->stream));
-    BL_HIP(hipMemsetAsync(c->ws, 0, bl_ctx::fixed_bytes() + n_tiles * sizeof(unsigned long long), c->stream));
+    BL_HIP(hipEventRecord(c->cur->ev_start, c->stream));
+    BL_HIP(hipMemsetAsync(c->cur->ws, 0, bl_ctx::fixed_bytes(), c->stream));
     return BL_OK;
 }
 
@@ -181,7 +209,7 @@ int end_scan(bl_ctx* c, uint32_t add_mask, bl_result* user, bool has_capacity, u
              bool already_folded = false)
 {
     if (!already_folded) {
-        hipError_t e = bl::launch_reduce_shards(c->shards(), c->result(), add_mask, c->error(), c->stream);
+        hipError_t e = bl::launch_reduce_shards(c->shards(), c->result(), add_mask, c->stream);
         if (e != hipSuccess) return fail(BL_ERR_HIP, std::string("reduce_shards: ") + hipGetErrorString(e));
     }
     if ((int)c->pending.size() >= RING) {
@@ -192,15 +220,14 @@ int end_scan(bl_ctx* c, uint32_t add_mask, bl_result* user, bool has_capacity, u
     c->next_slot = (c->next_slot + 1) % RING;
     BL_HIP(hipMemcpyAsync(c->pinned + (size_t)slot * RESULT_WORDS, c->result(), RESULT_WORDS * sizeof(unsigned long long),
                           hipMemcpyDeviceToHost, c->stream));
-    BL_HIP(hipEventRecord(c->ev_stop, c->stream));
+    BL_HIP(hipEventRecord(c->cur->ev_stop, c->stream));
     c->timed = true;
     c->pending.push_back(Pending{user, slot, capacity, has_capacity});
     if (flags & BL_FLAG_SYNC) {
         int rc = sync_ctx(c);
         if (rc != BL_OK) return rc;
         if (user && user->status != BL_OK)
-            return fail(user->status, user->status == BL_ERR_CAPACITY ? "output capacity too small for the records found"
-                                                                       : "inter-tile protocol timed out");
+            return fail(user->status, "output capacity too small for the records found");
     }
     return BL_OK;
 }
@@ -248,6 +275,7 @@ int make_start_bits(bl_ctx* c, bl_batch* b, const uint64_t* offsets, uint64_t n_
         hipError_t e = bl::launch_start_bits_fixed(b->start_bits, n_words, b->n_bases, read_len, c->stream);
         if (e != hipSuccess) return fail(BL_ERR_HIP, std::string("start_bits_fixed: ") + hipGetErrorString(e));
         b->n_seqs = (b->n_bases + read_len - 1) / read_len;
+        BL_HIP(hipStreamSynchronize(c->stream));  // the batch may be scanned from either lane
     }
     return BL_OK;
 }
@@ -284,17 +312,25 @@ int bl_ctx_create(int device, bl_ctx** out)
     bl_ctx* c = new (std::nothrow) bl_ctx();
     if (!c) return fail(BL_ERR_OOM, "host allocation failed");
     c->device = device;
-    hipError_t e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipEventCreate(&c->ev_start);
-    if (e == hipSuccess) e = hipEventCreate(&c->ev_stop);
+    hipError_t e = hipSuccess;
+    for (Lane& l : c->lanes) {
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&l.own, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreate(&l.ev_start);
+        if (e == hipSuccess) e = hipEventCreate(&l.ev_stop);
+    }
     if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&c->pinned), (size_t)RING * RESULT_WORDS * sizeof(unsigned long long), hipHostMallocDefault);
     if (e != hipSuccess) {
         bl_ctx_destroy(c);
         return fail(BL_ERR_HIP, std::string("context setup: ") + hipGetErrorString(e));
     }
-    c->stream = c->own_stream;
-    int rc = ensure_workspace(c, 1 << 16);
-    if (rc != BL_OK) { bl_ctx_destroy(c); return rc; }
+    for (int i = 0; i < 2; ++i) {  // fixed workspace of both lanes
+        c->cur = &c->lanes[i];
+        c->stream = c->cur->own;
+        int rc = ensure_workspace(c);
+        if (rc != BL_OK) { bl_ctx_destroy(c); return rc; }
+    }
+    c->cur = &c->lanes[0];
+    c->stream = c->lanes[0].own;
     *out = c;
     return BL_OK;
 }
@@ -303,16 +339,22 @@ int bl_ctx_destroy(bl_ctx* c)
 {
     if (!c) return BL_OK;
     (void)hipSetDevice(c->device);
-    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (Lane& l : c->lanes)
+        if (l.own) (void)hipStreamSynchronize(l.own);
+    if (c->user_stream) (void)hipStreamSynchronize(c->user_stream);
     while (!c->batches.empty()) bl_batch_destroy(c->batches.back());  // handles of leftover batches become invalid
-    if (c->ws) (void)hipFree(c->ws);
-    if (c->last_buf) (void)hipFree(c->last_buf);
+    for (Lane& l : c->lanes) {
+        if (l.ws) (void)hipFree(l.ws);
+        if (l.tile_buf) (void)hipFree(l.tile_buf);
+        if (l.slot_buf) (void)hipFree(l.slot_buf);
+        if (l.last_buf) (void)hipFree(l.last_buf);
+        if (l.ev_start) (void)hipEventDestroy(l.ev_start);
+        if (l.ev_stop) (void)hipEventDestroy(l.ev_stop);
+        if (l.own) (void)hipStreamDestroy(l.own);
+    }
     if (c->pinned) (void)hipHostFree(c->pinned);
     for (auto& pr : c->ev_open) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     for (hipEvent_t ev : c->ev_pool) (void)hipEventDestroy(ev);
-    if (c->ev_start) (void)hipEventDestroy(c->ev_start);
-    if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
-    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
     return BL_OK;
 }
@@ -322,7 +364,9 @@ int bl_ctx_set_stream(bl_ctx* c, void* hip_stream)
     if (!c) return fail(BL_ERR_INVALID, "ctx is NULL");
     int rc = sync_ctx(c);
     if (rc != BL_OK) return rc;
-    c->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->own_stream;
+    c->user_stream = static_cast<hipStream_t>(hip_stream);
+    c->cur = &c->lanes[0];
+    c->stream = c->user_stream ? c->user_stream : c->lanes[0].own;
     return BL_OK;
 }
 
@@ -336,8 +380,8 @@ int bl_ctx_last_scan_ms(bl_ctx* c, float* ms)
 {
     if (!c || !ms) return fail(BL_ERR_INVALID, "NULL argument");
     if (!c->timed) return fail(BL_ERR_INVALID, "no scan has been issued on this context");
-    BL_HIP(hipEventSynchronize(c->ev_stop));
-    BL_HIP(hipEventElapsedTime(ms, c->ev_start, c->ev_stop));
+    BL_HIP(hipEventSynchronize(c->cur->ev_stop));
+    BL_HIP(hipEventElapsedTime(ms, c->cur->ev_start, c->cur->ev_stop));
     return BL_OK;
 }
 
@@ -429,6 +473,7 @@ int bl_batch_synth(bl_ctx* c, uint64_t seed, uint64_t n_bases, uint64_t read_len
     if (e == hipSuccess) e = bl::launch_synth(b->bases, 0, n_bases, seed, c->stream);
     if (e != hipSuccess) { bl_batch_destroy(b); return fail(BL_ERR_HIP, std::string("synth: ") + hipGetErrorString(e)); }
     rc = make_start_bits(c, b, nullptr, 0, read_len);
+    if (rc == BL_OK && hipStreamSynchronize(c->stream) != hipSuccess) rc = fail(BL_ERR_HIP, "synth sync failed");
     if (rc != BL_OK) { bl_batch_destroy(b); return rc; }
     *out = b;
     return BL_OK;
@@ -439,7 +484,9 @@ int bl_batch_destroy(bl_batch* b)
     if (!b) return BL_OK;
     if (b->ctx) {
         (void)hipSetDevice(b->ctx->device);
-        (void)hipStreamSynchronize(b->ctx->stream);
+        for (Lane& l : b->ctx->lanes)
+            if (l.own) (void)hipStreamSynchronize(l.own);
+        if (b->ctx->user_stream) (void)hipStreamSynchronize(b->ctx->user_stream);
         auto& v = b->ctx->batches;
         for (size_t i = 0; i < v.size(); ++i)
             if (v[i] == b) { v[i] = v.back(); v.pop_back(); break; }
@@ -459,7 +506,8 @@ int bl_batch_download(bl_batch* b, uint64_t first, uint64_t n, char* out)
     if (!b || (!out && n)) return fail(BL_ERR_INVALID, "NULL argument");
     if (first + n > b->n_bases) return fail(BL_ERR_INVALID, "range beyond the batch");
     BL_HIP(hipSetDevice(b->ctx->device));
-    BL_HIP(hipStreamSynchronize(b->ctx->stream));
+    int rc = sync_ctx(b->ctx);
+    if (rc != BL_OK) return rc;
     if (n) BL_HIP(hipMemcpy(out, b->bases + first, n, hipMemcpyDeviceToHost));
     return BL_OK;
 }
@@ -490,7 +538,7 @@ int bl_scan_kmers(bl_ctx* c, const bl_batch* b, uint64_t first, uint64_t n, uint
     p.out_value = d_values;
     p.out_hash = d_hashes;
     p.out_valid = d_valid;
-    rc = begin_scan(c, 0);
+    rc = begin_scan(c);
     if (rc != BL_OK) return rc;
     p.shards = c->shards();
     const int n_blocks = p.n_tiles < 256 * 8 ? p.n_tiles : 256 * 8;
@@ -523,18 +571,34 @@ static int scan_windows(int mode, bl_ctx* c, const bl_batch* b, uint64_t first, 
     p.canonical = (flags & BL_FLAG_CANONICAL) ? 1 : 0;
     p.drop_last = (flags & BL_FLAG_DROP_LAST) ? 1 : 0;
     p.capacity = capacity;
-    rc = begin_scan(c, (size_t)p.n_tiles);
+    rc = begin_scan(c);
     if (rc != BL_OK) return rc;
-    p.status = c->status();
-    p.ticket = c->ticket();
+    // scratch: tile counts + local prefixes + scan-block totals/prefixes, and the per-tile u16 list slots
+    const size_t nt = (size_t)p.n_tiles, nb = (nt + bl::SCAN_BLK - 1) / bl::SCAN_BLK;
+    rc = grow(c, reinterpret_cast<void**>(&c->cur->tile_buf), &c->cur->tile_buf_bytes, (2 * nt + 2 * nb + 8) * sizeof(unsigned long long));
+    if (rc != BL_OK) return rc;
+    const size_t n_lists = mode == bl::MODE_SUPERKMER ? 3 : 1;
+    const size_t slot_entries = nt * (size_t)p.stride;
+    rc = grow(c, reinterpret_cast<void**>(&c->cur->slot_buf), &c->cur->slot_buf_bytes, n_lists * slot_entries * sizeof(uint16_t));
+    if (rc != BL_OK) return rc;
+    unsigned long long* tb = reinterpret_cast<unsigned long long*>(c->cur->tile_buf);
+    p.tile_counts = tb;
+    p.tile_base = tb + nt;
+    unsigned long long* block_tot = tb + 2 * nt;
+    p.block_base = block_tot + nb;
+    p.slots_a = c->cur->slot_buf;
+    p.slots_j = mode == bl::MODE_SUPERKMER ? c->cur->slot_buf + slot_entries : nullptr;
+    p.slots_e = mode == bl::MODE_SUPERKMER ? c->cur->slot_buf + 2 * slot_entries : nullptr;
     p.shards = c->shards();
-    p.error = c->error();
-    if (const char* ab = std::getenv("BL_ABLATE")) p.ablate = (uint32_t)std::atoi(ab);  // profiling only
     rc = kernel_event(c, true);
     if (rc != BL_OK) return rc;
-    hipError_t e = bl::launch_scan(mode, p, c->stream);
-    if (e != hipSuccess) return fail(BL_ERR_HIP, std::string("scan_kernel: ") + hipGetErrorString(e));
-    return kernel_event(c, false);
+    hipError_t e = bl::launch_scan_count(mode, p, c->stream);  // pass 1: the dominant kernel (timed alone)
+    if (e != hipSuccess) return fail(BL_ERR_HIP, std::string("scan_count_kernel: ") + hipGetErrorString(e));
+    rc = kernel_event(c, false);
+    if (rc != BL_OK) return rc;
+    e = bl::launch_scan_emit(mode, p, block_tot, c->stream);    // tile prefix scan + pass 2
+    if (e != hipSuccess) return fail(BL_ERR_HIP, std::string("scan_emit_kernel: ") + hipGetErrorString(e));
+    return BL_OK;
 }
 
 int bl_scan_minimizers(bl_ctx* c, const bl_batch* b, uint64_t first, uint64_t n, uint32_t unit, uint32_t w, uint64_t seed, uint32_t flags,
@@ -564,23 +628,25 @@ int bl_scan_super_kmers(bl_ctx* c, const bl_batch* b, uint64_t first, uint64_t n
     p.out_hash = d_hashes;
     const bool wants = d_minimizers || d_first_pos || d_mm_pos || d_sizes || d_hashes;
     if (d_sizes && capacity) {
-        if (c->last_cap < capacity) {
-            BL_HIP(hipStreamSynchronize(c->stream));
-            if (c->last_buf) BL_HIP(hipFree(c->last_buf));
-            c->last_buf = nullptr;
-            c->last_cap = 0;
-            BL_HIP(hipMalloc(&c->last_buf, capacity * sizeof(uint64_t)));
-            c->last_cap = capacity;
+        Lane* ln = c->user_stream ? &c->lanes[0] : &c->lanes[c->next_lane];  // the lane begin_scan() will pick
+        if (ln->last_cap < capacity) {
+            BL_HIP(hipSetDevice(c->device));
+            BL_HIP(hipStreamSynchronize(c->user_stream ? c->user_stream : ln->own));
+            if (ln->last_buf) BL_HIP(hipFree(ln->last_buf));
+            ln->last_buf = nullptr;
+            ln->last_cap = 0;
+            BL_HIP(hipMalloc(&ln->last_buf, capacity * sizeof(uint64_t)));
+            ln->last_cap = capacity;
         }
-        p.out_last = c->last_buf;
+        p.out_last = ln->last_buf;
     }
     int rc = scan_windows(bl::MODE_SUPERKMER, c, b, first, n, m, k - m + 1, seed, flags, p, wants ? capacity : 0, result);
     if (rc != BL_OK || p.n_tiles == 0) return rc;
     // fold first so that result[0] (the record count) is final on the device, then derive the sizes
-    hipError_t e = bl::launch_reduce_shards(c->shards(), c->result(), (1u << 0) | (1u << 4), c->error(), c->stream);
+    hipError_t e = bl::launch_reduce_shards(c->shards(), c->result(), (1u << 0) | (1u << 4), c->stream);
     if (e != hipSuccess) return fail(BL_ERR_HIP, std::string("reduce_shards: ") + hipGetErrorString(e));
     if (d_sizes && capacity) {
-        e = bl::launch_superkmer_size(d_first_pos, c->last_buf, d_sizes, c->result(), capacity, c->stream);
+        e = bl::launch_superkmer_size(d_first_pos, c->cur->last_buf, d_sizes, c->result(), capacity, c->stream);
         if (e != hipSuccess) return fail(BL_ERR_HIP, std::string("superkmer_size: ") + hipGetErrorString(e));
     }
     return end_scan(c, (1u << 0) | (1u << 4), result, wants, capacity, flags, /*already_folded=*/true);
@@ -615,7 +681,8 @@ int bl_device_free(bl_ctx* c, void* d_ptr)
 {
     if (!c) return fail(BL_ERR_INVALID, "ctx is NULL");
     BL_HIP(hipSetDevice(c->device));
-    BL_HIP(hipStreamSynchronize(c->stream));
+    int rc = sync_ctx(c);
+    if (rc != BL_OK) return rc;
     if (d_ptr) BL_HIP(hipFree(d_ptr));
     return BL_OK;
 }

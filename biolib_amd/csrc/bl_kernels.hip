@@ -1,6 +1,7 @@
 // bl_kernels.hip — gfx950 kernels of the fused k-mer / minimizer scan and their launchers.
 // Written for CDNA4 only (wave64, 256-thread workgroups, LDS-staged tiles); no portability layer.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include "bl_scan_phases.hpp"
 #include "bl_launch.hpp"
 
@@ -52,148 +53,141 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* wave_t
 }
 
 // ------------------------------------------------------------------------------------------------
-// Ordered compaction across tiles: decoupled look-back over one 8-byte status word per tile.
-// The word carries flag + both counters, written by ONE agent-scope store and polled with
-// agent-scope relaxed loads (sc1, L1-bypassing): the {data, tag} granule of MI355X_MICROARCH.md
-// "R2" — no separate payload, hence no release/acquire pair is needed.
-// Tile ids come from an atomic ticket, so every predecessor of a running tile is itself running
-// or finished: the waits below cannot deadlock whatever the dispatch order.  Every spin is bounded.
-constexpr unsigned long long FLAG_AGG = 1ull << 62, FLAG_INC = 2ull << 62, FLAG_MASK = 3ull << 62;
-constexpr unsigned long long CNT_MASK = (1ull << 31) - 1;
-
-__device__ __forceinline__ unsigned long long pack_status(unsigned long long flag, uint32_t s, uint32_t e)
-{
-    return flag | ((unsigned long long)e << 31) | s;
-}
-
-// called by the whole first wave; returns the exclusive prefix (starts, ends) of tile `tile`.
-// One hop inspects LB_DEPTH x 64 predecessors (LB_DEPTH independent loads per lane in flight), so the
-// number of tiles whose prefix is still unknown when a tile arrives — tile rate x visibility latency —
-// is covered in one or two hops even at several hundred tiles per microsecond.
-constexpr int LB_DEPTH = 4;
-
-__device__ __forceinline__ void lookback(const ScanParams& p, uint32_t tile, uint32_t agg_s, uint32_t agg_e, int lane,
-                                         uint32_t& excl_s, uint32_t& excl_e)
-{
-    if (tile == 0) {
-        if (lane == 0) __hip_atomic_store(&p.status[0], pack_status(FLAG_INC, agg_s, agg_e), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        excl_s = excl_e = 0;
-        return;
-    }
-    if (lane == 0) __hip_atomic_store(&p.status[tile], pack_status(FLAG_AGG, agg_s, agg_e), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    unsigned long long run_s = 0, run_e = 0;
-    int64_t pos = (int64_t)tile - 1;
-    bool done = false;
-    for (int hop = 0; hop < (1 << 20) && !done; ++hop) {
-        unsigned long long w[LB_DEPTH];
-#pragma unroll
-        for (int j = 0; j < LB_DEPTH; ++j) {  // issue all loads first
-            const int64_t idx = pos - lane - 64 * j;
-            w[j] = idx >= 0 ? __hip_atomic_load(&p.status[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : FLAG_INC;  // before tile 0: prefix 0
-        }
-#pragma unroll
-        for (int j = 0; j < LB_DEPTH; ++j) {  // nearest 64 predecessors first
-            if (done) break;
-            const int64_t idx = pos - lane - 64 * j;
-            unsigned spins = 0;
-            while ((w[j] & FLAG_MASK) == 0) {
-                if (++spins > (1u << 22)) { atomicOr(p.error, 1u); break; }
-                __builtin_amdgcn_s_sleep(1);
-                w[j] = __hip_atomic_load(&p.status[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            const unsigned long long inc_mask = __ballot((w[j] & FLAG_MASK) == FLAG_INC);
-            // lanes closer than the first inclusive prefix contribute their aggregate, that lane its prefix
-            const int first_inc = inc_mask ? __builtin_ctzll(inc_mask) : 64;
-            const bool use = lane <= first_inc && (w[j] & FLAG_MASK) != 0;
-            run_s += wave_sum_u64(use ? (w[j] & CNT_MASK) : 0);
-            run_e += wave_sum_u64(use ? ((w[j] >> 31) & CNT_MASK) : 0);
-            if (inc_mask) done = true;
-            if (__ballot((w[j] & FLAG_MASK) == 0)) done = true;  // timed out: error flag is set, leave
-        }
-        pos -= 64 * LB_DEPTH;
-    }
-    excl_s = (uint32_t)run_s;
-    excl_e = (uint32_t)run_e;
-    if (lane == 0)
-        __hip_atomic_store(&p.status[tile], pack_status(FLAG_INC, excl_s + agg_s, excl_e + agg_e), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// ------------------------------------------------------------------------------------------------
-// The fused scan kernel: one workgroup per tile.
+// Pass 1: one workgroup per tile.  Hash, window minimum, start/end decisions, tile-local compaction;
+// leaves the tile's record counts and u16 lists in global scratch.  Tiles are independent: no ticket,
+// no inter-workgroup wait, any dispatch order.
 template <int MODE, int W>
-__global__ __launch_bounds__(TPB, (MODE == MODE_SYNCMER ? 2 : (W != 0 && W <= 11 ? 6 : 4))) void scan_kernel(const ScanParams p)
+__global__ __launch_bounds__(TPB, (MODE == MODE_SYNCMER || W == 0 ? 2 : (W <= 11 ? 6 : 4))) void scan_count_kernel(const ScanParams p)
 {
     __shared__ TileShared<MODE, W> sh;
     const int tid = threadIdx.x;
-    if (tid == 0) sh.tile = (p.ablate & 1) ? blockIdx.x : atomicAdd(p.ticket, 1u);
+    // a workgroup walks tiles blockIdx, blockIdx + gridDim, ... (normally exactly one: grid = n_tiles)
+    for (uint32_t tile = blockIdx.x; tile < (uint32_t)p.n_tiles; tile += gridDim.x) {
+        const int64_t q0 = p.origin + (int64_t)tile * p.stride;
+        __syncthreads();  // previous tile's LDS contents are dead
+        phase_load<MODE, W>(p, sh, tid, q0);
+        __syncthreads();
+
+        ThreadState st;
+        phase_hash<MODE, W>(p, sh, tid, st);
+        if (W == 0) __syncthreads();  // runtime-w fallback exchanges hashes through LDS
+
+        uint32_t packed;
+        if (MODE == MODE_SYNCMER) {
+            uint8_t af[S + 1];
+            phase_sync_fwd<MODE, W>(p, sh, tid, st, nullptr, af);
+            if (W == 0 && p.canonical) {
+                __syncthreads();
+                phase_publish_h2<MODE, W>(sh, tid, st);
+                __syncthreads();
+            }
+            packed = phase_sync_rev<MODE, W>(p, sh, tid, q0, st, nullptr, af);
+        } else {
+            packed = phase_window<MODE, W>(p, sh, tid, q0, st, nullptr);
+        }
+
+        uint32_t total;
+        const uint32_t excl = block_excl_scan(packed, sh.wave_tot, tid, total);
+        const uint32_t n_s = total & 0xffffu, n_e = total >> 16;  // a tile owns fewer than H positions: 16 bits suffice
+        phase_list<MODE, W>(sh, tid, st, excl & 0xffffu, excl >> 16);
+        if (tid == 0) p.tile_counts[tile] = (unsigned long long)n_s | ((unsigned long long)n_e << 32);
+        __syncthreads();  // lists complete
+
+        // spill the compacted lists (2 bytes per record, coalesced)
+        const size_t slot = (size_t)tile * p.stride;
+        for (uint32_t r = tid; r < n_s; r += TPB) {
+            p.slots_a[slot + r] = sh.list_a[r];
+            if (MODE == MODE_SUPERKMER) p.slots_j[slot + r] = sh.list_j[r];
+        }
+        if (MODE == MODE_SUPERKMER)
+            for (uint32_t r = tid; r < n_e; r += TPB) p.slots_e[slot + r] = sh.list_e[r];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Prefix scan over the tile counts (two 32-bit counters packed in 64 bits; totals stay below 2^31).
+__global__ __launch_bounds__(512) void tile_scan_local_kernel(const unsigned long long* counts, unsigned long long* tile_base,
+                                                              unsigned long long* block_tot, int n_tiles)
+{
+    __shared__ unsigned long long wtot[8];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int first = blockIdx.x * SCAN_BLK + tid * 4;
+    unsigned long long c[4], run = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        c[i] = first + i < n_tiles ? counts[first + i] : 0;
+        run += c[i];
+    }
+    unsigned long long incl = run;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned long long o = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += o;
+    }
+    if (lane == 63) wtot[wv] = incl;
+    __syncthreads();
+    unsigned long long before = 0, all = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        if (i < wv) before += wtot[i];
+        all += wtot[i];
+    }
+    unsigned long long ex = before + incl - run;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (first + i < n_tiles) tile_base[first + i] = ex;
+        ex += c[i];
+    }
+    if (tid == 0) block_tot[blockIdx.x] = all;
+}
+
+// one thread: exclusive scan of the (few hundred) block totals; the grand totals go to the digest
+__global__ void tile_scan_top_kernel(const unsigned long long* block_tot, unsigned long long* block_base, int n_blocks,
+                                     unsigned long long* shards)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    unsigned long long run = 0;
+    for (int i = 0; i < n_blocks; ++i) {
+        block_base[i] = run;
+        run += block_tot[i];
+    }
+    shards[0] += run & 0xffffffffull;  // records (starts)
+    shards[4] += run >> 32;            // group ends (super-k-mer mode)
+}
+
+// ------------------------------------------------------------------------------------------------
+// Pass 2: one workgroup per tile.  Re-stage the tile's codes, rebuild each record from its u16 list
+// entry (unit value, hash, position) and store it at the tile's global offset with coalesced stores.
+template <int MODE>
+__global__ __launch_bounds__(TPB) void scan_emit_kernel(const ScanParams p)
+{
+    __shared__ TileShared<MODE, 1> sh;  // W only sizes the fallback hash array: not used here
+    const int tid = threadIdx.x;
+    Digest dg{0, 0, 0};
+    for (uint32_t tile = blockIdx.x; tile < (uint32_t)p.n_tiles; tile += gridDim.x) {
+        const unsigned long long cnt = p.tile_counts[tile];
+        const uint32_t n_s = (uint32_t)cnt, n_e = (uint32_t)(cnt >> 32);
+        if (n_s == 0 && n_e == 0) continue;  // uniform for the workgroup
+        const unsigned long long base = p.tile_base[tile] + p.block_base[tile / SCAN_BLK];
+        const uint64_t base_s = base & 0xffffffffull, base_e = base >> 32;
+        const int64_t q0 = p.origin + (int64_t)tile * p.stride;
+        const size_t slot = (size_t)tile * p.stride;
+
+        __syncthreads();  // previous tile's LDS contents are dead
+        phase_load<MODE, 1>(p, sh, tid, q0);
+        for (uint32_t r = tid; r < n_s; r += TPB) {
+            sh.list_a[r] = p.slots_a[slot + r];
+            if (MODE == MODE_SUPERKMER) sh.list_j[r] = p.slots_j[slot + r];
+        }
+        if (MODE == MODE_SUPERKMER)
+            for (uint32_t r = tid; r < n_e; r += TPB) sh.list_e[r] = p.slots_e[slot + r];
+        __syncthreads();
+        phase_emit<MODE, 1>(p, sh, tid, q0, n_s, n_e, base_s, base_e, dg);
+    }
+
+    // digest: wave reduce -> LDS -> one set of atomics per workgroup into a shard line
     if (tid < 4) sh.dig[tid] = 0;
     __syncthreads();
-    const uint32_t tile = sh.tile;
-    const int64_t q0 = p.origin + (int64_t)tile * p.stride;
-
-    phase_load<MODE, W>(p, sh, tid, q0);
-    __syncthreads();
-
-    ThreadState st;
-    phase_hash<MODE, W>(p, sh, tid, st);
-    if (W == 0) __syncthreads();  // runtime-w fallback exchanges hashes through LDS
-    if (p.ablate & 32) return;
-
-    uint32_t packed;
-    if (MODE == MODE_SYNCMER) {
-        uint8_t af[S + 1];
-        phase_sync_fwd<MODE, W>(p, sh, tid, st, nullptr, af);
-        if (W == 0 && p.canonical) {
-            __syncthreads();
-            phase_publish_h2<MODE, W>(sh, tid, st);
-            __syncthreads();
-        }
-        packed = phase_sync_rev<MODE, W>(p, sh, tid, q0, st, nullptr, af);
-    } else {
-        packed = phase_window<MODE, W>(p, sh, tid, q0, st, nullptr);
-    }
-
-    if (p.ablate & 16) return;
-    uint32_t total;
-    const uint32_t excl = block_excl_scan(packed, sh.wave_tot, tid, total);
-    const uint32_t n_s = total & 0xffffu, n_e = total >> 16;
-    // note: a tile owns fewer than H positions, so the counters fit 16 bits
-
-    phase_list<MODE, W>(sh, tid, st, excl & 0xffffu, excl >> 16);
-    __syncthreads();  // lists complete
-
-    // wave 0 resolves the tile's global offset while the other waves already rebuild their records
-    if (tid < 64) {
-        uint32_t bs, be;
-        if (p.ablate & 2) { bs = 0; be = 0; }
-        else lookback(p, tile, n_s, n_e, tid, bs, be);
-        if (tid == 0) { sh.base_s = bs; sh.base_e = be; }
-    }
-    Digest dg{0, 0, 0};
-    constexpr int PRE = 3;  // records prepared in registers per thread before the offset is known
-    Record rec[PRE];
-#pragma unroll
-    for (int k = 0; k < PRE; ++k) {
-        const uint32_t r = tid + k * TPB;
-        if (r < n_s && !(p.ablate & 4)) rec[k] = emit_prepare<MODE, W>(p, sh, q0, r, dg);
-    }
-    __syncthreads();  // offset known
-    const uint64_t base_s = sh.base_s, base_e = sh.base_e;
-    if (!(p.ablate & 4)) {
-#pragma unroll
-        for (int k = 0; k < PRE; ++k) {
-            const uint32_t r = tid + k * TPB;
-            if (r < n_s) emit_store<MODE>(p, rec[k], base_s + r);
-        }
-        for (uint32_t r = tid + PRE * TPB; r < n_s; r += TPB) {  // denser than 3 records per thread: rare
-            const Record x = emit_prepare<MODE, W>(p, sh, q0, r, dg);
-            emit_store<MODE>(p, x, base_s + r);
-        }
-        emit_ends<MODE, W>(p, sh, tid, q0, n_e, base_e);
-    }
-    if (p.ablate & 8) return;
-
-    // digest: wave reduce -> LDS -> one set of atomics per tile into a shard line
     const unsigned long long xv = wave_xor_u64(dg.xv), xh = wave_xor_u64(dg.xh), xp = wave_xor_u64(dg.xp);
     if ((tid & 63) == 0) {
         atomicXor(&sh.dig[1], xv);
@@ -201,12 +195,7 @@ __global__ __launch_bounds__(TPB, (MODE == MODE_SYNCMER ? 2 : (W != 0 && W <= 11
         atomicXor(&sh.dig[3], xp);
     }
     __syncthreads();
-    if (tid < 4) {
-        unsigned long long* shard = p.shards + 8 * (tile % NSHARD);
-        if (tid == 0) atomicAdd(&shard[0], (unsigned long long)n_s);
-        else atomicXor(&shard[tid], sh.dig[tid]);
-    }
-    if (MODE == MODE_SUPERKMER && tid == 4) atomicAdd(&p.shards[8 * (tile % NSHARD) + 4], (unsigned long long)n_e);
+    if (tid >= 1 && tid < 4) atomicXor(&p.shards[8 * (blockIdx.x % NSHARD) + tid], sh.dig[tid]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -254,13 +243,11 @@ __global__ __launch_bounds__(TPB) void kmer_kernel(const KmerParams p)
 // ------------------------------------------------------------------------------------------------
 // small helper kernels
 
-// fold the NSHARD digest lines into result[0..7]; slots listed in add_mask are sums, the others XORs;
-// result[8] = the protocol error word
-__global__ void reduce_shards_kernel(const unsigned long long* shards, unsigned long long* result, uint32_t add_mask,
-                                     const unsigned int* error)
+// fold the NSHARD digest lines into result[0..7]; slots listed in add_mask are sums, the others XORs
+__global__ void reduce_shards_kernel(const unsigned long long* shards, unsigned long long* result, uint32_t add_mask)
 {
     const int slot = threadIdx.x;
-    if (slot == 8) result[8] = *error;
+    if (slot == 8) result[8] = 0;
     if (slot >= 8) return;
     unsigned long long acc = 0;
     for (int i = 0; i < NSHARD; ++i) {
@@ -337,28 +324,65 @@ __global__ void start_bits_offsets_kernel(uint32_t* bits, const uint64_t* offset
 // ------------------------------------------------------------------------------------------------
 // launchers
 
-template <int MODE>
-static hipError_t launch_mode(const ScanParams& p, hipStream_t stream)
+// Grid size: one workgroup per tile by default (measured fastest: 3.7 ms vs 4.5 ms per 1.5 Gbp for a
+// persistent grid of 5 workgroups per CU).  BL_GRID1 / BL_GRID2 = workgroups per CU make the count /
+// emit kernels persistent for experiments; the kernels' tile loops handle either.
+static unsigned grid_for(int n_tiles, const char* env)
 {
-    const dim3 grid(p.n_tiles), block(TPB);
+    const char* e = std::getenv(env);
+    const int per_cu = e ? std::atoi(e) : 0;
+    if (per_cu <= 0) return (unsigned)n_tiles;
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
+        if (n_cu <= 0) n_cu = 256;
+    }
+    const long g = (long)n_cu * per_cu;
+    return (unsigned)(n_tiles < g ? n_tiles : g);
+}
+
+template <int MODE>
+static hipError_t launch_count(const ScanParams& p, hipStream_t stream)
+{
+    const dim3 grid(grid_for(p.n_tiles, "BL_GRID1")), block(TPB);
     switch (p.w) {
-        case 11: hipLaunchKernelGGL((scan_kernel<MODE, 11>), grid, block, 0, stream, p); break;
-        case 17: hipLaunchKernelGGL((scan_kernel<MODE, 17>), grid, block, 0, stream, p); break;
-        case 21: hipLaunchKernelGGL((scan_kernel<MODE, 21>), grid, block, 0, stream, p); break;
-        default: hipLaunchKernelGGL((scan_kernel<MODE, 0>), grid, block, 0, stream, p); break;
+        case 11: hipLaunchKernelGGL((scan_count_kernel<MODE, 11>), grid, block, 0, stream, p); break;
+        case 17: hipLaunchKernelGGL((scan_count_kernel<MODE, 17>), grid, block, 0, stream, p); break;
+        case 21: hipLaunchKernelGGL((scan_count_kernel<MODE, 21>), grid, block, 0, stream, p); break;
+        default: hipLaunchKernelGGL((scan_count_kernel<MODE, 0>), grid, block, 0, stream, p); break;
     }
     return hipGetLastError();
 }
 
-hipError_t launch_scan(int mode, const ScanParams& p, hipStream_t stream)
+// pass 1
+hipError_t launch_scan_count(int mode, const ScanParams& p, hipStream_t stream)
 {
     if (p.n_tiles <= 0) return hipSuccess;
     switch (mode) {
-        case MODE_MINIMIZER: return launch_mode<MODE_MINIMIZER>(p, stream);
-        case MODE_SUPERKMER: return launch_mode<MODE_SUPERKMER>(p, stream);
-        case MODE_SYNCMER: return launch_mode<MODE_SYNCMER>(p, stream);
+        case MODE_MINIMIZER: return launch_count<MODE_MINIMIZER>(p, stream);
+        case MODE_SUPERKMER: return launch_count<MODE_SUPERKMER>(p, stream);
+        case MODE_SYNCMER: return launch_count<MODE_SYNCMER>(p, stream);
     }
     return hipErrorInvalidValue;
+}
+
+// prefix scan of the tile counts + pass 2
+hipError_t launch_scan_emit(int mode, const ScanParams& p, unsigned long long* block_tot, hipStream_t stream)
+{
+    if (p.n_tiles <= 0) return hipSuccess;
+    const int n_blocks = (p.n_tiles + SCAN_BLK - 1) / SCAN_BLK;
+    hipLaunchKernelGGL(tile_scan_local_kernel, dim3(n_blocks), dim3(512), 0, stream, p.tile_counts, p.tile_base, block_tot, p.n_tiles);
+    hipLaunchKernelGGL(tile_scan_top_kernel, dim3(1), dim3(64), 0, stream, block_tot, p.block_base, n_blocks, p.shards);
+    const dim3 grid(grid_for(p.n_tiles, "BL_GRID2")), block(TPB);
+    switch (mode) {
+        case MODE_MINIMIZER: hipLaunchKernelGGL((scan_emit_kernel<MODE_MINIMIZER>), grid, block, 0, stream, p); break;
+        case MODE_SUPERKMER: hipLaunchKernelGGL((scan_emit_kernel<MODE_SUPERKMER>), grid, block, 0, stream, p); break;
+        case MODE_SYNCMER: hipLaunchKernelGGL((scan_emit_kernel<MODE_SYNCMER>), grid, block, 0, stream, p); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
 }
 
 hipError_t launch_kmers(const KmerParams& p, int n_blocks, hipStream_t stream)
@@ -368,10 +392,9 @@ hipError_t launch_kmers(const KmerParams& p, int n_blocks, hipStream_t stream)
     return hipGetLastError();
 }
 
-hipError_t launch_reduce_shards(const unsigned long long* shards, unsigned long long* result, uint32_t add_mask,
-                                const unsigned int* error, hipStream_t stream)
+hipError_t launch_reduce_shards(const unsigned long long* shards, unsigned long long* result, uint32_t add_mask, hipStream_t stream)
 {
-    hipLaunchKernelGGL(reduce_shards_kernel, dim3(1), dim3(64), 0, stream, shards, result, add_mask, error);
+    hipLaunchKernelGGL(reduce_shards_kernel, dim3(1), dim3(64), 0, stream, shards, result, add_mask);
     return hipGetLastError();
 }
 

@@ -4,10 +4,10 @@
 #include "bl_scan_phases.hpp"
 
 namespace bl {
-hipError_t launch_scan(int mode, const ScanParams& p, hipStream_t stream);
+hipError_t launch_scan_count(int mode, const ScanParams& p, hipStream_t stream);
+hipError_t launch_scan_emit(int mode, const ScanParams& p, unsigned long long* block_tot, hipStream_t stream);
 hipError_t launch_kmers(const KmerParams& p, int n_blocks, hipStream_t stream);
-hipError_t launch_reduce_shards(const unsigned long long* shards, unsigned long long* result, uint32_t add_mask,
-                                const unsigned int* error, hipStream_t stream);
+hipError_t launch_reduce_shards(const unsigned long long* shards, unsigned long long* result, uint32_t add_mask, hipStream_t stream);
 hipError_t launch_superkmer_size(const uint64_t* first, const uint64_t* last, uint8_t* size, const unsigned long long* count,
                                  uint64_t capacity, hipStream_t stream);
 hipError_t launch_synth(uint8_t* bases, uint64_t first, uint64_t n, uint64_t seed, hipStream_t stream);

@@ -25,13 +25,14 @@
 
 namespace bl {
 
-constexpr int TPB = 512;            // threads per workgroup (8 wave64): one ticket / status word per 8 wave tiles
+constexpr int TPB = 256;            // threads per workgroup (4 wave64)
 constexpr int S = 16;               // window/unit start positions owned by one thread (= one 16-byte load)
 constexpr int H = TPB * S;          // positions hashed per tile
 constexpr int NCHUNK = H / 16 + 8;  // 16-base chunks staged per tile (halo of up to 128 bases)
 constexpr int MAX_UNIT = 32;        // KmerType = uint64_t only
 constexpr int MAX_W = 64;
 constexpr int NSHARD = 256;         // digest accumulator shards (one 64-byte line each)
+constexpr int SCAN_BLK = 2048;      // tiles per block of the tile-count prefix scan
 
 enum ScanMode { MODE_MINIMIZER = 0, MODE_SUPERKMER = 1, MODE_SYNCMER = 2 };
 
@@ -56,12 +57,17 @@ struct ScanParams {
     uint8_t* out_mmpos;          // super-k-mer: minimizer offset inside the first k-mer
     uint64_t* out_last;          // super-k-mer: position of the last k-mer of the group (scratch)
     uint64_t capacity;           // records the output arrays can hold
-    // inter-tile ordered compaction
-    unsigned long long* status;  // one word per tile: [63:62] flag, [61:31] ends, [30:0] starts
-    unsigned int* ticket;        // dynamic tile id
-    unsigned long long* shards;  // [NSHARD][8] digest accumulators
-    unsigned int* error;         // set non-zero on protocol timeout
-    uint32_t ablate;             // profiling only (env BL_ABLATE): bit mask of pipeline stages to skip; 0 in production
+    // two-pass ordered compaction (no inter-workgroup communication inside a kernel):
+    //   pass 1 (scan_count_kernel) writes per tile its record counts and its compacted u16 lists,
+    //   a prefix scan over the tile counts gives every tile its global record offset,
+    //   pass 2 (scan_emit_kernel) rebuilds the records of its tile and stores them at that offset.
+    unsigned long long* tile_counts;  // [n_tiles] starts | ends << 32
+    unsigned long long* tile_base;    // [n_tiles] exclusive prefix inside its scan block
+    unsigned long long* block_base;   // [ceil(n_tiles / SCAN_BLK)] exclusive prefix of the scan blocks
+    uint16_t* slots_a;                // [n_tiles][stride] list_a of every tile (first `starts` entries valid)
+    uint16_t* slots_j;                // super-k-mer: list_j
+    uint16_t* slots_e;                // super-k-mer: list_e (first `ends` entries valid)
+    unsigned long long* shards;       // [NSHARD][8] digest accumulators
 };
 
 // Tile plan shared by the C ABI (bl_capi.hip) and the emulation harness: which positions tile 0

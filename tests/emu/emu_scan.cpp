@@ -34,46 +34,80 @@ std::vector<uint32_t> make_start_bits(uint64_t n_bases, const uint64_t* offsets,
     return bits;
 }
 
+// pass 1 (scan_count_kernel) for every tile, the tile-count prefix scan, pass 2 (scan_emit_kernel)
 template <int MODE, int W>
-void run_tiles(const ScanParams& p, unsigned long long* result)
+void run_tiles(ScanParams p, unsigned long long* result)
 {
-    auto* sh = new TileShared<MODE, W>();
-    std::vector<ThreadState> st(TPB);
-    std::vector<uint32_t> packed(TPB), excl(TPB);
-    std::vector<uint8_t> af(TPB * (S + 1));
-    uint64_t base_s = 0, base_e = 0;
-    Digest dg{0, 0, 0};
-    for (int tile = 0; tile < p.n_tiles; ++tile) {
-        std::memset(sh, 0xA5, sizeof(*sh));  // poison: nothing may depend on stale LDS contents
-        std::memset(st.data(), 0x5A, st.size() * sizeof(ThreadState));
-        const int64_t q0 = p.origin + (int64_t)tile * p.stride;
-        for (int tid = 0; tid < TPB; ++tid) phase_load<MODE, W>(p, *sh, tid, q0);
-        for (int tid = 0; tid < TPB; ++tid) phase_hash<MODE, W>(p, *sh, tid, st[tid]);
-        if (MODE == MODE_SYNCMER) {
-            for (int tid = 0; tid < TPB; ++tid) phase_sync_fwd<MODE, W>(p, *sh, tid, st[tid], st.data(), &af[tid * (S + 1)]);
-            if (W == 0 && p.canonical)
-                for (int tid = 0; tid < TPB; ++tid) phase_publish_h2<MODE, W>(*sh, tid, st[tid]);
-            for (int tid = 0; tid < TPB; ++tid) packed[tid] = phase_sync_rev<MODE, W>(p, *sh, tid, q0, st[tid], st.data(), &af[tid * (S + 1)]);
-        } else {
-            for (int tid = 0; tid < TPB; ++tid) packed[tid] = phase_window<MODE, W>(p, *sh, tid, q0, st[tid], st.data());
+    const size_t nt = (size_t)p.n_tiles;
+    std::vector<unsigned long long> counts(nt), base(nt);
+    std::vector<uint16_t> sa(nt * p.stride), sj(MODE == MODE_SUPERKMER ? nt * p.stride : 1), se(MODE == MODE_SUPERKMER ? nt * p.stride : 1);
+    {
+        auto* sh = new TileShared<MODE, W>();
+        std::vector<ThreadState> st(TPB);
+        std::vector<uint32_t> packed(TPB), excl(TPB);
+        std::vector<uint8_t> af(TPB * (S + 1));
+        for (size_t tile = 0; tile < nt; ++tile) {
+            std::memset(sh, 0xA5, sizeof(*sh));  // poison: nothing may depend on stale LDS contents
+            std::memset(st.data(), 0x5A, st.size() * sizeof(ThreadState));
+            const int64_t q0 = p.origin + (int64_t)tile * p.stride;
+            for (int tid = 0; tid < TPB; ++tid) phase_load<MODE, W>(p, *sh, tid, q0);
+            for (int tid = 0; tid < TPB; ++tid) phase_hash<MODE, W>(p, *sh, tid, st[tid]);
+            if (MODE == MODE_SYNCMER) {
+                for (int tid = 0; tid < TPB; ++tid) phase_sync_fwd<MODE, W>(p, *sh, tid, st[tid], st.data(), &af[tid * (S + 1)]);
+                if (W == 0 && p.canonical)
+                    for (int tid = 0; tid < TPB; ++tid) phase_publish_h2<MODE, W>(*sh, tid, st[tid]);
+                for (int tid = 0; tid < TPB; ++tid)
+                    packed[tid] = phase_sync_rev<MODE, W>(p, *sh, tid, q0, st[tid], st.data(), &af[tid * (S + 1)]);
+            } else {
+                for (int tid = 0; tid < TPB; ++tid) packed[tid] = phase_window<MODE, W>(p, *sh, tid, q0, st[tid], st.data());
+            }
+            uint32_t run = 0;
+            for (int tid = 0; tid < TPB; ++tid) {
+                excl[tid] = run;
+                run += packed[tid];
+            }
+            const uint32_t n_s = run & 0xffffu, n_e = run >> 16;
+            for (int tid = 0; tid < TPB; ++tid) phase_list<MODE, W>(*sh, tid, st[tid], excl[tid] & 0xffffu, excl[tid] >> 16);
+            counts[tile] = (unsigned long long)n_s | ((unsigned long long)n_e << 32);
+            for (uint32_t r = 0; r < n_s; ++r) {
+                sa[tile * p.stride + r] = sh->list_a[r];
+                if (MODE == MODE_SUPERKMER) sj[tile * p.stride + r] = sh->list_j[r];
+            }
+            if (MODE == MODE_SUPERKMER)
+                for (uint32_t r = 0; r < n_e; ++r) se[tile * p.stride + r] = sh->list_e[r];
         }
-        uint32_t run = 0;
-        for (int tid = 0; tid < TPB; ++tid) {
-            excl[tid] = run;
-            run += packed[tid];
-        }
-        const uint32_t n_s = run & 0xffffu, n_e = run >> 16;
-        for (int tid = 0; tid < TPB; ++tid) phase_list<MODE, W>(*sh, tid, st[tid], excl[tid] & 0xffffu, excl[tid] >> 16);
-        for (int tid = 0; tid < TPB; ++tid) phase_emit<MODE, W>(p, *sh, tid, q0, n_s, n_e, base_s, base_e, dg);
-        base_s += n_s;
-        base_e += n_e;
+        delete sh;
     }
-    result[0] = base_s;
+    unsigned long long run = 0;
+    for (size_t tile = 0; tile < nt; ++tile) {
+        base[tile] = run;
+        run += counts[tile];
+    }
+    Digest dg{0, 0, 0};
+    {
+        auto* sh = new TileShared<MODE, 1>();
+        for (size_t tile = 0; tile < nt; ++tile) {
+            const uint32_t n_s = (uint32_t)counts[tile], n_e = (uint32_t)(counts[tile] >> 32);
+            if (n_s == 0 && n_e == 0) continue;
+            std::memset(sh, 0xA5, sizeof(*sh));
+            const int64_t q0 = p.origin + (int64_t)tile * p.stride;
+            for (int tid = 0; tid < TPB; ++tid) phase_load<MODE, 1>(p, *sh, tid, q0);
+            for (uint32_t r = 0; r < n_s; ++r) {
+                sh->list_a[r] = sa[tile * p.stride + r];
+                if (MODE == MODE_SUPERKMER) sh->list_j[r] = sj[tile * p.stride + r];
+            }
+            if (MODE == MODE_SUPERKMER)
+                for (uint32_t r = 0; r < n_e; ++r) sh->list_e[r] = se[tile * p.stride + r];
+            for (int tid = 0; tid < TPB; ++tid)
+                phase_emit<MODE, 1>(p, *sh, tid, q0, n_s, n_e, base[tile] & 0xffffffffull, base[tile] >> 32, dg);
+        }
+        delete sh;
+    }
+    result[0] = run & 0xffffffffull;
     result[1] = dg.xv;
     result[2] = dg.xh;
     result[3] = dg.xp;
-    result[4] = base_e;
-    delete sh;
+    result[4] = run >> 32;
 }
 
 template <int MODE>

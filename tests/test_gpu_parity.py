@@ -256,3 +256,29 @@ def test_large_batch_properties_and_oracle_digest(ctx):
     cnt, _ = O.syncmers(seq2[:2_000_000], O.fixed_offsets(2_000_000, 10_000), 31, 11, 0, 20, True, threads=16, positions=False)
     part = b2.syncmers(31, 11, 0, 20, canonical=True, positions=False, first=0, n=2_000_000)
     assert part["count"] == cnt and sy["count"] > cnt
+
+
+def test_async_scans_on_internal_lanes():
+    """With the context's own streams, consecutive asynchronous scans alternate between two lanes and
+    overlap; results and outputs are valid after ctx.sync() and equal the synchronous ones."""
+    import biolib_amd as B
+
+    c = B.Context(0, torch_stream=False)
+    n = 12_000_000
+    b = c.synth(5, n, 150)
+    cuts = [(i * 2_000_000, 2_000_000) for i in range(6)]
+    cap = 400_000
+    outs = [(c.empty_u64(cap), c.empty_u64(cap), c.empty_u64(cap)) for _ in cuts]
+    res = [B.Result() for _ in cuts]
+    for (a, m), (v, p, h), r in zip(cuts, outs, res):
+        b.minimizers_raw(31, 11, 42, B.FLAG_CANONICAL, first=a, n=m, values=v, positions=p, hashes=h, capacity=cap, result=r)
+    sk = B.Result()
+    b.syncmers_raw(31, 11, 0, 20, 0, B.FLAG_CANONICAL, first=0, n=n, result=sk)
+    c.sync()
+    whole = b.minimizers(31, 11, seed=42, canonical=True)
+    assert sum(int(r.count) for r in res) == whole["count"] and all(r.status == 0 for r in res)
+    pos = np.concatenate([p[: int(r.count)].cpu().numpy().view(np.uint64) for (v, p, h), r in zip(outs, res)])
+    hsh = np.concatenate([h[: int(r.count)].cpu().numpy().view(np.uint64) for (v, p, h), r in zip(outs, res)])
+    assert np.array_equal(pos, whole["positions"]) and np.array_equal(hsh, whole["hashes"])
+    assert int(sk.count) == b.syncmers(31, 11, 0, 20, canonical=True, positions=False)["count"]
+    c.close()
