@@ -118,14 +118,16 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         t_max = float(t.item())
-        # optional final k-mer-count style reduction over RCCL/xGMI (64-bit sum); outside the timed region
-        c = torch.tensor([count], dtype=torch.int64, device="cuda")
+        # optional final count reduction over RCCL/xGMI (64-bit sums all-reduced, XOR digests gathered and
+        # folded: biolib_amd/shard.py); outside the timed region, its time is reported
+        from biolib_amd.shard import reduce_digests
+
         torch.cuda.synchronize()
         ta = time.perf_counter()
-        dist.all_reduce(c, op=dist.ReduceOp.SUM)
+        tot = reduce_digests(dict(count=count, xor_hash=xor_hash), device="cuda")
         torch.cuda.synchronize()
         allreduce_ms = (time.perf_counter() - ta) * 1e3
-        total_count = int(c.item())
+        total_count, xor_hash = tot["count"], tot["xor_hash"]
         k = torch.tensor([kernel_ms], dtype=torch.float64, device="cuda")
         dist.all_reduce(k, op=dist.ReduceOp.MAX)
         kernel_ms = float(k.item())
@@ -164,7 +166,7 @@ def main():
                 "sharding": f"{n_gpus} independent shard(s), seed 42+rank",
             },
             "records_per_step": total_count,
-            "xor_hash_rank0": xor_hash,
+            "xor_hash": xor_hash,
             "roofline": {
                 "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5),
                 "traffic": traffic, "kernel": "bl::scan_kernel<MODE_MINIMIZER,11>", "avg_kernel_ms": round(avg_kernel_s * 1e3, 4),
@@ -183,6 +185,18 @@ def main():
     return out
 
 
+def usable_cores():
+    """threads worth starting: the affinity mask, capped by the cgroup CPU quota when there is one"""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
 def cpu_baseline(np, ctx, batch, n_bases):
     """The CPU oracle (oracle/bl_oracle.c, streaming variant = the reference's operation counts:
     per-base roll, one MurmurHash3_x64_128 per 31-mer, ring-buffer window minimum) on the first
@@ -190,7 +204,7 @@ def cpu_baseline(np, ctx, batch, n_bases):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
 
-    cores = len(os.sched_getaffinity(0))
+    cores = usable_cores()
     n1 = min(n_bases, 2_000_000 * READ_LEN)       # 300 Mbp single-thread (~8 s)
     nall = min(n_bases, 20_000_000 * READ_LEN)    # 3 Gbp on all cores
     seq = batch.download(0, nall)

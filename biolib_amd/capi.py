@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libbiolib_amd.so")
+LIB_PATH = os.environ.get("BIOLIB_AMD_LIB", os.path.join(_HERE, "lib", "libbiolib_amd.so"))  # override: A/B builds only
 
 BL_OK, BL_ERR_INVALID, BL_ERR_HIP, BL_ERR_OOM, BL_ERR_CAPACITY, BL_ERR_NO_DEVICE, BL_ERR_INTERNAL = 0, -1, -2, -3, -4, -5, -6
 FLAG_CANONICAL, FLAG_DROP_LAST, FLAG_SYNC = 1, 2, 4

@@ -46,9 +46,10 @@ struct Pending {
 
 }  // namespace
 
-// One execution lane: a stream plus the scratch its scans use.  With the context's own streams,
-// consecutive asynchronous scans alternate between two lanes, so the HBM-bound record pass of one
-// scan overlaps the ALU-bound hashing pass of the next; a borrowed caller stream uses lane 0 only.
+// One execution lane: a stream plus the scratch its scans use.  With BL_LANES=2 and the context's own
+// streams, consecutive asynchronous scans alternate between two lanes so that the record pass of one
+// scan can overlap the hashing pass of the next; measured on MI355X this gains nothing (both passes
+// are issue-bound), so the default is one lane.  A borrowed caller stream always uses lane 0.
 struct Lane {
     hipStream_t own = nullptr;
     unsigned char* ws = nullptr;  // [hdr 256 B][shards][result]
@@ -70,6 +71,7 @@ struct bl_ctx {
     Lane lanes[2];
     Lane* cur = nullptr;               // lane of the scan being issued / issued last
     int next_lane = 0;
+    int n_lanes = 1;                   // 2 (env BL_LANES=2): consecutive async scans alternate lanes (measured: no gain)
     hipStream_t user_stream = nullptr; // borrowed (bl_ctx_set_stream)
     hipStream_t stream = nullptr;      // stream of `cur`
     unsigned long long* pinned = nullptr;  // RING * RESULT_WORDS
@@ -127,7 +129,7 @@ void select_lane(bl_ctx* c)
         c->stream = c->user_stream;
     } else {
         c->cur = &c->lanes[c->next_lane];
-        c->next_lane ^= 1;
+        if (c->n_lanes == 2) c->next_lane ^= 1;
         c->stream = c->cur->own;
     }
 }
@@ -331,6 +333,7 @@ int bl_ctx_create(int device, bl_ctx** out)
     }
     c->cur = &c->lanes[0];
     c->stream = c->lanes[0].own;
+    if (const char* e = std::getenv("BL_LANES")) c->n_lanes = std::atoi(e) == 2 ? 2 : 1;
     *out = c;
     return BL_OK;
 }

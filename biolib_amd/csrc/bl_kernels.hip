@@ -52,12 +52,28 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* wave_t
     return before + incl - v;
 }
 
+// copy n u16 entries between LDS and the tile's global slot as dwords (both 4-byte aligned; the odd
+// tail entry travels with a don't-care partner)
+__device__ __forceinline__ void spill_list(uint16_t* dst, const uint16_t* src, uint32_t n, int tid)
+{
+    uint32_t* d32 = reinterpret_cast<uint32_t*>(dst);
+    const uint32_t* s32 = reinterpret_cast<const uint32_t*>(src);
+    for (uint32_t i = tid; i < (n + 1) / 2; i += TPB) d32[i] = s32[i];
+}
+
+__device__ __forceinline__ void fill_list(uint16_t* dst, const uint16_t* src, uint32_t n, int tid)
+{
+    uint32_t* d32 = reinterpret_cast<uint32_t*>(dst);
+    const uint32_t* s32 = reinterpret_cast<const uint32_t*>(src);
+    for (uint32_t i = tid; i < (n + 1) / 2; i += TPB) d32[i] = s32[i];
+}
+
 // ------------------------------------------------------------------------------------------------
 // Pass 1: one workgroup per tile.  Hash, window minimum, start/end decisions, tile-local compaction;
 // leaves the tile's record counts and u16 lists in global scratch.  Tiles are independent: no ticket,
 // no inter-workgroup wait, any dispatch order.
 template <int MODE, int W>
-__global__ __launch_bounds__(TPB, (MODE == MODE_SYNCMER || W == 0 ? 2 : (W <= 11 ? 6 : 4))) void scan_count_kernel(const ScanParams p)
+__global__ __launch_bounds__(TPB, (MODE == MODE_SYNCMER || W == 0 ? 2 : (W <= 11 ? 5 : 4))) void scan_count_kernel(const ScanParams p)
 {
     __shared__ TileShared<MODE, W> sh;
     const int tid = threadIdx.x;
@@ -93,14 +109,15 @@ __global__ __launch_bounds__(TPB, (MODE == MODE_SYNCMER || W == 0 ? 2 : (W <= 11
         if (tid == 0) p.tile_counts[tile] = (unsigned long long)n_s | ((unsigned long long)n_e << 32);
         __syncthreads();  // lists complete
 
-        // spill the compacted lists (2 bytes per record, coalesced)
-        const size_t slot = (size_t)tile * p.stride;
-        for (uint32_t r = tid; r < n_s; r += TPB) {
-            p.slots_a[slot + r] = sh.list_a[r];
-            if (MODE == MODE_SUPERKMER) p.slots_j[slot + r] = sh.list_j[r];
+        // spill the compacted lists: two u16 entries per 32-bit store (sub-dword global stores are not
+        // write-combined on gfx950: 2-byte stores cost a 32-byte memory write each, measured 6.4 GB of
+        // WRITE_SIZE per 1.5 Gbp launch for 0.4 GB of payload)
+        const size_t slot = (size_t)tile * p.stride;  // multiple of 16 entries: dword aligned
+        spill_list(p.slots_a + slot, sh.list_a, n_s, tid);
+        if (MODE == MODE_SUPERKMER) {
+            spill_list(p.slots_j + slot, sh.list_j, n_s, tid);
+            spill_list(p.slots_e + slot, sh.list_e, n_e, tid);
         }
-        if (MODE == MODE_SUPERKMER)
-            for (uint32_t r = tid; r < n_e; r += TPB) p.slots_e[slot + r] = sh.list_e[r];
     }
 }
 
@@ -175,12 +192,11 @@ __global__ __launch_bounds__(TPB) void scan_emit_kernel(const ScanParams p)
 
         __syncthreads();  // previous tile's LDS contents are dead
         phase_load<MODE, 1>(p, sh, tid, q0);
-        for (uint32_t r = tid; r < n_s; r += TPB) {
-            sh.list_a[r] = p.slots_a[slot + r];
-            if (MODE == MODE_SUPERKMER) sh.list_j[r] = p.slots_j[slot + r];
+        fill_list(sh.list_a, p.slots_a + slot, n_s, tid);
+        if (MODE == MODE_SUPERKMER) {
+            fill_list(sh.list_j, p.slots_j + slot, n_s, tid);
+            fill_list(sh.list_e, p.slots_e + slot, n_e, tid);
         }
-        if (MODE == MODE_SUPERKMER)
-            for (uint32_t r = tid; r < n_e; r += TPB) sh.list_e[r] = p.slots_e[slot + r];
         __syncthreads();
         phase_emit<MODE, 1>(p, sh, tid, q0, n_s, n_e, base_s, base_e, dg);
     }

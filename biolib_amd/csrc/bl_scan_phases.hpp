@@ -30,10 +30,10 @@ struct TileShared {
     uint32_t codes[NCHUNK];         // 2-bit codes, 16 bases per dword, first base most significant
     uint32_t flags[NCHUNK];         // [15:0] good-base bits, [31:16] sequence-start bits (bit b = base b)
     uint64_t hash[W == 0 ? S : 1][W == 0 ? TPB : 1];  // runtime-w fallback only: hash[s][tid]
-    uint16_t list_a[H];             // compacted records: (wave << 12) | wave-relative argmin position
+    alignas(4) uint16_t list_a[H];  // compacted records: (wave << 12) | wave-relative argmin position
                                     // (syncmer mode: the k-mer's own position)
-    uint16_t list_j[MODE == MODE_SUPERKMER ? H : 1];  // compacted: first window of the occurrence
-    uint16_t list_e[MODE == MODE_SUPERKMER ? H : 1];  // compacted: last window of the occurrence
+    alignas(4) uint16_t list_j[MODE == MODE_SUPERKMER ? H : 2];  // compacted: first window of the occurrence
+    alignas(4) uint16_t list_e[MODE == MODE_SUPERKMER ? H : 2];  // compacted: last window of the occurrence
     uint32_t wave_tot[NWAVE];
     unsigned long long dig[4];
     uint32_t tile;

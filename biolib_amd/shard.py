@@ -1,0 +1,60 @@
+"""Multi-GPU sharding of a batch of reads and the final count reduction.
+
+The scan is embarrassingly parallel over sequences (every read / contig is scanned independently,
+SURVEY.md §8e), so N GPUs = N independent shards: contiguous ranges of reads balanced by count,
+one process per GPU, no data-path collective.  The only exchange is the optional reduction of the
+per-shard digests at the end: counts are summed with one all-reduce (RCCL over xGMI when the
+backend is "nccl", gloo in the CPU tests); XOR digests, for which RCCL has no reduction op, are
+all-gathered (8 bytes each) and folded locally.
+"""
+import numpy as np
+
+
+def shard_reads(n_reads, world_size, rank):
+    """Contiguous, balanced range of reads for `rank`: (first_read, n_reads_of_rank)."""
+    base, extra = divmod(int(n_reads), int(world_size))
+    first = rank * base + min(rank, extra)
+    return first, base + (1 if rank < extra else 0)
+
+
+def shard_ranges(offsets, world_size, rank):
+    """For ragged batches: split the sequences so that every rank gets about the same number of BASES.
+    offsets: uint64[n_seqs+1].  Returns (first_seq, end_seq)."""
+    offsets = np.asarray(offsets, dtype=np.uint64)
+    total = int(offsets[-1])
+    lo = np.searchsorted(offsets, np.uint64(total * rank // world_size), side="left")
+    hi = np.searchsorted(offsets, np.uint64(total * (rank + 1) // world_size), side="left")
+    n_seqs = len(offsets) - 1
+    lo = 0 if rank == 0 else min(int(lo), n_seqs)
+    hi = n_seqs if rank == world_size - 1 else min(int(hi), n_seqs)
+    return lo, max(hi, lo)
+
+
+def reduce_digests(local, device=None, group=None):
+    """local: dict with integer 'count' (and optionally other *_count / sum_* keys, summed) and xor_* keys
+    (folded with XOR).  Returns the whole-job digest on every rank.  Without an initialised process
+    group the input is returned unchanged."""
+    import torch
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()):
+        return dict(local)
+    sums = sorted(k for k in local if not k.startswith("xor_"))
+    xors = sorted(k for k in local if k.startswith("xor_"))
+    out = {}
+    if sums:
+        # uint64 wrap-around sums travel as int64 bit patterns
+        t = torch.tensor(np.array([local[k] for k in sums], dtype=np.uint64).view(np.int64), dtype=torch.int64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        vals = t.cpu().numpy().view(np.uint64)
+        out.update({k: int(v) for k, v in zip(sums, vals)})
+    if xors:
+        t = torch.tensor(np.array([local[k] for k in xors], dtype=np.uint64).view(np.int64), dtype=torch.int64, device=device)
+        world = dist.get_world_size(group)
+        gathered = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(gathered, t, group=group)
+        acc = np.zeros(len(xors), dtype=np.uint64)
+        for g in gathered:
+            acc ^= g.cpu().numpy().view(np.uint64)
+        out.update({k: int(v) for k, v in zip(xors, acc)})
+    return out
