@@ -3,6 +3,7 @@
 // plus a 1-bit-per-base sequence-start vector; scans enqueue  memset -> tile kernel -> digest fold
 // -> async copy of the 72-byte result into a pinned slot, all on the context's stream.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -593,13 +594,19 @@ static int scan_windows(int mode, bl_ctx* c, const bl_batch* b, uint64_t first, 
     p.slots_j = mode == bl::MODE_SUPERKMER ? c->cur->slot_buf + slot_entries : nullptr;
     p.slots_e = mode == bl::MODE_SUPERKMER ? c->cur->slot_buf + 2 * slot_entries : nullptr;
     p.shards = c->shards();
+    // count -> tile prefix scan -> emit, all tiles in one group (the prefix scan supports several
+    // groups with a running carry; one group is what is used)
+    const bl::GroupRange all{0, (uint32_t)p.n_tiles};
+    unsigned long long* carry = reinterpret_cast<unsigned long long*>(c->cur->ws);  // header word, zeroed by begin_scan
     rc = kernel_event(c, true);
     if (rc != BL_OK) return rc;
-    hipError_t e = bl::launch_scan_count(mode, p, c->stream);  // pass 1: the dominant kernel (timed alone)
+    hipError_t e = bl::launch_scan_count(mode, p, all, c->stream);  // pass 1: the dominant kernel (timed alone)
     if (e != hipSuccess) return fail(BL_ERR_HIP, std::string("scan_count_kernel: ") + hipGetErrorString(e));
     rc = kernel_event(c, false);
     if (rc != BL_OK) return rc;
-    e = bl::launch_scan_emit(mode, p, block_tot, c->stream);    // tile prefix scan + pass 2
+    e = bl::launch_tile_scan(p, all, block_tot, carry, c->stream);
+    if (e != hipSuccess) return fail(BL_ERR_HIP, std::string("tile_scan: ") + hipGetErrorString(e));
+    e = bl::launch_scan_emit(mode, p, all, c->stream);  // pass 2
     if (e != hipSuccess) return fail(BL_ERR_HIP, std::string("scan_emit_kernel: ") + hipGetErrorString(e));
     return BL_OK;
 }

@@ -69,70 +69,132 @@ __device__ __forceinline__ void fill_list(uint16_t* dst, const uint16_t* src, ui
 }
 
 // ------------------------------------------------------------------------------------------------
-// Pass 1: one workgroup per tile.  Hash, window minimum, start/end decisions, tile-local compaction;
-// leaves the tile's record counts and u16 lists in global scratch.  Tiles are independent: no ticket,
-// no inter-workgroup wait, any dispatch order.
+// Pass 1 of one tile: hash, window minimum, start/end decisions, tile-local compaction; leaves the
+// tile's record counts and u16 lists in global scratch.  Tiles are independent: no ticket, no
+// inter-workgroup wait, any dispatch order.
 template <int MODE, int W>
-__global__ __launch_bounds__(TPB, (MODE == MODE_SYNCMER || W == 0 ? 2 : (W <= 11 ? 5 : 4))) void scan_count_kernel(const ScanParams p)
+__device__ __forceinline__ void count_tile(const ScanParams& p, TileShared<MODE, W>& sh, uint32_t tile, int tid)
 {
-    __shared__ TileShared<MODE, W> sh;
-    const int tid = threadIdx.x;
-    // a workgroup walks tiles blockIdx, blockIdx + gridDim, ... (normally exactly one: grid = n_tiles)
-    for (uint32_t tile = blockIdx.x; tile < (uint32_t)p.n_tiles; tile += gridDim.x) {
-        const int64_t q0 = p.origin + (int64_t)tile * p.stride;
-        __syncthreads();  // previous tile's LDS contents are dead
-        phase_load<MODE, W>(p, sh, tid, q0);
-        __syncthreads();
+    const int64_t q0 = p.origin + (int64_t)tile * p.stride;
+    phase_load<MODE, W>(p, sh, tid, q0);
+    __syncthreads();
 
-        ThreadState st;
-        phase_hash<MODE, W>(p, sh, tid, st);
-        if (W == 0) __syncthreads();  // runtime-w fallback exchanges hashes through LDS
+    ThreadState st;
+    phase_hash<MODE, W>(p, sh, tid, st);
+    if (W == 0) __syncthreads();  // runtime-w fallback exchanges hashes through LDS
 
-        uint32_t packed;
-        if (MODE == MODE_SYNCMER) {
-            uint8_t af[S + 1];
-            phase_sync_fwd<MODE, W>(p, sh, tid, st, nullptr, af);
-            if (W == 0 && p.canonical) {
-                __syncthreads();
-                phase_publish_h2<MODE, W>(sh, tid, st);
-                __syncthreads();
-            }
-            packed = phase_sync_rev<MODE, W>(p, sh, tid, q0, st, nullptr, af);
-        } else {
-            packed = phase_window<MODE, W>(p, sh, tid, q0, st, nullptr);
+    uint32_t packed;
+    if (MODE == MODE_SYNCMER) {
+        uint8_t af[S + 1];
+        phase_sync_fwd<MODE, W>(p, sh, tid, st, nullptr, af);
+        if (W == 0 && p.canonical) {
+            __syncthreads();
+            phase_publish_h2<MODE, W>(sh, tid, st);
+            __syncthreads();
         }
+        packed = phase_sync_rev<MODE, W>(p, sh, tid, q0, st, nullptr, af);
+    } else {
+        packed = phase_window<MODE, W>(p, sh, tid, q0, st, nullptr);
+    }
 
-        uint32_t total;
-        const uint32_t excl = block_excl_scan(packed, sh.wave_tot, tid, total);
-        const uint32_t n_s = total & 0xffffu, n_e = total >> 16;  // a tile owns fewer than H positions: 16 bits suffice
-        phase_list<MODE, W>(sh, tid, st, excl & 0xffffu, excl >> 16);
-        if (tid == 0) p.tile_counts[tile] = (unsigned long long)n_s | ((unsigned long long)n_e << 32);
-        __syncthreads();  // lists complete
+    uint32_t total;
+    const uint32_t excl = block_excl_scan(packed, sh.wave_tot, tid, total);
+    const uint32_t n_s = total & 0xffffu, n_e = total >> 16;  // a tile owns fewer than H positions: 16 bits suffice
+    phase_list<MODE, W>(sh, tid, st, excl & 0xffffu, excl >> 16);
+    if (tid == 0) p.tile_counts[tile] = (unsigned long long)n_s | ((unsigned long long)n_e << 32);
+    __syncthreads();  // lists complete
 
-        // spill the compacted lists: two u16 entries per 32-bit store (sub-dword global stores are not
-        // write-combined on gfx950: 2-byte stores cost a 32-byte memory write each, measured 6.4 GB of
-        // WRITE_SIZE per 1.5 Gbp launch for 0.4 GB of payload)
-        const size_t slot = (size_t)tile * p.stride;  // multiple of 16 entries: dword aligned
-        spill_list(p.slots_a + slot, sh.list_a, n_s, tid);
-        if (MODE == MODE_SUPERKMER) {
-            spill_list(p.slots_j + slot, sh.list_j, n_s, tid);
-            spill_list(p.slots_e + slot, sh.list_e, n_e, tid);
-        }
+    // spill the compacted lists: two u16 entries per 32-bit store (sub-dword global stores are not
+    // write-combined on gfx950: 2-byte stores cost a 32-byte memory write each, measured 6.4 GB of
+    // WRITE_SIZE per 1.5 Gbp launch for 0.4 GB of payload)
+    const size_t slot = (size_t)tile * p.stride;  // multiple of 16 entries: dword aligned
+    spill_list(p.slots_a + slot, sh.list_a, n_s, tid);
+    if (MODE == MODE_SUPERKMER) {
+        spill_list(p.slots_j + slot, sh.list_j, n_s, tid);
+        spill_list(p.slots_e + slot, sh.list_e, n_e, tid);
     }
 }
 
+// Pass 2 of one tile: re-stage the tile's 2-bit codes, rebuild each record from its u16 list entry
+// (unit value, hash, position) and store it at the tile's global offset with coalesced stores.
+template <int MODE, int W>
+__device__ __forceinline__ void emit_tile(const ScanParams& p, TileShared<MODE, W>& sh, uint32_t tile, int tid, Digest& dg)
+{
+    // one memory round trip: every load of the tile is issued before the first one is consumed
+    const int64_t q0 = p.origin + (int64_t)tile * p.stride;
+    const size_t slot = (size_t)tile * p.stride;
+    const unsigned long long cnt = p.tile_counts[tile];
+    const unsigned long long base = p.tile_base[tile] + p.block_base[tile / SCAN_BLK];
+    const int needed = wave_chunk0(p, NWAVE - 1) + WCHUNK;
+    const Vec16 c0 = tid < needed ? load_chunk(p, tid, q0) : Vec16{0, 0, 0, 0};
+    const Vec16 c1 = TPB + tid < needed ? load_chunk(p, TPB + tid, q0) : Vec16{0, 0, 0, 0};
+    // the first 2*TPB list entries speculatively (a tile of 150-bp reads holds ~545)
+    const uint32_t* sa32 = reinterpret_cast<const uint32_t*>(p.slots_a + slot);
+    const uint32_t la = 2 * tid < p.stride ? sa32[tid] : 0;
+    const uint32_t n_s = (uint32_t)cnt, n_e = (uint32_t)(cnt >> 32);
+    if (n_s == 0 && n_e == 0) return;  // uniform for the workgroup
+    const uint64_t base_s = base & 0xffffffffull, base_e = base >> 32;
+
+    if (tid < needed) sh.codes[tid] = codes_of(c0);
+    if (TPB + tid < needed) sh.codes[TPB + tid] = codes_of(c1);
+    reinterpret_cast<uint32_t*>(sh.list_a)[tid] = la;
+    for (uint32_t i = TPB + tid; i < (n_s + 1) / 2; i += TPB) reinterpret_cast<uint32_t*>(sh.list_a)[i] = sa32[i];
+    if (MODE == MODE_SUPERKMER) {
+        fill_list(sh.list_j, p.slots_j + slot, n_s, tid);
+        fill_list(sh.list_e, p.slots_e + slot, n_e, tid);
+    }
+    __syncthreads();
+    phase_emit<MODE, W>(p, sh, tid, q0, n_s, n_e, base_s, base_e, dg);
+}
+
 // ------------------------------------------------------------------------------------------------
-// Prefix scan over the tile counts (two 32-bit counters packed in 64 bits; totals stay below 2^31).
+// The two kernels.  One workgroup per tile; a scan is  count -> tile prefix scan -> emit  on one stream.
+// (Fusing pass 1 of one tile group with pass 2 of the previous one into a single launch — even
+// workgroups counting, odd ones emitting — was measured SLOWER, 200 vs 290 Gbp/s: the emit
+// workgroups inherit pass 1's 96-VGPR footprint and take residency away from the ALU-bound pass.)
+template <int MODE, int W>
+__global__ __launch_bounds__(TPB, (MODE == MODE_SYNCMER || W == 0 ? 2 : (W <= 11 ? 5 : 4))) void scan_count_kernel(const ScanParams p, GroupRange g)
+{
+    __shared__ TileShared<MODE, W> sh;
+    if (blockIdx.x < g.count) count_tile<MODE, W>(p, sh, g.first + blockIdx.x, threadIdx.x);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(TPB) void scan_emit_kernel(const ScanParams p, GroupRange g)
+{
+    __shared__ TileShared<MODE, 1> sh;  // W only sizes the fallback hash array: not used here
+    const int tid = threadIdx.x;
+    if (blockIdx.x >= g.count) return;
+    Digest dg{0, 0, 0};
+    emit_tile<MODE, 1>(p, sh, g.first + blockIdx.x, tid, dg);
+
+    // digest: wave reduce -> LDS -> one set of atomics per workgroup into a shard line
+    __syncthreads();
+    if (tid < 4) sh.dig[tid] = 0;
+    __syncthreads();
+    const unsigned long long xv = wave_xor_u64(dg.xv), xh = wave_xor_u64(dg.xh), xp = wave_xor_u64(dg.xp);
+    if ((tid & 63) == 0) {
+        atomicXor(&sh.dig[1], xv);
+        atomicXor(&sh.dig[2], xh);
+        atomicXor(&sh.dig[3], xp);
+    }
+    __syncthreads();
+    if (tid >= 1 && tid < 4) atomicXor(&p.shards[8 * (blockIdx.x % NSHARD) + tid], sh.dig[tid]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Prefix scan over the tile counts of one group (two 32-bit counters packed in 64 bits; totals stay
+// below 2^31).  Block b of the group covers tiles first + b*SCAN_BLK ...
 __global__ __launch_bounds__(512) void tile_scan_local_kernel(const unsigned long long* counts, unsigned long long* tile_base,
-                                                              unsigned long long* block_tot, int n_tiles)
+                                                              unsigned long long* block_tot, uint32_t first_tile, uint32_t n_group)
 {
     __shared__ unsigned long long wtot[8];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int first = blockIdx.x * SCAN_BLK + tid * 4;
+    const uint32_t rel = blockIdx.x * SCAN_BLK + tid * 4;  // tile index inside the group
     unsigned long long c[4], run = 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        c[i] = first + i < n_tiles ? counts[first + i] : 0;
+        c[i] = rel + i < n_group ? counts[first_tile + rel + i] : 0;
         run += c[i];
     }
     unsigned long long incl = run;
@@ -152,66 +214,27 @@ __global__ __launch_bounds__(512) void tile_scan_local_kernel(const unsigned lon
     unsigned long long ex = before + incl - run;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        if (first + i < n_tiles) tile_base[first + i] = ex;
+        if (rel + i < n_group) tile_base[first_tile + rel + i] = ex;
         ex += c[i];
     }
-    if (tid == 0) block_tot[blockIdx.x] = all;
+    if (tid == 0) block_tot[first_tile / SCAN_BLK + blockIdx.x] = all;
 }
 
-// one thread: exclusive scan of the (few hundred) block totals; the grand totals go to the digest
-__global__ void tile_scan_top_kernel(const unsigned long long* block_tot, unsigned long long* block_base, int n_blocks,
-                                     unsigned long long* shards)
+// one thread: exclusive scan of the group's block totals, continuing from the running total of the
+// previous groups (*carry); the grand totals go to the digest
+__global__ void tile_scan_top_kernel(const unsigned long long* block_tot, unsigned long long* block_base, uint32_t first_block,
+                                     uint32_t n_blocks, unsigned long long* carry, unsigned long long* shards)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    unsigned long long run = 0;
-    for (int i = 0; i < n_blocks; ++i) {
-        block_base[i] = run;
-        run += block_tot[i];
+    unsigned long long run = *carry;
+    const unsigned long long before = run;
+    for (uint32_t i = 0; i < n_blocks; ++i) {
+        block_base[first_block + i] = run;
+        run += block_tot[first_block + i];
     }
-    shards[0] += run & 0xffffffffull;  // records (starts)
-    shards[4] += run >> 32;            // group ends (super-k-mer mode)
-}
-
-// ------------------------------------------------------------------------------------------------
-// Pass 2: one workgroup per tile.  Re-stage the tile's codes, rebuild each record from its u16 list
-// entry (unit value, hash, position) and store it at the tile's global offset with coalesced stores.
-template <int MODE>
-__global__ __launch_bounds__(TPB) void scan_emit_kernel(const ScanParams p)
-{
-    __shared__ TileShared<MODE, 1> sh;  // W only sizes the fallback hash array: not used here
-    const int tid = threadIdx.x;
-    Digest dg{0, 0, 0};
-    for (uint32_t tile = blockIdx.x; tile < (uint32_t)p.n_tiles; tile += gridDim.x) {
-        const unsigned long long cnt = p.tile_counts[tile];
-        const uint32_t n_s = (uint32_t)cnt, n_e = (uint32_t)(cnt >> 32);
-        if (n_s == 0 && n_e == 0) continue;  // uniform for the workgroup
-        const unsigned long long base = p.tile_base[tile] + p.block_base[tile / SCAN_BLK];
-        const uint64_t base_s = base & 0xffffffffull, base_e = base >> 32;
-        const int64_t q0 = p.origin + (int64_t)tile * p.stride;
-        const size_t slot = (size_t)tile * p.stride;
-
-        __syncthreads();  // previous tile's LDS contents are dead
-        phase_load<MODE, 1>(p, sh, tid, q0);
-        fill_list(sh.list_a, p.slots_a + slot, n_s, tid);
-        if (MODE == MODE_SUPERKMER) {
-            fill_list(sh.list_j, p.slots_j + slot, n_s, tid);
-            fill_list(sh.list_e, p.slots_e + slot, n_e, tid);
-        }
-        __syncthreads();
-        phase_emit<MODE, 1>(p, sh, tid, q0, n_s, n_e, base_s, base_e, dg);
-    }
-
-    // digest: wave reduce -> LDS -> one set of atomics per workgroup into a shard line
-    if (tid < 4) sh.dig[tid] = 0;
-    __syncthreads();
-    const unsigned long long xv = wave_xor_u64(dg.xv), xh = wave_xor_u64(dg.xh), xp = wave_xor_u64(dg.xp);
-    if ((tid & 63) == 0) {
-        atomicXor(&sh.dig[1], xv);
-        atomicXor(&sh.dig[2], xh);
-        atomicXor(&sh.dig[3], xp);
-    }
-    __syncthreads();
-    if (tid >= 1 && tid < 4) atomicXor(&p.shards[8 * (blockIdx.x % NSHARD) + tid], sh.dig[tid]);
+    *carry = run;
+    shards[0] += (run - before) & 0xffffffffull;  // records (starts)
+    shards[4] += (run >> 32) - (before >> 32);    // group ends (super-k-mer mode)
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -340,64 +363,53 @@ __global__ void start_bits_offsets_kernel(uint32_t* bits, const uint64_t* offset
 // ------------------------------------------------------------------------------------------------
 // launchers
 
-// Grid size: one workgroup per tile by default (measured fastest: 3.7 ms vs 4.5 ms per 1.5 Gbp for a
-// persistent grid of 5 workgroups per CU).  BL_GRID1 / BL_GRID2 = workgroups per CU make the count /
-// emit kernels persistent for experiments; the kernels' tile loops handle either.
-static unsigned grid_for(int n_tiles, const char* env)
-{
-    const char* e = std::getenv(env);
-    const int per_cu = e ? std::atoi(e) : 0;
-    if (per_cu <= 0) return (unsigned)n_tiles;
-    static int n_cu = 0;
-    if (n_cu == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
-        if (n_cu <= 0) n_cu = 256;
-    }
-    const long g = (long)n_cu * per_cu;
-    return (unsigned)(n_tiles < g ? n_tiles : g);
-}
-
 template <int MODE>
-static hipError_t launch_count(const ScanParams& p, hipStream_t stream)
+static hipError_t launch_count_mode(const ScanParams& p, GroupRange g, hipStream_t stream)
 {
-    const dim3 grid(grid_for(p.n_tiles, "BL_GRID1")), block(TPB);
+    const dim3 grid(g.count), block(TPB);
     switch (p.w) {
-        case 11: hipLaunchKernelGGL((scan_count_kernel<MODE, 11>), grid, block, 0, stream, p); break;
-        case 17: hipLaunchKernelGGL((scan_count_kernel<MODE, 17>), grid, block, 0, stream, p); break;
-        case 21: hipLaunchKernelGGL((scan_count_kernel<MODE, 21>), grid, block, 0, stream, p); break;
-        default: hipLaunchKernelGGL((scan_count_kernel<MODE, 0>), grid, block, 0, stream, p); break;
+        case 11: hipLaunchKernelGGL((scan_count_kernel<MODE, 11>), grid, block, 0, stream, p, g); break;
+        case 17: hipLaunchKernelGGL((scan_count_kernel<MODE, 17>), grid, block, 0, stream, p, g); break;
+        case 21: hipLaunchKernelGGL((scan_count_kernel<MODE, 21>), grid, block, 0, stream, p, g); break;
+        default: hipLaunchKernelGGL((scan_count_kernel<MODE, 0>), grid, block, 0, stream, p, g); break;
     }
     return hipGetLastError();
 }
 
-// pass 1
-hipError_t launch_scan_count(int mode, const ScanParams& p, hipStream_t stream)
+// pass 1 over the tiles of group g
+hipError_t launch_scan_count(int mode, const ScanParams& p, GroupRange g, hipStream_t stream)
 {
-    if (p.n_tiles <= 0) return hipSuccess;
+    if (g.count == 0) return hipSuccess;
     switch (mode) {
-        case MODE_MINIMIZER: return launch_count<MODE_MINIMIZER>(p, stream);
-        case MODE_SUPERKMER: return launch_count<MODE_SUPERKMER>(p, stream);
-        case MODE_SYNCMER: return launch_count<MODE_SYNCMER>(p, stream);
+        case MODE_MINIMIZER: return launch_count_mode<MODE_MINIMIZER>(p, g, stream);
+        case MODE_SUPERKMER: return launch_count_mode<MODE_SUPERKMER>(p, g, stream);
+        case MODE_SYNCMER: return launch_count_mode<MODE_SYNCMER>(p, g, stream);
     }
     return hipErrorInvalidValue;
 }
 
-// prefix scan of the tile counts + pass 2
-hipError_t launch_scan_emit(int mode, const ScanParams& p, unsigned long long* block_tot, hipStream_t stream)
+// pass 2 over the tiles of group g (its prefix scan must have run)
+hipError_t launch_scan_emit(int mode, const ScanParams& p, GroupRange g, hipStream_t stream)
 {
-    if (p.n_tiles <= 0) return hipSuccess;
-    const int n_blocks = (p.n_tiles + SCAN_BLK - 1) / SCAN_BLK;
-    hipLaunchKernelGGL(tile_scan_local_kernel, dim3(n_blocks), dim3(512), 0, stream, p.tile_counts, p.tile_base, block_tot, p.n_tiles);
-    hipLaunchKernelGGL(tile_scan_top_kernel, dim3(1), dim3(64), 0, stream, block_tot, p.block_base, n_blocks, p.shards);
-    const dim3 grid(grid_for(p.n_tiles, "BL_GRID2")), block(TPB);
+    if (g.count == 0) return hipSuccess;
+    const dim3 grid(g.count), block(TPB);
     switch (mode) {
-        case MODE_MINIMIZER: hipLaunchKernelGGL((scan_emit_kernel<MODE_MINIMIZER>), grid, block, 0, stream, p); break;
-        case MODE_SUPERKMER: hipLaunchKernelGGL((scan_emit_kernel<MODE_SUPERKMER>), grid, block, 0, stream, p); break;
-        case MODE_SYNCMER: hipLaunchKernelGGL((scan_emit_kernel<MODE_SYNCMER>), grid, block, 0, stream, p); break;
+        case MODE_MINIMIZER: hipLaunchKernelGGL((scan_emit_kernel<MODE_MINIMIZER>), grid, block, 0, stream, p, g); break;
+        case MODE_SUPERKMER: hipLaunchKernelGGL((scan_emit_kernel<MODE_SUPERKMER>), grid, block, 0, stream, p, g); break;
+        case MODE_SYNCMER: hipLaunchKernelGGL((scan_emit_kernel<MODE_SYNCMER>), grid, block, 0, stream, p, g); break;
         default: return hipErrorInvalidValue;
     }
+    return hipGetLastError();
+}
+
+// prefix scan of the tile counts of group g (first tile must be a multiple of SCAN_BLK)
+hipError_t launch_tile_scan(const ScanParams& p, GroupRange g, unsigned long long* block_tot, unsigned long long* carry, hipStream_t stream)
+{
+    if (g.count == 0) return hipSuccess;
+    const uint32_t n_blocks = (g.count + SCAN_BLK - 1) / SCAN_BLK;
+    hipLaunchKernelGGL(tile_scan_local_kernel, dim3(n_blocks), dim3(512), 0, stream, p.tile_counts, p.tile_base, block_tot, g.first, g.count);
+    hipLaunchKernelGGL(tile_scan_top_kernel, dim3(1), dim3(64), 0, stream, block_tot, p.block_base, g.first / SCAN_BLK, n_blocks, carry,
+                       p.shards);
     return hipGetLastError();
 }
 

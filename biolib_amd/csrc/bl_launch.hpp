@@ -4,8 +4,9 @@
 #include "bl_scan_phases.hpp"
 
 namespace bl {
-hipError_t launch_scan_count(int mode, const ScanParams& p, hipStream_t stream);
-hipError_t launch_scan_emit(int mode, const ScanParams& p, unsigned long long* block_tot, hipStream_t stream);
+hipError_t launch_scan_count(int mode, const ScanParams& p, GroupRange g, hipStream_t stream);
+hipError_t launch_scan_emit(int mode, const ScanParams& p, GroupRange g, hipStream_t stream);
+hipError_t launch_tile_scan(const ScanParams& p, GroupRange g, unsigned long long* block_tot, unsigned long long* carry, hipStream_t stream);
 hipError_t launch_kmers(const KmerParams& p, int n_blocks, hipStream_t stream);
 hipError_t launch_reduce_shards(const unsigned long long* shards, unsigned long long* result, uint32_t add_mask, hipStream_t stream);
 hipError_t launch_superkmer_size(const uint64_t* first, const uint64_t* last, uint8_t* size, const unsigned long long* count,

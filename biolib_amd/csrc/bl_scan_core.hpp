@@ -70,6 +70,11 @@ struct ScanParams {
     unsigned long long* shards;       // [NSHARD][8] digest accumulators
 };
 
+// a contiguous group of tiles handled by one stage of the software pipeline
+struct GroupRange {
+    uint32_t first, count;
+};
+
 // Tile plan shared by the C ABI (bl_capi.hip) and the emulation harness: which positions tile 0
 // starts at, how many positions a tile owns and how many tiles cover the range [first, end).
 BL_DEV int64_t align_down16(int64_t x) { return x >= 0 ? (x & ~15LL) : -(((-x) + 15) & ~15LL); }

@@ -80,6 +80,37 @@ BL_DEV void stage_chunk(const ScanParams& p, uint32_t* codes, uint32_t* flags, i
     flags[c] = (~bad & 0xffffu) | (start << 16);
 }
 
+// Pass 2 only needs the 2-bit codes (to rebuild unit values): no validity, no sequence starts.
+BL_DEV Vec16 load_chunk(const ScanParams& p, int c, int64_t q0)
+{
+    const int64_t g = q0 + 16 * (int64_t)c;
+    Vec16 v{0, 0, 0, 0};
+    if (g >= 0 && g + 16 <= p.n_bases) {
+        v = *reinterpret_cast<const Vec16*>(p.bases + g);
+    } else if (g + 16 > 0 && g < p.n_bases) {
+        uint32_t d[4] = {0, 0, 0, 0};
+        for (int b = 0; b < 16; ++b) {
+            const int64_t q = g + b;
+            if (q >= 0 && q < p.n_bases) d[b >> 2] |= (uint32_t)p.bases[q] << (8 * (b & 3));
+        }
+        v = Vec16{d[0], d[1], d[2], d[3]};
+    }
+    return v;
+}
+
+BL_DEV uint32_t codes_of(const Vec16& v)
+{
+    const uint32_t d[4] = {v.x, v.y, v.z, v.w};
+    uint32_t code = 0;
+    BL_UNROLL
+    for (int i = 0; i < 4; ++i) {
+        uint32_t x = (d[i] >> 1) & 0x03030303u;
+        x ^= (x >> 1) & 0x01010101u;
+        code = (code << 8) | ((x * 0x40100401u) >> 24);
+    }
+    return code;
+}
+
 // global position of the first hashed position of wave `wv` of the tile that starts at q0
 BL_DEV int64_t wave_origin(const ScanParams& p, int64_t q0, int wv) { return q0 + (int64_t)wv * (p.stride / NWAVE); }
 
