@@ -152,10 +152,17 @@ __device__ __forceinline__ void emit_tile(const ScanParams& p, TileShared<MODE, 
 // (Fusing pass 1 of one tile group with pass 2 of the previous one into a single launch — even
 // workgroups counting, odd ones emitting — was measured SLOWER, 200 vs 290 Gbp/s: the emit
 // workgroups inherit pass 1's 96-VGPR footprint and take residency away from the ALU-bound pass.)
-template <int MODE, int W>
-__global__ __launch_bounds__(TPB, (MODE == MODE_SYNCMER || W == 0 ? 2 : (W <= 11 ? 5 : 4))) void scan_count_kernel(const ScanParams p, GroupRange g)
+// U (unit length) and C (canonical flag) specialise the BASELINE configurations at compile time: the
+// parameter block is copied and the fields overwritten with constants, which the inlined phases fold
+// (constant shifts and masks in the roller, no strand selects).  U = 0 / C = -1: taken from the arguments.
+template <int MODE, int W, int U, int C>
+__global__ __launch_bounds__(TPB, (MODE == MODE_SYNCMER || W == 0 ? 2 : (W <= 11 ? 5 : 4))) void scan_count_kernel(const ScanParams pin, GroupRange g)
 {
     __shared__ TileShared<MODE, W> sh;
+    ScanParams p = pin;
+    if (U != 0) p.unit = U;
+    if (W != 0) p.w = W;
+    if (C >= 0) p.canonical = C;
     if (blockIdx.x < g.count) count_tile<MODE, W>(p, sh, g.first + blockIdx.x, threadIdx.x);
 }
 
@@ -367,11 +374,24 @@ template <int MODE>
 static hipError_t launch_count_mode(const ScanParams& p, GroupRange g, hipStream_t stream)
 {
     const dim3 grid(g.count), block(TPB);
+    // the BASELINE.json configurations, fully specialised
+    if (MODE == MODE_MINIMIZER && p.w == 11 && p.unit == 31 && p.canonical) {
+        hipLaunchKernelGGL((scan_count_kernel<MODE, 11, 31, 1>), grid, block, 0, stream, p, g);
+        return hipGetLastError();
+    }
+    if (MODE == MODE_SUPERKMER && p.w == 17 && p.unit == 15 && p.canonical) {
+        hipLaunchKernelGGL((scan_count_kernel<MODE, 17, 15, 1>), grid, block, 0, stream, p, g);
+        return hipGetLastError();
+    }
+    if (MODE == MODE_SYNCMER && p.w == 21 && p.unit == 11 && p.canonical) {
+        hipLaunchKernelGGL((scan_count_kernel<MODE, 21, 11, 1>), grid, block, 0, stream, p, g);
+        return hipGetLastError();
+    }
     switch (p.w) {
-        case 11: hipLaunchKernelGGL((scan_count_kernel<MODE, 11>), grid, block, 0, stream, p, g); break;
-        case 17: hipLaunchKernelGGL((scan_count_kernel<MODE, 17>), grid, block, 0, stream, p, g); break;
-        case 21: hipLaunchKernelGGL((scan_count_kernel<MODE, 21>), grid, block, 0, stream, p, g); break;
-        default: hipLaunchKernelGGL((scan_count_kernel<MODE, 0>), grid, block, 0, stream, p, g); break;
+        case 11: hipLaunchKernelGGL((scan_count_kernel<MODE, 11, 0, -1>), grid, block, 0, stream, p, g); break;
+        case 17: hipLaunchKernelGGL((scan_count_kernel<MODE, 17, 0, -1>), grid, block, 0, stream, p, g); break;
+        case 21: hipLaunchKernelGGL((scan_count_kernel<MODE, 21, 0, -1>), grid, block, 0, stream, p, g); break;
+        default: hipLaunchKernelGGL((scan_count_kernel<MODE, 0, 0, -1>), grid, block, 0, stream, p, g); break;
     }
     return hipGetLastError();
 }
