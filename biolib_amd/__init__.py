@@ -5,6 +5,6 @@ The product is the HIP library (biolib_amd/csrc -> biolib_amd/lib/libbiolib_amd.
 the thin host-side binding used by the tests and bench.py (ctypes + torch for device memory).
 """
 from .capi import BiolibError, FLAG_CANONICAL, FLAG_DROP_LAST, FLAG_SYNC, LIB_PATH, Result, lib  # noqa: F401
-from .scan import Batch, Context, hash64  # noqa: F401
+from .scan import Batch, Context, Reader, hash64  # noqa: F401
 
-__all__ = ["Batch", "Context", "BiolibError", "hash64", "lib", "LIB_PATH", "FLAG_CANONICAL", "FLAG_DROP_LAST", "FLAG_SYNC"]
+__all__ = ["Batch", "Context", "Reader", "BiolibError", "hash64", "lib", "LIB_PATH", "FLAG_CANONICAL", "FLAG_DROP_LAST", "FLAG_SYNC"]

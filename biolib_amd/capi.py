@@ -18,7 +18,8 @@ SYMBOLS = [
     "bl_last_error", "bl_version", "bl_device_count", "bl_ctx_create", "bl_ctx_destroy", "bl_ctx_set_stream", "bl_ctx_sync",
     "bl_batch_upload", "bl_batch_from_device", "bl_batch_synth", "bl_batch_destroy", "bl_batch_n_bases", "bl_batch_n_seqs",
     "bl_batch_device_bases", "bl_batch_download", "bl_scan_kmers", "bl_scan_minimizers", "bl_scan_super_kmers", "bl_scan_syncmers",
-    "bl_ctx_last_scan_ms", "bl_ctx_kernel_timing", "bl_ctx_kernel_time", "bl_device_alloc", "bl_device_free", "bl_copy_to_host", "bl_hash64_u64",
+    "bl_ctx_last_scan_ms", "bl_ctx_kernel_timing", "bl_ctx_kernel_time", "bl_reader_open", "bl_reader_close", "bl_reader_next_record",
+    "bl_reader_next_batch", "bl_reader_last_batch", "bl_reader_last_name", "bl_device_alloc", "bl_device_free", "bl_copy_to_host", "bl_hash64_u64",
 ]
 
 
@@ -80,6 +81,13 @@ def lib():
     L.bl_ctx_last_scan_ms.argtypes = [vp, C.POINTER(C.c_float)]
     L.bl_ctx_kernel_timing.argtypes = [vp, C.c_int]
     L.bl_ctx_kernel_time.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(u64)]
+    L.bl_reader_open.argtypes = [C.c_char_p, C.POINTER(vp)]
+    L.bl_reader_close.argtypes = [vp]
+    L.bl_reader_next_record.argtypes = [vp, C.POINTER(C.c_char_p), C.POINTER(vp), C.POINTER(u64)]
+    L.bl_reader_next_batch.argtypes = [vp, vp, u64, C.POINTER(vp), C.POINTER(u64), C.POINTER(u64)]
+    L.bl_reader_last_batch.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(u64)]
+    L.bl_reader_last_name.restype = C.c_char_p
+    L.bl_reader_last_name.argtypes = [vp, u64]
     L.bl_device_alloc.argtypes = [vp, u64, C.POINTER(vp)]
     L.bl_device_free.argtypes = [vp, vp]
     L.bl_copy_to_host.argtypes = [vp, vp, vp, u64]

@@ -25,6 +25,13 @@ int fail(int code, const std::string& msg)
     return code;
 }
 
+}  // namespace
+
+// used by the host-only translation units of the library (bl_ingest.cpp)
+int bl_set_error(int code, const char* msg) { return fail(code, msg ? msg : ""); }
+
+namespace {
+
 #define BL_HIP(call)                                                                                       \
     do {                                                                                                   \
         hipError_t e_ = (call);                                                                            \

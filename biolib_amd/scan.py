@@ -267,3 +267,47 @@ class Batch:
             return out
 
         return self._with_capacity(guess, run)
+
+
+class Reader:
+    """FASTA / FASTQ (plain or gzip) reader of the library (bl_reader_*): host records or device batches."""
+
+    def __init__(self, path):
+        self._lib = capi.lib()
+        h = C.c_void_p()
+        check(self._lib.bl_reader_open(str(path).encode(), C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.bl_reader_close(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def records(self):
+        """yield (name, sequence bytes) — host only, no GPU needed"""
+        name, seq, n = C.c_char_p(), C.c_void_p(), C.c_uint64()
+        while True:
+            rc = self._lib.bl_reader_next_record(self._h, C.byref(name), C.byref(seq), C.byref(n))
+            if rc == 1:
+                return
+            check(rc)
+            yield name.value.decode("latin1"), C.string_at(seq.value, n.value) if n.value else b""
+
+    def batches(self, ctx, max_bases=0):
+        """yield (Batch, names, offsets) of whole records holding at most max_bases bases each"""
+        while True:
+            b, ns, nb = C.c_void_p(), C.c_uint64(), C.c_uint64()
+            check(self._lib.bl_reader_next_batch(ctx._h, self._h, int(max_bases), C.byref(b), C.byref(ns), C.byref(nb)))
+            if not b.value:
+                return
+            offs_p, n2 = C.c_void_p(), C.c_uint64()
+            check(self._lib.bl_reader_last_batch(self._h, None, C.byref(offs_p), C.byref(n2)))
+            offs = np.ctypeslib.as_array(C.cast(offs_p, C.POINTER(C.c_uint64)), shape=(n2.value + 1,)).copy()
+            names = [self._lib.bl_reader_last_name(self._h, i).decode("latin1") for i in range(n2.value)]
+            yield Batch(ctx, b), names, offs

@@ -155,6 +155,23 @@ int bl_ctx_last_scan_ms(bl_ctx* ctx, float* ms);
 int bl_ctx_kernel_timing(bl_ctx* ctx, int enable);
 int bl_ctx_kernel_time(bl_ctx* ctx, double* total_ms, uint64_t* launches);
 
+/* ---- ingest: FASTA / FASTQ, plain or gzip -> batches -----------------------------
+ * Record semantics are those of the reader biolib's own tools use (reference tests/kseq.h:185-234): a record
+ * starts at '>' or '@'; the name ends at the first whitespace; sequence lines are concatenated, empty lines and a
+ * line-final '\r' dropped; FASTQ quality must match the sequence length.  Bases are not altered: the scans treat
+ * everything but ACGTUacgtu as a break, exactly as the reference table does (constants.hpp:12-21). */
+typedef struct bl_reader bl_reader;
+int bl_reader_open(const char* path, bl_reader** out);
+int bl_reader_close(bl_reader* reader);
+/* Host only: next record.  Returns BL_OK, 1 at end of file, or an error.  Pointers stay valid until the next call. */
+int bl_reader_next_record(bl_reader* reader, const char** name, const char** seq, uint64_t* seq_len);
+/* Next batch of whole records holding at most max_bases bases (0 = the rest of the file; always at least one
+ * record), uploaded to the device.  At end of file *out is NULL and *n_seqs is 0. */
+int bl_reader_next_batch(bl_ctx* ctx, bl_reader* reader, uint64_t max_bases, bl_batch** out, uint64_t* n_seqs, uint64_t* n_bases);
+/* Host copy of the batch produced last: concatenated bases, offsets[n_seqs+1], names. */
+int bl_reader_last_batch(bl_reader* reader, const char** bases, const uint64_t** offsets, uint64_t* n_seqs);
+const char* bl_reader_last_name(bl_reader* reader, uint64_t i);
+
 /* ---- device memory helpers (for callers without their own allocator) ----------------------------- */
 int bl_device_alloc(bl_ctx* ctx, uint64_t bytes, void** d_ptr);
 int bl_device_free(bl_ctx* ctx, void* d_ptr);
