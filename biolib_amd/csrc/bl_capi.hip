@@ -590,7 +590,8 @@ static int scan_windows(int mode, bl_ctx* c, const bl_batch* b, uint64_t first, 
     if (rc != BL_OK) return rc;
     const size_t n_lists = mode == bl::MODE_SUPERKMER ? 3 : 1;
     const size_t slot_entries = nt * (size_t)p.stride;
-    rc = grow(c, reinterpret_cast<void**>(&c->cur->slot_buf), &c->cur->slot_buf_bytes, n_lists * slot_entries * sizeof(uint16_t));
+    const size_t list_bytes = n_lists * slot_entries * sizeof(uint16_t);  // multiple of 32 bytes (stride % 16 == 0)
+    rc = grow(c, reinterpret_cast<void**>(&c->cur->slot_buf), &c->cur->slot_buf_bytes, list_bytes + nt * bl::NCHUNK * sizeof(uint32_t));
     if (rc != BL_OK) return rc;
     unsigned long long* tb = reinterpret_cast<unsigned long long*>(c->cur->tile_buf);
     p.tile_counts = tb;
@@ -600,6 +601,7 @@ static int scan_windows(int mode, bl_ctx* c, const bl_batch* b, uint64_t first, 
     p.slots_a = c->cur->slot_buf;
     p.slots_j = mode == bl::MODE_SUPERKMER ? c->cur->slot_buf + slot_entries : nullptr;
     p.slots_e = mode == bl::MODE_SUPERKMER ? c->cur->slot_buf + 2 * slot_entries : nullptr;
+    p.slots_c = reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(c->cur->slot_buf) + list_bytes);
     p.shards = c->shards();
     // count -> tile prefix scan -> emit, all tiles in one group (the prefix scan supports several
     // groups with a running carry; one group is what is used)

@@ -67,6 +67,7 @@ struct ScanParams {
     uint16_t* slots_a;                // [n_tiles][stride] list_a of every tile (first `starts` entries valid)
     uint16_t* slots_j;                // super-k-mer: list_j
     uint16_t* slots_e;                // super-k-mer: list_e (first `ends` entries valid)
+    uint32_t* slots_c;                // [n_tiles][NCHUNK] the tile's 2-bit codes (pass 2 rebuilds unit values from them)
     unsigned long long* shards;       // [NSHARD][8] digest accumulators
 };
 

@@ -60,7 +60,7 @@ BL_DEV void stage_chunk(const ScanParams& p, uint32_t* codes, uint32_t* flags, i
     const int64_t g = q0 + 16 * (int64_t)c;
     uint32_t d[4] = {0, 0, 0, 0};
     if (g >= 0 && g + 16 <= p.n_bases) {
-        const Vec16 v = *reinterpret_cast<const Vec16*>(p.bases + g);  // one global_load_dwordx4
+        const Vec16 v = *reinterpret_cast<const Vec16*>(p.bases + g);  // one global_load_dwordx4 (a non-temporal load measured no faster)
         d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
     } else if (g + 16 > 0 && g < p.n_bases) {  // ragged edge: byte-wise, zeros (= breaks) outside
         for (int b = 0; b < 16; ++b) {
@@ -452,20 +452,31 @@ BL_DEV Record emit_prepare(const ScanParams& p, const TileShared<MODE, W>& sh, i
     return rec;
 }
 
-// 5b: coalesced stores (thread r writes record r)
+// 5b: coalesced stores (thread r writes record r).  Records are written once and not read again by
+// the scan: non-temporal stores keep them from displacing the tile data in L2.
+template <typename T>
+BL_DEV void stream_store(T* dst, T v)
+{
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(BL_CPU_EMU)
+    __builtin_nontemporal_store(v, dst);
+#else
+    *dst = v;
+#endif
+}
+
 template <int MODE>
 BL_DEV void emit_store(const ScanParams& p, const Record& rec, uint64_t g)
 {
     if (g >= p.capacity) return;
     if (MODE == MODE_SYNCMER) {
-        if (p.out_pos) p.out_pos[g] = rec.pos;
+        if (p.out_pos) stream_store(&p.out_pos[g], rec.pos);
         return;
     }
-    if (p.out_value) p.out_value[g] = rec.v;
-    if (p.out_hash) p.out_hash[g] = rec.h;
-    if (p.out_pos) p.out_pos[g] = rec.pos;
+    if (p.out_value) stream_store(&p.out_value[g], rec.v);
+    if (p.out_hash) stream_store(&p.out_hash[g], rec.h);
+    if (p.out_pos) stream_store(&p.out_pos[g], rec.pos);
     if (MODE == MODE_SUPERKMER) {
-        if (p.out_first) p.out_first[g] = rec.first;
+        if (p.out_first) stream_store(&p.out_first[g], rec.first);
         if (p.out_mmpos) p.out_mmpos[g] = (uint8_t)rec.mmpos;
     }
 }
