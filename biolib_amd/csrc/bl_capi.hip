@@ -29,6 +29,9 @@ int fail(int code, const std::string& msg)
 
 // used by the host-only translation units of the library (bl_ingest.cpp)
 int bl_set_error(int code, const char* msg) { return fail(code, msg ? msg : ""); }
+struct bl_ctx;
+hipStream_t bl_ctx_stream(bl_ctx* ctx);
+int bl_ctx_device(bl_ctx* ctx);
 
 namespace {
 
@@ -291,6 +294,9 @@ int make_start_bits(bl_ctx* c, bl_batch* b, const uint64_t* offsets, uint64_t n_
 }
 
 }  // namespace
+
+hipStream_t bl_ctx_stream(bl_ctx* c) { return c->user_stream ? c->user_stream : c->lanes[0].own; }
+int bl_ctx_device(bl_ctx* c) { return c->device; }
 
 extern "C" {
 
@@ -629,6 +635,21 @@ int bl_scan_minimizers(bl_ctx* c, const bl_batch* b, uint64_t first, uint64_t n,
     p.out_hash = d_hashes;
     const bool wants = d_values || d_positions || d_hashes;
     int rc = scan_windows(bl::MODE_MINIMIZER, c, b, first, n, unit, w, seed, flags, p, wants ? capacity : 0, result);
+    if (rc != BL_OK || p.n_tiles == 0) return rc;
+    return end_scan(c, 1u << 0, result, wants, capacity, flags);
+}
+
+int bl_scan_hash_sample(bl_ctx* c, const bl_batch* b, uint64_t first, uint64_t n, uint32_t k, uint64_t seed, uint64_t threshold, uint32_t flags,
+                        uint64_t* d_values, uint64_t* d_positions, uint64_t* d_hashes, uint64_t capacity, bl_result* result)
+{
+    bl::ScanParams p{};
+    p.out_value = d_values;
+    p.out_pos = d_positions;
+    p.out_hash = d_hashes;
+    p.use_threshold = 1;
+    p.hash_below = threshold;
+    const bool wants = d_values || d_positions || d_hashes;
+    int rc = scan_windows(bl::MODE_MINIMIZER, c, b, first, n, k, 1, seed, flags, p, wants ? capacity : 0, result);
     if (rc != BL_OK || p.n_tiles == 0) return rc;
     return end_scan(c, 1u << 0, result, wants, capacity, flags);
 }

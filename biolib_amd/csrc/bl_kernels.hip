@@ -395,6 +395,7 @@ static hipError_t launch_count_mode(const ScanParams& p, GroupRange g, hipStream
         return hipGetLastError();
     }
     switch (p.w) {
+        case 1: hipLaunchKernelGGL((scan_count_kernel<MODE, 1, 0, -1>), grid, block, 0, stream, p, g); break;
         case 11: hipLaunchKernelGGL((scan_count_kernel<MODE, 11, 0, -1>), grid, block, 0, stream, p, g); break;
         case 17: hipLaunchKernelGGL((scan_count_kernel<MODE, 17, 0, -1>), grid, block, 0, stream, p, g); break;
         case 21: hipLaunchKernelGGL((scan_count_kernel<MODE, 21, 0, -1>), grid, block, 0, stream, p, g); break;

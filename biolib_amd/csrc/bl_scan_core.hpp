@@ -48,7 +48,9 @@ struct ScanParams {
     uint32_t seed;
     int32_t canonical;
     int32_t soff, eoff;          // syncmer offsets
-    int32_t drop_last;           // syncmer / k-mer scans: skip the k-mer that ends a sequence (quirk Q1)
+    int32_t drop_last;           // syncmer / k-mer scans (and w = 1 unit lists): skip the k-mer that ends a sequence (quirk Q1)
+    int32_t use_threshold;       // w = 1 only: keep units with hash < hash_below (hash_sampler.hpp:136-141)
+    uint64_t hash_below;
     // outputs (device pointers, nullable)
     uint64_t* out_value;
     uint64_t* out_pos;

@@ -287,12 +287,19 @@ BL_DEV uint32_t phase_window(const ScanParams& p, const TileShared<MODE, W>& sh,
     const int wv = tid >> 6, lane = tid & 63;
     const int w = W ? W : p.w;
     uint8_t a[S + 1];
+    uint32_t below = 0x1ffffu;  // w = 1 with a hash threshold (hash_sampler): bit s = hash of unit s is below it
     if (W) {
         uint64_t e[S + (W ? W : 1)];
         BL_UNROLL
         for (int s = 0; s < S; ++s) e[s] = st.h[s];
         gather_halo<(W ? W : 1), false>(all, tid, st, e);
         window_argmin<S + 1, (W ? W : 1), true>(e, a);
+        if (W == 1 && p.use_threshold) {
+            below = 0;
+            BL_UNROLL
+            for (int s = 0; s <= S; ++s)
+                if (e[s] < p.hash_below) below |= 1u << s;
+        }
     } else {
         window_argmin_lds<MODE, W, true>(sh, tid, w, S + 1, a);
     }
@@ -301,6 +308,15 @@ BL_DEV uint32_t phase_window(const ScanParams& p, const TileShared<MODE, W>& sh,
     uint32_t valid = window_valid_mask(good, start, p.unit + w - 1);
     // windows outside the requested range: never reported; in super-k-mer mode they also cut groups
     const int64_t j0 = wave_origin(p, q0, wv) + 16 * (int64_t)lane;  // global position of the lane's window 0
+    if (W == 1) {  // a plain list of units (k-mers): optional hash threshold and the reference idiom's dropped last k-mer
+        valid &= below;
+        if (p.drop_last) {
+            uint32_t last = (uint32_t)b128_shr(start, p.unit).lo & 0x1ffffu;  // a sequence starts right after unit s
+            const int64_t s_end = p.n_bases - p.unit - j0;                    // ... or the batch ends there
+            if (s_end >= 0 && s_end <= S) last |= 1u << s_end;
+            valid &= ~last;
+        }
+    }
     const uint32_t inrange = range_mask(p.win_first - j0, p.win_end - j0);
     if (MODE == MODE_SUPERKMER) valid &= inrange;
     uint32_t differ = 0;  // bit s: argmin of window s+1 is a different occurrence than window s

@@ -100,6 +100,20 @@ class Context:
         b._keep = t
         return b
 
+    # ---- set operations on device k-mer lists (int64 CUDA tensors holding uint64 keys)
+    def sort_unique(self, keys, n=None):
+        """in-place sort + unique of keys[:n]; returns the number of distinct keys now at the front"""
+        n = keys.numel() if n is None else int(n)
+        out = C.c_uint64()
+        check(self._lib.bl_sort_unique_u64(self._h, C.c_void_p(keys.data_ptr()), n, C.byref(out)))
+        return int(out.value)
+
+    def jaccard(self, a, na, b, nb):
+        """(|A n B|, |A u B|) of two sorted duplicate-free key arrays"""
+        i, u = C.c_uint64(), C.c_uint64()
+        check(self._lib.bl_jaccard_sorted_u64(self._h, C.c_void_p(a.data_ptr()), int(na), C.c_void_p(b.data_ptr()), int(nb), C.byref(i), C.byref(u)))
+        return int(i.value), int(u.value)
+
     # ---- device arrays (torch plumbing)
     def empty_u64(self, n):
         import torch
@@ -168,6 +182,12 @@ class Batch:
                                            capacity, C.byref(result)))
         return result
 
+    def hash_sample_raw(self, k, seed, threshold, flags, first=0, n=0, values=None, positions=None, hashes=None, capacity=0, result=None):
+        result = result if result is not None else Result()
+        check(self._lib.bl_scan_hash_sample(self.ctx._h, self._h, first, n, k, seed, threshold, flags, _ptr(values), _ptr(positions), _ptr(hashes),
+                                            capacity, C.byref(result)))
+        return result
+
     def super_kmers_raw(self, k, m, seed, flags, first=0, n=0, minimizers=None, first_pos=None, mm_pos=None, sizes=None, hashes=None,
                         capacity=0, result=None):
         result = result if result is not None else Result()
@@ -226,6 +246,21 @@ class Batch:
             return out
 
         return self._with_capacity(guess, run)
+
+    def hash_sample(self, k, seed=0, threshold=2**64 - 1, canonical=False, drop_last=False, first=0, n=0, device=False):
+        """k-mers with hash64(value, seed) < threshold (hash_sampler over kmer_view).  device=True keeps the value tensor on the GPU."""
+        span = self._span(first, n)
+        cap = span + 64
+        c = self.ctx
+        v, p, h = c.empty_u64(cap), c.empty_u64(cap), c.empty_u64(cap)
+        r = self.hash_sample_raw(k, seed, threshold, _flags(canonical, drop_last, True), first, n, v, p, h, cap)
+        cnt = int(r.count)
+        out = r.as_dict()
+        if device:
+            out.update(values_device=v, n=cnt)
+        else:
+            out.update(values=_host_u64(v, cnt), positions=_host_u64(p, cnt), hashes=_host_u64(h, cnt))
+        return out
 
     def super_kmers(self, k, m, seed=0, canonical=False, first=0, n=0, capacity=None):
         span = self._span(first, n)

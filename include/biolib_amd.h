@@ -128,6 +128,14 @@ int bl_scan_minimizers(bl_ctx* ctx, const bl_batch* batch, uint64_t first, uint6
                        uint32_t flags, uint64_t* d_values, uint64_t* d_positions, uint64_t* d_hashes, uint64_t capacity,
                        bl_result* result);
 
+/* hash_sampler over kmer_view (reference hash_sampler.hpp:73-78,136-141): the k-mers whose
+ * hash64(value, seed) is BELOW `threshold` (the reference computes threshold = rate * 2^64-1 in double), position-ordered,
+ * same arrays as bl_scan_minimizers.  threshold = UINT64_MAX with BL_FLAG_DROP_LAST gives exactly the k-mers the
+ * reference idiom visits.  (bl_scan_minimizers with w = 1 is the same list without a threshold.) */
+int bl_scan_hash_sample(bl_ctx* ctx, const bl_batch* batch, uint64_t first, uint64_t n, uint32_t k, uint64_t seed, uint64_t threshold,
+                        uint32_t flags, uint64_t* d_values, uint64_t* d_positions, uint64_t* d_hashes, uint64_t capacity,
+                        bl_result* result);
+
 /* super-k-mers (C4): maximal groups of consecutive k-mers sharing one minimizer occurrence
  * (m-mer, w = k - m + 1):
  *   d_minimizers[r] m-mer value, d_first_pos[r] global position of the group's first k-mer,
@@ -171,6 +179,14 @@ int bl_reader_next_batch(bl_ctx* ctx, bl_reader* reader, uint64_t max_bases, bl_
 /* Host copy of the batch produced last: concatenated bases, offsets[n_seqs+1], names. */
 int bl_reader_last_batch(bl_reader* reader, const char** bases, const uint64_t** offsets, uint64_t* n_seqs);
 const char* bl_reader_last_name(bl_reader* reader, uint64_t i);
+
+/* ---- set operations on k-mer lists (the consumer in reference tests/test_jaccard.cpp:55-130) ---
+ * bl_sort_unique_u64: sorts d_keys[0..n) in place and removes duplicates (ordered_unique_sampler.hpp:115-130 over a
+ * sorted vector); *n_unique = number of distinct keys now at the front.  Synchronous.
+ * bl_jaccard_sorted_u64: |A n B| and |A u B| of two sorted duplicate-free device arrays (jaccard.hpp:8-37). */
+int bl_sort_unique_u64(bl_ctx* ctx, uint64_t* d_keys, uint64_t n, uint64_t* n_unique);
+int bl_jaccard_sorted_u64(bl_ctx* ctx, const uint64_t* d_a, uint64_t na, const uint64_t* d_b, uint64_t nb, uint64_t* intersection,
+                          uint64_t* union_size);
 
 /* ---- device memory helpers (for callers without their own allocator) ----------------------------- */
 int bl_device_alloc(bl_ctx* ctx, uint64_t bytes, void** d_ptr);

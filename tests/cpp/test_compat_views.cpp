@@ -14,6 +14,7 @@
 #include "minimizer_view.hpp"
 #include "super_kmer_view.hpp"
 #include "syncmer_sampler.hpp"
+#include "hash_sampler.hpp"
 
 extern "C" {
 #include "../../oracle/bl_oracle.h"
@@ -155,6 +156,21 @@ int main()
                 if (kc.value) CHECK(ex(kc) == blo_minimizer_position(*kc.value, 31, 11), "extractor at %zu", kc.position);
                 else CHECK(ex(kc) == 32, "null item extractor");
             }
+        }
+        for (double rate : {1.0, 0.3, 0.0}) {  // hash_sampler over kmer_view, hash64: GPU path
+            using view_t = wrapper::kmer_view<kmer_t, char_iterator>;
+            auto view = wrapper::kmer_view_from_cstr<kmer_t>(s.c_str(), s.size(), 21, true);
+            sampler::hash_sampler<view_t::const_iterator, hash::hash64> smp(view.cbegin(), view.cend(), hash::hash64(), 42, rate);
+            std::vector<uint64_t> exp;
+            const uint64_t thr = rate >= 1.0 ? ~0ULL : (uint64_t)(rate * 18446744073709551615.0);
+            for (auto itr = view.cbegin(); itr != view.cend(); ++itr) {  // the reference's own filter, item by item
+                auto kc = *itr;
+                if (kc.value && hash::hash64::hash(*kc.value, 42) < thr) exp.push_back(*kc.value);
+            }
+            size_t i = 0;
+            for (auto it = smp.cbegin(); it != smp.cend(); ++it, ++i)
+                if (i < exp.size()) CHECK(*it == exp[i], "hash_sampler rate %.1f item %zu", rate, i);
+            CHECK(i == exp.size(), "hash_sampler rate %.1f: %zu vs %zu", rate, i, exp.size());
         }
         {   // generic path of the sampler: any iterator + any extractor (here: even numbers)
             struct even_extractor { using value_type = int; std::size_t operator()(int v) const {return v % 2;} };

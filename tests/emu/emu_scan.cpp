@@ -116,6 +116,7 @@ template <int MODE>
 void run_mode(const ScanParams& p, unsigned long long* result)
 {
     switch (p.w) {
+        case 1: run_tiles<MODE, 1>(p, result); break;
         case 11: run_tiles<MODE, 11>(p, result); break;
         case 17: run_tiles<MODE, 17>(p, result); break;
         case 21: run_tiles<MODE, 21>(p, result); break;
@@ -177,6 +178,21 @@ void emu_minimizers(const EmuBatch* b, uint64_t first, uint64_t n, unsigned unit
 {
     ScanParams p{};
     fill_common(p, b->bases, b->n_bases, b->single ? nullptr : b->bits.data(), MODE_MINIMIZER, first, n, unit, w, seed, flags);
+    p.out_value = out_value;
+    p.out_pos = out_pos;
+    p.out_hash = out_hash;
+    p.capacity = capacity;
+    std::memset(result, 0, 8 * sizeof(unsigned long long));
+    run_mode<MODE_MINIMIZER>(p, result);
+}
+
+void emu_hash_sample(const EmuBatch* b, uint64_t first, uint64_t n, unsigned k, uint64_t seed, uint64_t threshold, unsigned flags,
+                     uint64_t* out_value, uint64_t* out_pos, uint64_t* out_hash, uint64_t capacity, unsigned long long* result)
+{
+    ScanParams p{};
+    fill_common(p, b->bases, b->n_bases, b->single ? nullptr : b->bits.data(), MODE_MINIMIZER, first, n, k, 1, seed, flags);
+    p.use_threshold = 1;
+    p.hash_below = threshold;
     p.out_value = out_value;
     p.out_pos = out_pos;
     p.out_hash = out_hash;

@@ -25,6 +25,8 @@ void emu_syncmers(const EmuBatch* b, uint64_t first, uint64_t n, unsigned k, uns
                   unsigned flags, uint64_t* out_pos, uint64_t capacity, unsigned long long* result);
 void emu_kmers(const EmuBatch* b, uint64_t first, uint64_t n, unsigned k, uint64_t seed, unsigned flags, uint64_t* out_value,
                uint64_t* out_hash, uint8_t* out_valid, unsigned long long* result);
+void emu_hash_sample(const EmuBatch* b, uint64_t first, uint64_t n, unsigned k, uint64_t seed, uint64_t threshold, unsigned flags,
+                     uint64_t* out_value, uint64_t* out_pos, uint64_t* out_hash, uint64_t capacity, unsigned long long* result);
 uint64_t emu_hash64(uint64_t v, uint64_t seed);
 }
 
@@ -150,6 +152,25 @@ static void check_case(const Case& c, std::mt19937_64& rng)
             emu_kmers(b, 0, 0, k, 77, (canon ? 1u : 0u) | 2u, nullptr, nullptr, nullptr, res);
             CHECK(res[0] == dg[0] && res[1] == dg[1] && res[2] == dg[2] && res[3] == dg[3], "%s kmers k%u c%d drop_last digest %llu vs %llu",
                   c.name.c_str(), k, canon, res[0], (unsigned long long)dg[0]);
+        }
+    }
+    // hash_sampler over kmer_view (hash_sampler.hpp:136-141): units with hash < threshold, optionally minus the
+    // k-mer the `it != cend()` idiom never reaches
+    for (unsigned k : {5u, 21u, 31u}) {
+        for (int canon = 0; canon < 2; ++canon) {
+            blo_units(s, c.offsets.data(), n_seqs, k, canon, uv.data(), uok.data());
+            for (uint64_t thr : {~0ULL, 1ULL << 62, 0ULL}) {
+                for (int drop = 0; drop < 2; ++drop) {
+                    std::vector<uint64_t> xp, xv;
+                    for (size_t q = 0; q < n_seqs; ++q)
+                        for (uint64_t pp = c.offsets[q]; pp + k <= c.offsets[q + 1]; ++pp)
+                            if (uok[pp] && blo_hash64_u64(uv[pp], 9) < thr && !(drop && pp + k == c.offsets[q + 1])) { xp.push_back(pp); xv.push_back(uv[pp]); }
+                    emu_hash_sample(b, 0, 0, k, 9, thr, (canon ? 1u : 0u) | (drop ? 2u : 0u), ev.data(), ep.data(), eh.data(), cap, res);
+                    CHECK(res[0] == xp.size(), "%s hash_sample k%u c%d thr %llx drop %d: %llu vs %zu", c.name.c_str(), k, canon, (unsigned long long)thr, drop, res[0], xp.size());
+                    if (res[0] == xp.size())
+                        for (size_t i = 0; i < xp.size(); ++i) CHECK(ep[i] == xp[i] && ev[i] == xv[i], "%s hash_sample record %zu", c.name.c_str(), i);
+                }
+            }
         }
     }
     emu_batch_free(b);

@@ -1,0 +1,103 @@
+"""GPU tests for SURVEY.md §8f rank 2: hash_sampler over kmer_view, sort + unique, Jaccard of two k-mer sets —
+the pipeline of the reference's tests/test_jaccard.cpp — against numpy on the oracle's k-mers."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import biolib_amd
+
+    c = biolib_amd.Context(0)
+    yield c
+    c.close()
+
+
+def _idiom_kmers(seq, offs, k, canonical):
+    """what the reference loop `for (it = cbegin(); it != cend(); ++it) if ((*it).value) push_back` collects"""
+    val, ok = O.units(seq, offs, k, canonical)
+    keep = ok.astype(bool)
+    ends = (np.asarray(offs[1:], dtype=np.int64) - k)  # the k-mer that ends each sequence is never visited (Q1)
+    ends = ends[(ends >= 0)]
+    keep[ends[ends < len(keep)]] = False
+    return val, keep
+
+
+@pytest.mark.parametrize("flavour", ["plain", "breaks", "ragged"])
+def test_hash_sample_vs_oracle(ctx, flavour):
+    rng = np.random.default_rng(11)
+    n = 50_000
+    seq = O.synth(77, n)
+    if flavour == "breaks":
+        seq[rng.integers(0, n, 200)] = ord("N")
+    offs = np.array([0, n], np.uint64) if flavour != "ragged" else np.unique(np.concatenate([[0, n], rng.integers(0, n, 60)])).astype(np.uint64)
+    b = ctx.upload(seq, offs)
+    L = O.oracle()
+    for k, canon in ((21, True), (31, False), (5, True)):
+        val, ok = O.units(seq, offs, k, canon)
+        hsh = np.array([L.blo_hash64_u64(int(v), 42) for v in val], np.uint64)
+        for rate in (1.0, 0.25, 0.0):
+            thr = 2**64 - 1 if rate >= 1.0 else int(rate * float(2**64 - 1))
+            exp = np.nonzero(ok.astype(bool) & (hsh < np.uint64(thr)))[0]
+            got = b.hash_sample(k, seed=42, threshold=thr, canonical=canon)
+            assert got["count"] == len(exp), (flavour, k, rate)
+            assert np.array_equal(got["positions"], exp.astype(np.uint64)) and np.array_equal(got["values"], val[exp]) and np.array_equal(got["hashes"], hsh[exp])
+        vals, keep = _idiom_kmers(seq, offs, k, canon)
+        got = b.hash_sample(k, seed=42, canonical=canon, drop_last=True)
+        assert np.array_equal(got["values"], vals[keep])
+        same = b.minimizers(k, 1, seed=42, canonical=canon)  # w = 1 is the plain unit list
+        assert np.array_equal(same["values"], vals[ok.astype(bool)])
+
+
+def test_sort_unique_and_jaccard(ctx):
+    import torch
+
+    rng = np.random.default_rng(5)
+    a = rng.integers(0, 5000, 40_000).astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15)
+    bb = rng.integers(2500, 9000, 70_000).astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15)
+    ta = torch.from_numpy(a.view(np.int64)).cuda()
+    tb = torch.from_numpy(bb.view(np.int64)).cuda()
+    na, nb = ctx.sort_unique(ta), ctx.sort_unique(tb)
+    ua, ub = np.unique(a), np.unique(bb)
+    assert na == len(ua) and nb == len(ub)
+    assert np.array_equal(ta[:na].cpu().numpy().view(np.uint64), ua) and np.array_equal(tb[:nb].cpu().numpy().view(np.uint64), ub)
+    inter, uni = ctx.jaccard(ta, na, tb, nb)
+    assert inter == len(np.intersect1d(ua, ub)) and uni == len(np.union1d(ua, ub))
+    assert ctx.jaccard(tb, nb, ta, na) == (inter, uni)
+    assert ctx.jaccard(ta, na, ta, na) == (na, na) and ctx.jaccard(ta, 0, tb, nb) == (0, nb)
+
+
+def test_jaccard_of_two_fasta_files_like_the_reference_tool(ctx):
+    """tests/test_jaccard.cpp:55-130 of the reference: canonical k-mers of two files (idiom loop), sorted, unique, merged."""
+    import biolib_amd
+
+    exp = json.load(open(os.path.join(HERE, "golden", "ingest", "expected.json")))
+    k = 15
+    sets = []
+    for fn in ("many.fa.gz", "mixed.fa"):
+        parts = []
+        for batch, names, offs in biolib_amd.Reader(os.path.join(HERE, "golden", "ingest", fn)).batches(ctx, 20_000):
+            r = batch.hash_sample(k, canonical=True, drop_last=True, device=True)
+            parts.append(r["values_device"][: r["n"]])
+        import torch
+        keys = torch.cat(parts)
+        n = ctx.sort_unique(keys)
+        sets.append((keys, n))
+        # oracle: the same set from the sequences the reference reader returned
+        seqs = exp[fn]["seqs"]
+        seq = np.frombuffer("".join(seqs).encode("latin1"), np.uint8)
+        offs = np.concatenate([[0], np.cumsum([len(s) for s in seqs])]).astype(np.uint64)
+        vals, keep = _idiom_kmers(seq, offs, k, True)
+        assert np.array_equal(keys[:n].cpu().numpy().view(np.uint64), np.unique(vals[keep]))
+    inter, uni = ctx.jaccard(sets[0][0], sets[0][1], sets[1][0], sets[1][1])
+    a = sets[0][0][: sets[0][1]].cpu().numpy().view(np.uint64)
+    b = sets[1][0][: sets[1][1]].cpu().numpy().view(np.uint64)
+    assert (inter, uni) == (len(np.intersect1d(a, b)), len(np.union1d(a, b)))
