@@ -190,3 +190,47 @@ int bl_reader_last_batch(bl_reader* r, const char** bases, const uint64_t** offs
 const char* bl_reader_last_name(bl_reader* r, uint64_t i) { return (r && i < r->names.size()) ? r->names[i].c_str() : nullptr; }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------
+// Spill / wire formats of the step right AFTER the scan: what biolib's consumers read.
+//   run file   emem::external_memory_vector<uint64_t>::sort_and_flush (external_memory_vector.hpp:243-262):
+//              the sorted elements one after the other through io::basic_store = raw little-endian 8-byte
+//              values, no header; file name <dir>/tmp.run[_<name>]_<id>.bin (:253-262)
+//   vector     io::basic_store(std::vector<uint64_t>) (io.hpp:104-112): size_t element count, then the elements
+#include <cstdio>
+
+extern "C" {
+
+int bl_run_file_name(const char* dir, const char* name, uint64_t id, char* out, uint64_t out_len)
+{
+    if (!dir || !out) return bl_set_error(BL_ERR_INVALID, "NULL argument");
+    std::string fn = std::string(dir) + "/tmp.run";
+    if (name && *name) fn += std::string("_") + name;
+    fn += "_" + std::to_string(id) + ".bin";
+    if (fn.size() + 1 > out_len) return bl_set_error(BL_ERR_INVALID, "file name buffer too small");
+    std::memcpy(out, fn.c_str(), fn.size() + 1);
+    return BL_OK;
+}
+
+static int write_u64_file(bl_ctx* ctx, const uint64_t* d_keys, uint64_t n, const char* path, bool with_count)
+{
+    if (!ctx || !path || (n && !d_keys)) return bl_set_error(BL_ERR_INVALID, "NULL argument");
+    std::vector<uint64_t> host(n);
+    int rc = bl_copy_to_host(ctx, host.data(), d_keys, n * sizeof(uint64_t));
+    if (rc != BL_OK) return rc;
+    FILE* f = std::fopen(path, "wb");
+    if (!f) return bl_set_error(BL_ERR_INVALID, (std::string("cannot create ") + path).c_str());
+    bool ok = true;
+    if (with_count) {
+        const size_t cnt = (size_t)n;  // io.hpp stores std::size_t
+        ok = std::fwrite(&cnt, sizeof(cnt), 1, f) == 1;
+    }
+    if (ok && n) ok = std::fwrite(host.data(), sizeof(uint64_t), n, f) == n;
+    ok = (std::fclose(f) == 0) && ok;
+    return ok ? BL_OK : bl_set_error(BL_ERR_INVALID, (std::string("short write to ") + path).c_str());
+}
+
+int bl_write_run_u64(bl_ctx* ctx, const uint64_t* d_sorted_keys, uint64_t n, const char* path) { return write_u64_file(ctx, d_sorted_keys, n, path, false); }
+int bl_write_vector_u64(bl_ctx* ctx, const uint64_t* d_keys, uint64_t n, const char* path) { return write_u64_file(ctx, d_keys, n, path, true); }
+
+}  // extern "C"

@@ -188,6 +188,16 @@ int bl_sort_unique_u64(bl_ctx* ctx, uint64_t* d_keys, uint64_t n, uint64_t* n_un
 int bl_jaccard_sorted_u64(bl_ctx* ctx, const uint64_t* d_a, uint64_t na, const uint64_t* d_b, uint64_t nb, uint64_t* intersection,
                           uint64_t* union_size);
 
+/* ---- spill / wire formats read by biolib's consumers -------------------------------------
+ * bl_write_run_u64: a run file of emem::external_memory_vector<uint64_t> (external_memory_vector.hpp:243-262): the
+ *   SORTED keys as raw little-endian 8-byte values, no header.  bl_run_file_name builds the reference's file name
+ *   <dir>/tmp.run[_<name>]_<id>.bin (:253-262).
+ * bl_write_vector_u64: io::basic_store(std::vector<uint64_t>) (io.hpp:104-112): size_t count, then the elements.
+ * Both copy the device array to the host and write synchronously. */
+int bl_run_file_name(const char* dir, const char* name, uint64_t id, char* out, uint64_t out_len);
+int bl_write_run_u64(bl_ctx* ctx, const uint64_t* d_sorted_keys, uint64_t n, const char* path);
+int bl_write_vector_u64(bl_ctx* ctx, const uint64_t* d_keys, uint64_t n, const char* path);
+
 /* ---- device memory helpers (for callers without their own allocator) ----------------------------- */
 int bl_device_alloc(bl_ctx* ctx, uint64_t bytes, void** d_ptr);
 int bl_device_free(bl_ctx* ctx, void* d_ptr);
