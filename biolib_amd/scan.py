@@ -36,6 +36,7 @@ class Context:
         check(self._lib.bl_ctx_create(self.device, C.byref(h)))
         self._h = h
         self._batches = weakref.WeakSet()
+        self._pending = []  # Result structs of asynchronous scans: the library fills them at the next sync
         if torch_stream:
             # run on torch's current stream so torch.cuda.Event / torch allocations are ordered with the scans
             with torch.cuda.device(self.device):
@@ -57,6 +58,7 @@ class Context:
 
     def sync(self):
         check(self._lib.bl_ctx_sync(self._h))
+        self._pending.clear()
 
     def last_scan_ms(self):
         ms = C.c_float()
@@ -65,6 +67,10 @@ class Context:
 
     def kernel_timing(self, enable=True):
         check(self._lib.bl_ctx_kernel_timing(self._h, 1 if enable else 0))
+
+    def _trim_pending(self):
+        if len(self._pending) > 4096:
+            self.sync()
 
     def kernel_time(self):
         """(total ms, launches) of the scan kernels alone since kernel_timing(True)."""
@@ -173,17 +179,20 @@ class Batch:
     # ---- raw (asynchronous) entry points: device tensors in, Result filled after ctx.sync()
     def kmers_raw(self, k, seed, flags, first=0, n=0, values=None, hashes=None, valid=None, result=None):
         result = result if result is not None else Result()
+        self.ctx._pending.append(result)  # must outlive the call: filled asynchronously
         check(self._lib.bl_scan_kmers(self.ctx._h, self._h, first, n, k, seed, flags, _ptr(values), _ptr(hashes), _ptr(valid), C.byref(result)))
         return result
 
     def minimizers_raw(self, unit, w, seed, flags, first=0, n=0, values=None, positions=None, hashes=None, capacity=0, result=None):
         result = result if result is not None else Result()
+        self.ctx._pending.append(result)  # must outlive the call: filled asynchronously
         check(self._lib.bl_scan_minimizers(self.ctx._h, self._h, first, n, unit, w, seed, flags, _ptr(values), _ptr(positions), _ptr(hashes),
                                            capacity, C.byref(result)))
         return result
 
     def hash_sample_raw(self, k, seed, threshold, flags, first=0, n=0, values=None, positions=None, hashes=None, capacity=0, result=None):
         result = result if result is not None else Result()
+        self.ctx._pending.append(result)  # must outlive the call: filled asynchronously
         check(self._lib.bl_scan_hash_sample(self.ctx._h, self._h, first, n, k, seed, threshold, flags, _ptr(values), _ptr(positions), _ptr(hashes),
                                             capacity, C.byref(result)))
         return result
@@ -191,12 +200,14 @@ class Batch:
     def super_kmers_raw(self, k, m, seed, flags, first=0, n=0, minimizers=None, first_pos=None, mm_pos=None, sizes=None, hashes=None,
                         capacity=0, result=None):
         result = result if result is not None else Result()
+        self.ctx._pending.append(result)  # must outlive the call: filled asynchronously
         check(self._lib.bl_scan_super_kmers(self.ctx._h, self._h, first, n, k, m, seed, flags, _ptr(minimizers), _ptr(first_pos), _ptr(mm_pos),
                                             _ptr(sizes), _ptr(hashes), capacity, C.byref(result)))
         return result
 
     def syncmers_raw(self, k, s, soff, eoff, seed, flags, first=0, n=0, positions=None, capacity=0, result=None):
         result = result if result is not None else Result()
+        self.ctx._pending.append(result)  # must outlive the call: filled asynchronously
         check(self._lib.bl_scan_syncmers(self.ctx._h, self._h, first, n, k, s, soff, eoff, seed, flags, _ptr(positions), capacity, C.byref(result)))
         return result
 

@@ -60,7 +60,8 @@ enum {
 typedef struct bl_ctx bl_ctx;
 typedef struct bl_batch bl_batch;
 
-/* Filled asynchronously; read after bl_ctx_sync() (or immediately with BL_FLAG_SYNC). */
+/* Filled asynchronously; read after bl_ctx_sync() (or immediately with BL_FLAG_SYNC).  The struct passed to a scan
+ * must stay alive until then (the library writes it during the sync); pass NULL if the digest is not wanted. */
 typedef struct bl_result {
     uint64_t count;      /* records found (k-mers / minimizer occurrences / super-k-mers / syncmers) */
     uint64_t xor_value;  /* XOR of the 2-bit packed values of all records */
