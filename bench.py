@@ -143,7 +143,7 @@ def main():
         tp = os.path.join(ROOT, "profiles", "traffic.json")  # written from a separate rocprofv3 --pmc run, see DESIGN.md
         if os.path.exists(tp):
             try:
-                traffic = json.load(open(tp)).get("hbm_bytes_per_launch")
+                traffic = int(json.load(open(tp))["hbm_bytes_per_base"] * bases_per_launch)  # PMC bytes per base x this run's bases per launch
             except Exception:
                 traffic = None
         out = {
@@ -169,7 +169,7 @@ def main():
             "xor_hash": xor_hash,
             "roofline": {
                 "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5),
-                "traffic": traffic, "kernel": "bl::scan_kernel<MODE_MINIMIZER,11>", "avg_kernel_ms": round(avg_kernel_s * 1e3, 4),
+                "traffic": traffic, "kernel": "bl::scan_count_kernel<MODE_MINIMIZER,W=11,U=31,C=1> (pass 1 of 2)", "avg_kernel_ms": round(avg_kernel_s * 1e3, 4),
                 "launches_timed": launches, "algorithmic_bytes_per_launch": int(bases_per_launch),
                 "note": "integer-ALU bound before HBM: 6 x 64-bit multiplies per base (MurmurHash3_x64_128), see DESIGN.md",
             },
