@@ -3,7 +3,7 @@
 line): C2 canonical 31-mer + hash64 digest, C4 super-k-mers k=31 m=15 on 10-kbp reads, C5 syncmers k=31 s=11 on
 10-kbp reads.  Each result is checked against the CPU oracle on a sample."""
 import os, sys, time, json
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import biolib_amd as B

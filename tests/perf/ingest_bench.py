@@ -2,8 +2,9 @@
 """Throughput of the FASTA/FASTQ ingest (host parse -> device batch) and of the scan on the ingested batches.
 Writes a synthetic FASTQ of 150-bp reads (plain and gzip), then times  reader -> batches -> minimizer scan."""
 import gzip, os, sys, tempfile, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import biolib_amd as B
 import oracle_lib as O
