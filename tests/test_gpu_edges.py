@@ -1,0 +1,168 @@
+"""GPU edge-case and property tests: limits of the C ABI, alternative batch constructors, extremes of k / w,
+super-k-mer and syncmer range unions, multi-context use from threads, size-independent properties at 1 Gbp."""
+import threading
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import biolib_amd
+
+    c = biolib_amd.Context(0)
+    yield c
+    c.close()
+
+
+def test_batch_from_device_tensor_offsets_and_fixed_reads(ctx):
+    import torch
+
+    n = 300_007
+    seq = O.synth(21, n)
+    seq[[5, 77_777, 150_000, n - 1]] = ord("N")
+    t = torch.from_numpy(seq.copy()).cuda()
+    rng = np.random.default_rng(2)
+    offs = np.unique(np.concatenate([[0, n], rng.integers(0, n, 500)])).astype(np.uint64)
+    for batch, o in ((ctx.from_tensor(t, offsets=offs), offs), (ctx.from_tensor(t, read_len=151), O.fixed_offsets(n, 151)), (ctx.from_tensor(t), np.array([0, n], np.uint64))):
+        assert batch.n_bases == n and batch.n_seqs == len(o) - 1
+        v, p, h = O.minimizers(seq, o, 31, 11, 42, True, brute=False)
+        got = batch.minimizers(31, 11, seed=42, canonical=True)
+        assert np.array_equal(got["positions"], p) and np.array_equal(got["values"], v) and np.array_equal(got["hashes"], h)
+    with pytest.raises(Exception):
+        ctx.from_tensor(t[1:])  # not 16-byte aligned
+
+
+def test_extreme_parameters_vs_oracle(ctx):
+    n = 60_000
+    seq = O.synth(8, n)
+    seq[np.random.default_rng(8).integers(0, n, 40)] = ord("N")
+    offs = O.fixed_offsets(n, 777)
+    b = ctx.upload(seq, offs)
+    for (unit, w) in ((1, 1), (1, 64), (32, 1), (32, 64), (2, 33), (17, 48), (31, 16), (31, 17), (16, 32)):
+        for canon in (0, 1):
+            v, p, h = O.minimizers(seq, offs, unit, w, 7, canon, brute=False)
+            got = b.minimizers(unit, w, seed=7, canonical=bool(canon))
+            assert got["count"] == len(v), (unit, w, canon)
+            assert np.array_equal(got["positions"], p) and np.array_equal(got["values"], v) and np.array_equal(got["hashes"], h)
+    for (k, m) in ((32, 32), (64, 1), (95, 32), (33, 2), (48, 17)):
+        mn, fp, mp, sz, hs = O.super_kmers(seq, offs, k, m, 3, 1)
+        got = b.super_kmers(k, m, seed=3, canonical=True)
+        assert got["count"] == len(mn) == got["aux"], (k, m)
+        assert np.array_equal(got["first_pos"], fp) and np.array_equal(got["sizes"], sz) and np.array_equal(got["mm_pos"], mp) and np.array_equal(got["minimizers"], mn)
+    for (k, s, a, e) in ((32, 1, 0, 31), (32, 32, 0, 0), (2, 1, 0, 1), (31, 30, 0, 1), (20, 5, 7, 7)):
+        for canon in (0, 1):
+            cnt, pos = O.syncmers(seq, offs, k, s, a, e, canon)
+            got = b.syncmers(k, s, a, e, canonical=bool(canon))
+            assert got["count"] == cnt and np.array_equal(got["positions"], pos), (k, s, canon)
+
+
+def test_range_unions_for_super_kmers_and_syncmers(ctx):
+    """ranges aligned to read boundaries compose exactly for super-k-mers (a range cuts groups otherwise, by contract)"""
+    L, n_reads = 1000, 3000
+    n = L * n_reads
+    b = ctx.synth(17, n, L)
+    whole = b.super_kmers(31, 15, seed=42, canonical=True)
+    cuts = [0, 700 * L, 701 * L, 2000 * L, n]
+    parts = [b.super_kmers(31, 15, seed=42, canonical=True, first=a, n=e - a) for a, e in zip(cuts[:-1], cuts[1:])]
+    assert sum(p["count"] for p in parts) == whole["count"]
+    for key in ("first_pos", "minimizers", "sizes", "mm_pos", "hashes"):
+        assert np.array_equal(np.concatenate([p[key] for p in parts]), whole[key]), key
+    # unaligned cut: group boundaries are cut at the range boundary, k-mers are still covered exactly once
+    a = b.super_kmers(31, 15, seed=42, canonical=True, first=0, n=12_345)
+    c = b.super_kmers(31, 15, seed=42, canonical=True, first=12_345, n=n - 12_345)
+    assert int(a["sizes"].sum(dtype=np.uint64)) + int(c["sizes"].sum(dtype=np.uint64)) == int(whole["sizes"].sum(dtype=np.uint64))
+    sw = b.syncmers(31, 11, 0, 20, canonical=True, drop_last=True)
+    sp = [b.syncmers(31, 11, 0, 20, canonical=True, drop_last=True, first=x, n=y - x) for x, y in zip([0, 999, 50_001, 2_222_222], [999, 50_001, 2_222_222, n])]
+    assert np.array_equal(np.concatenate([p["positions"] for p in sp]), sw["positions"])
+
+
+def test_limits_and_errors(ctx):
+    import biolib_amd as B
+
+    b = ctx.synth(1, 10_000, 100)
+    with pytest.raises(B.BiolibError):
+        b.minimizers_raw(31, 11, 0, B.FLAG_SYNC, first=20_000)  # range starts beyond the batch
+    with pytest.raises(B.BiolibError):
+        b.super_kmers(31, 0)
+    with pytest.raises(B.BiolibError):
+        b.super_kmers(10, 11)
+    with pytest.raises(B.BiolibError):
+        b.kmers(0)
+    with pytest.raises(B.BiolibError):
+        b.kmers(33)
+    # capacity errors report the count for every compacting scan
+    r = B.Result()
+    small = ctx.empty_u64(8)
+    with pytest.raises(B.BiolibError) as e:
+        b.syncmers_raw(31, 11, 0, 20, 0, B.FLAG_CANONICAL | B.FLAG_SYNC, positions=small, capacity=8, result=r)
+    assert e.value.code == -4 and r.count == b.syncmers(31, 11, 0, 20, canonical=True, positions=False)["count"]
+    r = B.Result()
+    with pytest.raises(B.BiolibError) as e:
+        b.super_kmers_raw(31, 15, 0, B.FLAG_SYNC, minimizers=small, capacity=8, result=r)
+    assert e.value.code == -4 and r.count == b.super_kmers(31, 15)["count"]
+    # an empty range and an empty batch are fine
+    assert b.minimizers(31, 11, first=5_000, n=0)["count"] > 0  # n = 0 means "to the end"
+    empty = ctx.upload(b"")
+    assert empty.minimizers(31, 11)["count"] == 0 and empty.kmers(5)["count"] == 0 and empty.syncmers(31, 11, 0, 20)["count"] == 0
+    # more than 2^31 positions in one range is refused (split it)
+    big = ctx.synth(1, (1 << 31) + 4096)
+    with pytest.raises(B.BiolibError):
+        big.minimizers_raw(31, 11, 0, B.FLAG_SYNC)
+    r = big.minimizers_raw(31, 11, 0, B.FLAG_SYNC | B.FLAG_CANONICAL, first=(1 << 31) - 1000, n=5000)  # a range straddling 2^31 works
+    assert r.count > 0
+    big.close()
+
+
+def test_two_contexts_in_two_threads():
+    import biolib_amd as B
+
+    results = {}
+
+    def work(seed):
+        c = B.Context(0, torch_stream=False)
+        b = c.synth(seed, 3_000_000, 150)
+        results[seed] = b.minimizers(31, 11, seed=42, canonical=True)["xor_hash"]
+        c.close()
+
+    ts = [threading.Thread(target=work, args=(s,)) for s in (101, 102)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    for s in (101, 102):
+        seq = O.synth(s, 3_000_000)
+        assert results[s] == O.minimizer_digest(seq, O.fixed_offsets(3_000_000, 150), 31, 11, 42, True, threads=8)["xor_hash"]
+
+
+def test_one_gbp_properties(ctx):
+    """size-independent properties at 1 Gbp of 10-kbp reads (the oracle would need minutes): chunk composition,
+    every k-mer in exactly one super-k-mer, sorted outputs, syncmer count sub-additivity across ranges."""
+    L = 10_000
+    n = 1_000_000_000
+    b = ctx.synth(7, n, L)
+    import biolib_amd as B
+
+    half = (n // 2) // L * L
+    r1 = b.super_kmers_raw(31, 15, 42, B.FLAG_CANONICAL | B.FLAG_SYNC, first=0, n=half)
+    r2 = b.super_kmers_raw(31, 15, 42, B.FLAG_CANONICAL | B.FLAG_SYNC, first=half, n=n - half)
+    rw = b.super_kmers_raw(31, 15, 42, B.FLAG_CANONICAL | B.FLAG_SYNC)
+    assert r1.count + r2.count == rw.count and (r1.xor_hash ^ r2.xor_hash) == rw.xor_hash and r1.aux + r2.aux == rw.aux == rw.count
+    g = b.super_kmers(31, 15, seed=42, canonical=True, first=0, n=100 * L)
+    assert int(g["sizes"].sum(dtype=np.uint64)) == 100 * (L - 30)
+    m1 = b.minimizers_raw(31, 11, 42, B.FLAG_CANONICAL | B.FLAG_SYNC, first=0, n=half)
+    m2 = b.minimizers_raw(31, 11, 42, B.FLAG_CANONICAL | B.FLAG_SYNC, first=half, n=n - half)
+    mw = b.minimizers_raw(31, 11, 42, B.FLAG_CANONICAL | B.FLAG_SYNC)
+    assert m1.count + m2.count == mw.count and (m1.xor_pos ^ m2.xor_pos) == mw.xor_pos
+    # density of random minimizers is 2/(w+1) per window
+    windows = (n // L) * (L - 41 + 1)
+    assert abs(mw.count / windows - 2 / 12) < 0.002
+    s1 = b.syncmers_raw(31, 11, 0, 20, 0, B.FLAG_CANONICAL | B.FLAG_SYNC, first=0, n=half).count
+    s2 = b.syncmers_raw(31, 11, 0, 20, 0, B.FLAG_CANONICAL | B.FLAG_SYNC, first=half, n=n - half).count
+    assert s1 + s2 == b.syncmers_raw(31, 11, 0, 20, 0, B.FLAG_CANONICAL | B.FLAG_SYNC).count
+    k1 = b.kmers_raw(31, 0, B.FLAG_CANONICAL | B.FLAG_SYNC, first=0, n=half)
+    k2 = b.kmers_raw(31, 0, B.FLAG_CANONICAL | B.FLAG_SYNC, first=half, n=n - half)
+    kw = b.kmers_raw(31, 0, B.FLAG_CANONICAL | B.FLAG_SYNC)
+    assert k1.count + k2.count == kw.count == (n // L) * (L - 30) and (k1.xor_hash ^ k2.xor_hash) == kw.xor_hash
