@@ -19,7 +19,7 @@ SYMBOLS = [
     "bl_batch_upload", "bl_batch_from_device", "bl_batch_synth", "bl_batch_destroy", "bl_batch_n_bases", "bl_batch_n_seqs",
     "bl_batch_device_bases", "bl_batch_download", "bl_scan_kmers", "bl_scan_minimizers", "bl_scan_hash_sample", "bl_scan_super_kmers", "bl_scan_syncmers", "bl_sort_unique_u64", "bl_jaccard_sorted_u64",
     "bl_ctx_last_scan_ms", "bl_ctx_kernel_timing", "bl_ctx_kernel_time", "bl_reader_open", "bl_reader_close", "bl_reader_next_record",
-    "bl_reader_next_batch", "bl_reader_last_batch", "bl_reader_last_name", "bl_run_file_name", "bl_write_run_u64", "bl_write_vector_u64",
+    "bl_reader_next_batch", "bl_reader_last_batch", "bl_reader_last_name", "bl_batch_from_text", "bl_run_file_name", "bl_write_run_u64", "bl_write_vector_u64",
     "bl_device_alloc", "bl_device_free", "bl_copy_to_host", "bl_hash64_u64",
 ]
 
@@ -92,6 +92,7 @@ def lib():
     L.bl_reader_last_batch.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(u64)]
     L.bl_reader_last_name.restype = C.c_char_p
     L.bl_reader_last_name.argtypes = [vp, u64]
+    L.bl_batch_from_text.argtypes = [vp, vp, u64, C.POINTER(vp), C.POINTER(u64), C.POINTER(u64)]
     L.bl_run_file_name.argtypes = [C.c_char_p, C.c_char_p, u64, C.c_char_p, u64]
     L.bl_write_run_u64.argtypes = [vp, vp, u64, C.c_char_p]
     L.bl_write_vector_u64.argtypes = [vp, vp, u64, C.c_char_p]

@@ -296,6 +296,7 @@ int make_start_bits(bl_ctx* c, bl_batch* b, const uint64_t* offsets, uint64_t n_
 }  // namespace
 
 hipStream_t bl_ctx_stream(bl_ctx* c) { return c->user_stream ? c->user_stream : c->lanes[0].own; }
+int bl_batch_adopt_device(bl_ctx* ctx, void* d_bases, uint64_t n_bases, uint64_t* d_offsets, uint64_t n_seqs, bl_batch** out);
 int bl_ctx_device(bl_ctx* c) { return c->device; }
 
 extern "C" {
@@ -495,6 +496,32 @@ int bl_batch_synth(bl_ctx* c, uint64_t seed, uint64_t n_bases, uint64_t read_len
     *out = b;
     return BL_OK;
 }
+
+}  // extern "C"
+
+// Used by the device-side text parser (bl_parse.hip): take ownership of a device base buffer (>= n_bases + 64 bytes,
+// zero padded) and of DEVICE offsets[n_seqs + 1]; builds the start bits and frees the offsets.
+int bl_batch_adopt_device(bl_ctx* c, void* d_bases, uint64_t n_bases, uint64_t* d_offsets, uint64_t n_seqs, bl_batch** out)
+{
+    bl_batch* b = nullptr;
+    int rc = new_batch(c, n_bases, out, b);
+    if (rc != BL_OK) { (void)hipFree(d_bases); (void)hipFree(d_offsets); return rc; }
+    b->bases = static_cast<uint8_t*>(d_bases);
+    b->owns_bases = true;
+    b->n_seqs = n_seqs;
+    hipStream_t s = bl_ctx_stream(c);
+    const uint64_t n_words = (n_bases + 31) / 32 + 4;
+    hipError_t e = hipMalloc(&b->start_bits, n_words * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemsetAsync(b->start_bits, 0, n_words * sizeof(uint32_t), s);
+    if (e == hipSuccess) e = bl::launch_start_bits_offsets(b->start_bits, d_offsets, n_seqs, n_bases, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(d_offsets);
+    if (e != hipSuccess) { bl_batch_destroy(b); return fail(BL_ERR_HIP, std::string("adopt: ") + hipGetErrorString(e)); }
+    *out = b;
+    return BL_OK;
+}
+
+extern "C" {
 
 int bl_batch_destroy(bl_batch* b)
 {

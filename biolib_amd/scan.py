@@ -94,6 +94,13 @@ class Context:
         check(self._lib.bl_batch_synth(self._h, int(seed), int(n_bases), int(read_len), C.byref(h)))
         return Batch(self, h)
 
+    def from_text(self, text):
+        """Parse raw FASTA / 4-line FASTQ text on the device (bl_batch_from_text).  text: bytes or a uint8 numpy array."""
+        arr = np.frombuffer(text, dtype=np.uint8) if isinstance(text, (bytes, bytearray, memoryview)) else np.ascontiguousarray(text, dtype=np.uint8)
+        h, ns, nb = C.c_void_p(), C.c_uint64(), C.c_uint64()
+        check(self._lib.bl_batch_from_text(self._h, arr.ctypes.data_as(C.c_void_p) if arr.size else None, arr.size, C.byref(h), C.byref(ns), C.byref(nb)))
+        return Batch(self, h)
+
     def from_tensor(self, t, offsets=None, read_len=0):
         """Wrap a uint8 CUDA tensor of ASCII bases (not copied; must stay alive)."""
         assert t.is_cuda and t.dtype.itemsize == 1 and t.is_contiguous()

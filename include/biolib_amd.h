@@ -189,6 +189,12 @@ int bl_sort_unique_u64(bl_ctx* ctx, uint64_t* d_keys, uint64_t n, uint64_t* n_un
 int bl_jaccard_sorted_u64(bl_ctx* ctx, const uint64_t* d_a, uint64_t na, const uint64_t* d_b, uint64_t nb, uint64_t* intersection,
                           uint64_t* union_size);
 
+/* Device-side parser: copy raw FASTA / FASTQ TEXT (already in host memory, e.g. a read()/mmap of the file) to the GPU
+ * and build the batch there: newline index, line classification, prefix sums, gather of the sequence lines.  Same
+ * sequences as bl_reader_* for the regular layouts it accepts — FASTQ with exactly 4 lines per record, FASTA with any
+ * line wrapping, LF or CRLF — and BL_ERR_INVALID for anything else (never a silent mis-parse).  Names are not kept. */
+int bl_batch_from_text(bl_ctx* ctx, const char* text, uint64_t n_bytes, bl_batch** out, uint64_t* n_seqs, uint64_t* n_bases);
+
 /* ---- spill / wire formats read by biolib's consumers -------------------------------------
  * bl_write_run_u64: a run file of emem::external_memory_vector<uint64_t> (external_memory_vector.hpp:243-262): the
  *   SORTED keys as raw little-endian 8-byte values, no header.  bl_run_file_name builds the reference's file name

@@ -27,4 +27,15 @@ with tempfile.TemporaryDirectory() as d:
             nb += batch.n_bases
             cnt += batch.minimizers_raw(31, 11, 42, B.FLAG_CANONICAL | B.FLAG_SYNC).count
         dt = time.perf_counter() - t0
-        print(f"{os.path.basename(p)}: {nb/1e6:.0f} Mbp, file {os.path.getsize(p)/1e6:.0f} MB, {nb/dt/1e6:.1f} Mbp/s end to end (parse+upload+scan), {cnt} minimizers")
+        print(f"{os.path.basename(p)}: {nb/1e6:.0f} Mbp, file {os.path.getsize(p)/1e6:.0f} MB, {nb/dt/1e6:.1f} Mbp/s end to end (host parse+upload+scan), {cnt} minimizers")
+    # device-side parser: the raw text goes to the GPU and is parsed there (bl_batch_from_text)
+    raw = np.fromfile(path, dtype=np.uint8)
+    for rep in range(3):
+        t0 = time.perf_counter()
+        batch = ctx.from_text(raw)
+        t1 = time.perf_counter()
+        cnt = batch.minimizers_raw(31, 11, 42, B.FLAG_CANONICAL | B.FLAG_SYNC).count
+        t2 = time.perf_counter()
+        print(f"device parser rep {rep}: {batch.n_bases/1e6:.0f} Mbp from {raw.size/1e6:.0f} MB of FASTQ text: parse+upload {batch.n_bases/(t1-t0)/1e9:.2f} Gbp/s "
+              f"({raw.size/(t1-t0)/1e9:.2f} GB/s of text), scan {batch.n_bases/(t2-t1)/1e9:.1f} Gbp/s, {cnt} minimizers")
+        batch.close()

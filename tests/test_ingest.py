@@ -62,3 +62,70 @@ def test_file_to_scan_vs_oracle(fn):
         assert np.array_equal(np.concatenate(val_all) if val_all else np.zeros(0, np.uint64), v)
         assert sync == O.syncmers(seq_all, offs_all, 21, 8, 0, 13, True, positions=False)[0]
     ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fn", ["mixed.fa", "reads.fq", "many.fa", "wrapped.fq", "bad_quality.fq"])
+def test_device_side_parser_vs_reference_reader(fn):
+    """bl_batch_from_text: same sequences as the reference reader for the regular layouts, an error for the others"""
+    import biolib_amd
+
+    ctx = biolib_amd.Context(0)
+    text = open(os.path.join(ING, fn), "rb").read()
+    exp = EXPECTED[fn]
+    regular = fn in ("mixed.fa", "reads.fq")  # many.fa has junk before the first header, wrapped.fq is multi-line FASTQ
+    if not regular:
+        with pytest.raises(biolib_amd.BiolibError):
+            ctx.from_text(text)
+        if fn == "many.fa":  # without the junk line it is a regular 2-line FASTA
+            b = ctx.from_text(text[text.index(b">"):])
+            assert bytes(b.download()).decode("latin1") == "".join(exp["seqs"]) and b.n_seqs == len(exp["seqs"])
+        ctx.close()
+        return
+    b = ctx.from_text(text)
+    seqs = exp["seqs"]
+    assert b.n_seqs == len(seqs) and b.n_bases == sum(len(s) for s in seqs)
+    assert bytes(b.download()).decode("latin1") == "".join(seqs)
+    seq_all = np.frombuffer("".join(seqs).encode("latin1"), np.uint8)
+    offs_all = np.concatenate([[0], np.cumsum([len(s) for s in seqs])]).astype(np.uint64)
+    v, p, h = O.minimizers(seq_all, offs_all, 15, 9, 3, True, brute=False)  # sequence boundaries = the parser's offsets
+    got = b.minimizers(15, 9, seed=3, canonical=True)
+    assert np.array_equal(got["positions"], p) and np.array_equal(got["values"], v)
+    ctx.close()
+
+
+@pytest.mark.gpu
+def test_device_side_parser_large_fastq_and_wrapped_fasta():
+    import biolib_amd
+
+    ctx = biolib_amd.Context(0)
+    rng = np.random.default_rng(4)
+    n_reads = 200_000
+    lens = rng.integers(30, 251, n_reads)
+    seq = O.synth(5, int(lens.sum()))
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    parts = []
+    for i in range(n_reads):
+        s = seq[int(offs[i]):int(offs[i + 1])].tobytes()
+        parts.append(b"@r%d some comment\n" % i + s + (b"\r\n" if i % 1000 == 7 else b"\n") + b"+\n" + b"I" * len(s) + b"\n")
+    b = ctx.from_text(b"".join(parts))
+    assert b.n_seqs == n_reads and b.n_bases == len(seq) and np.array_equal(b.download(), seq)
+    d = O.minimizer_digest(seq, offs, 31, 11, 42, True, threads=8)
+    g = b.minimizers_raw(31, 11, 42, biolib_amd.FLAG_CANONICAL | biolib_amd.FLAG_SYNC)
+    assert (g.count, g.xor_hash, g.xor_pos) == (d["count"], d["xor_hash"], d["xor_pos"])
+    # FASTA wrapped at 60 columns, contigs from 1 base to 3 Mbp
+    clens = [1, 59, 60, 61, 100_000, 3_000_000, 777]
+    cseq = O.synth(6, sum(clens))
+    coffs = np.concatenate([[0], np.cumsum(clens)]).astype(np.uint64)
+    fa = []
+    for i, L in enumerate(clens):
+        s = cseq[int(coffs[i]):int(coffs[i + 1])].tobytes()
+        fa.append(b">c%d\n" % i + b"\n".join(s[j:j + 60] for j in range(0, L, 60)) + b"\n")
+    b2 = ctx.from_text(b"".join(fa))
+    assert b2.n_seqs == len(clens) and np.array_equal(b2.download(), cseq)
+    mn, fp, mp, sz, hs = O.super_kmers(cseq[:200_000], np.minimum(coffs, 200_000)[:6], 31, 15, 42, True)
+    got = b2.super_kmers(31, 15, seed=42, canonical=True, first=0, n=int(coffs[5]))
+    exp_mn, exp_fp, _, exp_sz, _ = O.super_kmers(cseq, coffs, 31, 15, 42, True)
+    keep = exp_fp < coffs[5]
+    assert np.array_equal(got["first_pos"], exp_fp[keep]) and np.array_equal(got["sizes"], exp_sz[keep])
+    ctx.close()
