@@ -5,6 +5,7 @@
 // plumbing, like a BLAS GEMM would be); the set intersection is a hand-written merge-path-free
 // kernel: every element of the smaller... of A binary-searches B (both unique and sorted).
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_select.hpp>
@@ -102,6 +103,124 @@ int bl_jaccard_sorted_u64(bl_ctx* ctx, const uint64_t* d_a, uint64_t na, const u
     if (e != hipSuccess) return bl_set_error(BL_ERR_HIP, hipGetErrorString(e));
     *intersection = inter;
     *union_size = na + nb - inter;
+    return BL_OK;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------
+// k-mer counting pieces for the multi-GPU bucket exchange: split a key list into `parts`
+// buckets by hash64(key, seed) % parts (the owner GPU of a k-mer), and run-length count a sorted list.
+#include <rocprim/device/device_run_length_encode.hpp>
+#include "bl_scan_core.hpp"
+
+namespace {
+
+constexpr int MAX_PARTS = 64;
+
+__global__ void bucket_count_kernel(const unsigned long long* keys, unsigned long long n, uint32_t parts, uint32_t seed, unsigned long long* counts)
+{
+    __shared__ unsigned int hist[MAX_PARTS];
+    if (threadIdx.x < MAX_PARTS) hist[threadIdx.x] = 0;
+    __syncthreads();
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * blockDim.x)
+        atomicAdd(&hist[bl::murmur64(keys[i], seed) % parts], 1u);
+    __syncthreads();
+    if (threadIdx.x < parts && hist[threadIdx.x]) atomicAdd(&counts[threadIdx.x], (unsigned long long)hist[threadIdx.x]);
+}
+
+// cursor[b] starts at the bucket's offset; order inside a bucket is arbitrary (the buckets get sorted afterwards)
+__global__ void bucket_scatter_kernel(const unsigned long long* keys, unsigned long long n, uint32_t parts, uint32_t seed,
+                                      unsigned long long* cursor, unsigned long long* out)
+{
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * blockDim.x) {
+        const unsigned long long k = keys[i];
+        const unsigned long long at = atomicAdd(&cursor[bl::murmur64(k, seed) % parts], 1ull);
+        out[at] = k;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int bl_partition_u64(bl_ctx* ctx, const uint64_t* d_keys, uint64_t n, uint32_t parts, uint64_t seed, uint64_t* d_out, uint64_t* counts)
+{
+    if (!ctx || !counts || parts == 0 || parts > MAX_PARTS || (n && (!d_keys || !d_out))) return bl_set_error(BL_ERR_INVALID, "bad argument (1 <= parts <= 64)");
+    SET_HIP(hipSetDevice(bl_ctx_device(ctx)));
+    hipStream_t s = bl_ctx_stream(ctx);
+    unsigned long long* d_counts = nullptr;
+    SET_HIP(hipMalloc(&d_counts, 2 * MAX_PARTS * sizeof(unsigned long long)));
+    hipError_t e = hipMemsetAsync(d_counts, 0, 2 * MAX_PARTS * sizeof(unsigned long long), s);
+    const unsigned blocks = (unsigned)std::min<uint64_t>((n + 255) / 256 + 1, 256 * 8);
+    unsigned long long host[MAX_PARTS] = {0}, cursor[MAX_PARTS] = {0};
+    if (e == hipSuccess && n) {
+        hipLaunchKernelGGL(bucket_count_kernel, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const unsigned long long*>(d_keys), n, parts, (uint32_t)seed, d_counts);
+        e = hipMemcpyAsync(host, d_counts, parts * sizeof(unsigned long long), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        unsigned long long run = 0;
+        for (uint32_t b = 0; b < parts; ++b) { cursor[b] = run; run += host[b]; }
+        if (e == hipSuccess) e = hipMemcpyAsync(d_counts + MAX_PARTS, cursor, parts * sizeof(unsigned long long), hipMemcpyHostToDevice, s);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(bucket_scatter_kernel, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const unsigned long long*>(d_keys), n, parts, (uint32_t)seed,
+                               d_counts + MAX_PARTS, reinterpret_cast<unsigned long long*>(d_out));
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+    }
+    (void)hipFree(d_counts);
+    if (e != hipSuccess) return bl_set_error(BL_ERR_HIP, hipGetErrorString(e));
+    for (uint32_t b = 0; b < parts; ++b) counts[b] = host[b];
+    return BL_OK;
+}
+
+// sorted keys (duplicates kept) -> distinct keys + their multiplicities; returns the number of distinct keys
+int bl_count_sorted_u64(bl_ctx* ctx, const uint64_t* d_sorted, uint64_t n, uint64_t* d_unique, uint32_t* d_counts, uint64_t* n_unique)
+{
+    if (!ctx || !n_unique || (n && (!d_sorted || !d_unique || !d_counts))) return bl_set_error(BL_ERR_INVALID, "NULL argument");
+    *n_unique = 0;
+    if (n == 0) return BL_OK;
+    SET_HIP(hipSetDevice(bl_ctx_device(ctx)));
+    hipStream_t s = bl_ctx_stream(ctx);
+    unsigned long long* d_runs = nullptr;
+    void* tmp = nullptr;
+    size_t bytes = 0;
+    SET_HIP(hipMalloc(&d_runs, sizeof(unsigned long long)));
+    hipError_t e = rocprim::run_length_encode(nullptr, bytes, reinterpret_cast<const unsigned long long*>(d_sorted), n,
+                                              reinterpret_cast<unsigned long long*>(d_unique), d_counts, d_runs, s);
+    if (e == hipSuccess) e = hipMalloc(&tmp, bytes ? bytes : 16);
+    if (e == hipSuccess)
+        e = rocprim::run_length_encode(tmp, bytes, reinterpret_cast<const unsigned long long*>(d_sorted), n, reinterpret_cast<unsigned long long*>(d_unique),
+                                       d_counts, d_runs, s);
+    unsigned long long runs = 0;
+    if (e == hipSuccess) e = hipMemcpyAsync(&runs, d_runs, sizeof(runs), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(d_runs);
+    if (tmp) (void)hipFree(tmp);
+    if (e != hipSuccess) return bl_set_error(e == hipErrorOutOfMemory ? BL_ERR_OOM : BL_ERR_HIP, hipGetErrorString(e));
+    *n_unique = runs;
+    return BL_OK;
+}
+
+int bl_sort_u64(bl_ctx* ctx, uint64_t* d_keys, uint64_t n)
+{
+    if (!ctx || (n && !d_keys)) return bl_set_error(BL_ERR_INVALID, "NULL argument");
+    if (n == 0) return BL_OK;
+    SET_HIP(hipSetDevice(bl_ctx_device(ctx)));
+    hipStream_t s = bl_ctx_stream(ctx);
+    unsigned long long* keys = reinterpret_cast<unsigned long long*>(d_keys);
+    unsigned long long* tmp = nullptr;
+    void* scratch = nullptr;
+    size_t bytes = 0;
+    SET_HIP(hipMalloc(&tmp, n * sizeof(unsigned long long)));
+    hipError_t e = rocprim::radix_sort_keys(nullptr, bytes, keys, tmp, n, 0, 64, s);
+    if (e == hipSuccess) e = hipMalloc(&scratch, bytes ? bytes : 16);
+    if (e == hipSuccess) e = rocprim::radix_sort_keys(scratch, bytes, keys, tmp, n, 0, 64, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(keys, tmp, n * sizeof(unsigned long long), hipMemcpyDeviceToDevice, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(tmp);
+    if (scratch) (void)hipFree(scratch);
+    if (e != hipSuccess) return bl_set_error(e == hipErrorOutOfMemory ? BL_ERR_OOM : BL_ERR_HIP, hipGetErrorString(e));
     return BL_OK;
 }
 

@@ -127,6 +127,26 @@ class Context:
         check(self._lib.bl_jaccard_sorted_u64(self._h, C.c_void_p(a.data_ptr()), int(na), C.c_void_p(b.data_ptr()), int(nb), C.byref(i), C.byref(u)))
         return int(i.value), int(u.value)
 
+    def partition(self, keys, parts, seed=0, n=None):
+        """(bucketed copy of keys[:n], sizes[parts]): bucket b = keys with hash64(key, seed) % parts == b, contiguous, in bucket order"""
+        n = keys.numel() if n is None else int(n)
+        out = self.empty_u64(n)
+        counts = (C.c_uint64 * int(parts))()
+        check(self._lib.bl_partition_u64(self._h, C.c_void_p(keys.data_ptr()), n, int(parts), int(seed), C.c_void_p(out.data_ptr()), counts))
+        return out[:n], [int(c) for c in counts]
+
+    def sort_count(self, keys, n=None):
+        """(distinct keys ascending, multiplicities) of keys[:n]; keys is sorted in place"""
+        import torch
+
+        n = keys.numel() if n is None else int(n)
+        check(self._lib.bl_sort_u64(self._h, C.c_void_p(keys.data_ptr()), n))
+        uniq = self.empty_u64(n)
+        mult = torch.empty(max(n, 1), dtype=torch.int32, device=self.torch_device)
+        runs = C.c_uint64()
+        check(self._lib.bl_count_sorted_u64(self._h, C.c_void_p(keys.data_ptr()), n, C.c_void_p(uniq.data_ptr()), C.c_void_p(mult.data_ptr()), C.byref(runs)))
+        return uniq[: runs.value], mult[: runs.value]
+
     # ---- device arrays (torch plumbing)
     def empty_u64(self, n):
         import torch

@@ -58,3 +58,33 @@ def reduce_digests(local, device=None, group=None):
             acc ^= g.cpu().numpy().view(np.uint64)
         out.update({k: int(v) for k, v in zip(xors, acc)})
     return out
+
+
+def exchange_and_count(keys, partition, count, group=None):
+    """Partitioned k-mer counting across ranks (the step after the scan in a distributed counter).
+
+    keys       this rank's k-mers / minimizers: 1-D int64 tensor holding uint64 bit patterns (device tensor with RCCL,
+               CPU tensor with gloo), duplicates allowed
+    partition  callable(keys, parts) -> (bucketed_keys, counts[parts]): keys regrouped so that bucket b — the keys owned
+               by rank b, hash64(key) % parts == b — is contiguous and buckets follow each other in rank order
+               (Context.partition on the GPU)
+    count      callable(keys) -> (distinct_keys, multiplicities) (Context.sort_count on the GPU)
+
+    Every key travels at most once: one 8-byte-per-rank all-to-all of bucket sizes, then ONE variable-size all-to-all of
+    the keys themselves (RCCL over xGMI: each GPU pair uses its own direct link, so the exchange is bound by
+    keys_per_rank * 8 B * (world-1)/world over 7 links, not by a ring).  Returns this rank's (distinct_keys,
+    multiplicities): the exact global multiplicity of every key this rank owns."""
+    import torch
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()):
+        return count(keys)
+    world = dist.get_world_size(group)
+    bucketed, counts = partition(keys, world)
+    send = torch.tensor([int(c) for c in counts], dtype=torch.int64, device=keys.device)
+    recv = torch.empty_like(send)
+    dist.all_to_all_single(recv, send, group=group)
+    recv_sizes = [int(x) for x in recv.cpu().tolist()]
+    inbox = torch.empty(sum(recv_sizes), dtype=torch.int64, device=keys.device)
+    dist.all_to_all_single(inbox, bucketed[: int(sum(counts))], output_split_sizes=recv_sizes, input_split_sizes=[int(c) for c in counts], group=group)
+    return count(inbox)

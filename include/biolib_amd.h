@@ -189,6 +189,15 @@ int bl_sort_unique_u64(bl_ctx* ctx, uint64_t* d_keys, uint64_t n, uint64_t* n_un
 int bl_jaccard_sorted_u64(bl_ctx* ctx, const uint64_t* d_a, uint64_t na, const uint64_t* d_b, uint64_t nb, uint64_t* intersection,
                           uint64_t* union_size);
 
+/* ---- multi-GPU k-mer counting pieces ------------------------------------------------------
+ * bl_partition_u64: reorder keys into `parts` (<= 64) buckets by hash64(key, seed) % parts — the owner rank of a
+ *   k-mer in a partitioned count; counts[b] (host) = size of bucket b, buckets are contiguous in d_out in bucket order.
+ * bl_sort_u64: in-place ascending sort (duplicates kept).  bl_count_sorted_u64: run-length count of a sorted list.
+ * The exchange between the two (all-to-all over RCCL / xGMI) is biolib_amd/shard.py:exchange_and_count. */
+int bl_partition_u64(bl_ctx* ctx, const uint64_t* d_keys, uint64_t n, uint32_t parts, uint64_t seed, uint64_t* d_out, uint64_t* counts);
+int bl_sort_u64(bl_ctx* ctx, uint64_t* d_keys, uint64_t n);
+int bl_count_sorted_u64(bl_ctx* ctx, const uint64_t* d_sorted, uint64_t n, uint64_t* d_unique, uint32_t* d_counts, uint64_t* n_unique);
+
 /* Device-side parser: copy raw FASTA / FASTQ TEXT (already in host memory, e.g. a read()/mmap of the file) to the GPU
  * and build the batch there: newline index, line classification, prefix sums, gather of the sequence lines.  Same
  * sequences as bl_reader_* for the regular layouts it accepts — FASTQ with exactly 4 lines per record, FASTA with any

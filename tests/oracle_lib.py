@@ -197,3 +197,30 @@ def syncmers(seq, offsets, k, m, soff, eoff, canonical, drop_last=False, threads
 
 def xor_reduce(a):
     return int(np.bitwise_xor.reduce(a)) if len(a) else 0
+
+
+def hash64_np(values, seed):
+    """vectorised hash64 of uint64 keys (numpy restatement of blo_hash64_u64, pinned against it in
+    tests/test_shard_gloo.py): low half of MurmurHash3_x64_128 over the 8 key bytes, 32-bit seed."""
+    M = np.uint64
+    with np.errstate(over="ignore"):
+        k = np.asarray(values, dtype=np.uint64).copy()
+        s = M(int(seed) & 0xFFFFFFFF)
+        rotl = lambda x, r: (x << M(r)) | (x >> M(64 - r))
+        k *= M(0x87C37B91114253D5)
+        k = rotl(k, 31)
+        k *= M(0x4CF5AD432745937F)
+        h1 = (s ^ k) ^ M(8)
+        h2 = np.full_like(k, s ^ M(8))
+        h1 = h1 + h2
+        h2 = h2 + h1
+
+        def fmix(x):
+            x = x ^ (x >> M(33))
+            x = x * M(0xFF51AFD7ED558CCD)
+            x = x ^ (x >> M(33))
+            x = x * M(0xC4CEB9FE1A85EC53)
+            return x ^ (x >> M(33))
+
+        h1, h2 = fmix(h1), fmix(h2)
+        return h1 + h2

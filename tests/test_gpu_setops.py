@@ -101,3 +101,71 @@ def test_jaccard_of_two_fasta_files_like_the_reference_tool(ctx):
     a = sets[0][0][: sets[0][1]].cpu().numpy().view(np.uint64)
     b = sets[1][0][: sets[1][1]].cpu().numpy().view(np.uint64)
     assert (inter, uni) == (len(np.intersect1d(a, b)), len(np.union1d(a, b)))
+
+
+# ---- §8f rank 4: partitioned counting (bucket split -> exchange -> sort -> run-length count)
+@pytest.mark.parametrize("parts", [1, 2, 8, 64])
+def test_partition_by_owner(ctx, parts):
+    import torch
+
+    rng = np.random.default_rng(parts)
+    keys = rng.integers(0, 2**63, 300_001).astype(np.uint64)
+    keys[::7] = keys[0]  # heavy duplicates land in one bucket
+    t = torch.from_numpy(keys.view(np.int64).copy()).cuda()
+    out, counts = ctx.partition(t, parts, seed=5)
+    got = out.cpu().numpy().view(np.uint64)
+    owner = O.hash64_np(keys, 5) % np.uint64(parts)
+    assert counts == np.bincount(owner.astype(np.int64), minlength=parts).tolist()
+    edges = np.concatenate([[0], np.cumsum(counts)])
+    for b in range(parts):
+        seg = got[edges[b]:edges[b + 1]]
+        assert np.all(O.hash64_np(seg, 5) % np.uint64(parts) == b)
+        assert np.array_equal(np.sort(seg), np.sort(keys[owner == b]))
+    with pytest.raises(Exception):
+        ctx.partition(t, 65)
+
+
+def test_sort_count_vs_numpy(ctx):
+    import torch
+
+    seq = O.synth(3, 400_000)
+    vals, ok = O.units(seq, O.fixed_offsets(len(seq), 150), 9, True)   # 4^9 keys: plenty of repeats
+    keys = vals[ok != 0]
+    t = torch.from_numpy(keys.view(np.int64).copy()).cuda()
+    u, c = ctx.sort_count(t)
+    eu, ec = np.unique(keys, return_counts=True)
+    assert np.array_equal(u.cpu().numpy().view(np.uint64), eu) and np.array_equal(c.cpu().numpy().astype(np.int64), ec)
+    assert np.array_equal(t.cpu().numpy().view(np.uint64), np.sort(keys))
+    e = ctx.sort_count(ctx.empty_u64(0), n=0)
+    assert e[0].numel() == 0 and e[1].numel() == 0
+
+
+def test_exchange_and_count_single_rank_rccl(ctx):
+    """the whole distributed counter on one GPU: scan -> partition -> all-to-all (RCCL, world 1) -> sort -> count"""
+    import torch
+    import torch.distributed as dist
+
+    from biolib_amd.shard import exchange_and_count
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        n = 2_000_000
+        b = ctx.synth(12, n, 150)
+        import biolib_amd as B
+
+        span = n
+        v, ok_t = ctx.empty_u64(span), ctx.empty_u8(span)
+        b.kmers_raw(11, 0, B.FLAG_CANONICAL | B.FLAG_SYNC, values=v, valid=ok_t)
+        vals = v[:span][ok_t[:span].bool()].contiguous()               # device-resident k-mers straight from the scan
+        seq = O.synth(12, n)
+        ev, ok = O.units(seq, O.fixed_offsets(n, 150), 11, True)
+        u, c = exchange_and_count(vals, lambda k, parts: ctx.partition(k, parts), lambda k: ctx.sort_count(k))
+        eu, ec = np.unique(ev[ok != 0], return_counts=True)
+        assert np.array_equal(u.cpu().numpy().view(np.uint64), eu) and np.array_equal(c.cpu().numpy().astype(np.int64), ec)
+    finally:
+        if created:
+            dist.destroy_process_group()

@@ -77,3 +77,66 @@ def test_two_rank_scan_and_reduce(tmp_path):
     sy, _ = O.syncmers(seq, offs, 31, 11, 0, 20, True, positions=False)
     assert got["count"] == d["count"] and got["xor_value"] == d["xor_value"] and got["xor_hash"] == d["xor_hash"] and got["xor_pos"] == d["xor_pos"]
     assert got["syncmer_count"] == sy
+
+
+def test_hash64_np_matches_oracle():
+    L = O.oracle()
+    v = np.random.default_rng(1).integers(0, 2**63, 500).astype(np.uint64)
+    for seed in (0, 42, 2**32 + 5):
+        assert np.array_equal(O.hash64_np(v, seed), np.array([L.blo_hash64_u64(int(x), seed) for x in v], np.uint64))
+
+
+COUNT_WORKER = textwrap.dedent("""
+    import json, os, sys
+    sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+    import numpy as np, torch, torch.distributed as dist
+    import oracle_lib as O
+    from biolib_amd.shard import shard_reads, exchange_and_count
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    L, n_reads = 100, 3001
+    first, cnt = shard_reads(n_reads, world, rank)
+    seq = O.synth(9, n_reads * L)[first * L:(first + cnt) * L]
+    seq = np.concatenate([seq, seq[: 40 * L]])                      # repeats inside the shard -> multiplicities > 1
+    vals, valid = O.units(seq, O.fixed_offsets(len(seq), L), 13, True)
+    keys = torch.from_numpy(vals[valid != 0].view(np.int64).copy())
+
+    def partition(t, parts):                                         # numpy stand-in of Context.partition
+        k = t.numpy().view(np.uint64)
+        owner = O.hash64_np(k, 0) % np.uint64(parts)
+        order = np.argsort(owner, kind="stable")
+        return torch.from_numpy(k[order].view(np.int64).copy()), np.bincount(owner.astype(np.int64), minlength=parts).tolist()
+
+    def count(t):                                                    # numpy stand-in of Context.sort_count
+        u, c = np.unique(t.numpy().view(np.uint64), return_counts=True)
+        return u, c
+
+    u, c = exchange_and_count(keys, partition, count)
+    assert np.all(O.hash64_np(u, 0) % np.uint64(world) == rank)       # this rank only holds keys it owns
+    np.savez(os.path.join({out!r}, f"rank{{rank}}.npz"), u=u, c=c)
+    dist.destroy_process_group()
+""")
+
+
+def test_two_rank_exchange_and_count(tmp_path):
+    script = tmp_path / "count_worker.py"
+    script.write_text(COUNT_WORKER.format(root=ROOT, out=str(tmp_path)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29519", str(script)], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    from biolib_amd.shard import shard_reads
+    L, n_reads = 100, 3001
+    whole = []
+    for rank in range(2):
+        first, cnt = shard_reads(n_reads, 2, rank)
+        seq = O.synth(9, n_reads * L)[first * L:(first + cnt) * L]
+        seq = np.concatenate([seq, seq[: 40 * L]])
+        vals, valid = O.units(seq, O.fixed_offsets(len(seq), L), 13, True)
+        whole.append(vals[valid != 0])
+    u, c = np.unique(np.concatenate(whole), return_counts=True)
+    parts = [np.load(tmp_path / f"rank{r}.npz") for r in range(2)]
+    gu = np.concatenate([p["u"] for p in parts])
+    gc = np.concatenate([p["c"] for p in parts])
+    order = np.argsort(gu)
+    assert np.array_equal(gu[order], u) and np.array_equal(gc[order], c) and c.max() > 1
