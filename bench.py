@@ -48,16 +48,23 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    rehearse = world > 1 and os.environ.get("BL_BENCH_REHEARSE") == "1"
+    coll_dev = "cpu" if rehearse else "cuda"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # nccl == RCCL on ROCm
+        if rehearse:
+            # rehearsal of the multi-rank flow on a ONE-GPU box (never a measurement): every rank on cuda:0, gloo for
+            # the bookkeeping collectives because RCCL refuses two ranks on one device
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # nccl == RCCL on ROCm
     n_gpus = world
     if args.gpus != world and rank == 0:
         print(f"# note: --gpus {args.gpus} but WORLD_SIZE={world}; running {world} rank(s)", file=sys.stderr)
 
-    dev = local_rank if world > 1 else 0
+    dev = local_rank if (world > 1 and not rehearse) else 0
     torch.cuda.set_device(dev)
     ctx = biolib_amd.Context(dev, torch_stream=False)  # own streams: consecutive scans alternate between two lanes and overlap
 
@@ -115,7 +122,7 @@ def main():
     total_count = count
     allreduce_ms = None
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         t_max = float(t.item())
         # optional final count reduction over RCCL/xGMI (64-bit sums all-reduced, XOR digests gathered and
@@ -124,11 +131,11 @@ def main():
 
         torch.cuda.synchronize()
         ta = time.perf_counter()
-        tot = reduce_digests(dict(count=count, xor_hash=xor_hash), device="cuda")
+        tot = reduce_digests(dict(count=count, xor_hash=xor_hash), device=coll_dev)
         torch.cuda.synchronize()
         allreduce_ms = (time.perf_counter() - ta) * 1e3
         total_count, xor_hash = tot["count"], tot["xor_hash"]
-        k = torch.tensor([kernel_ms], dtype=torch.float64, device="cuda")
+        k = torch.tensor([kernel_ms], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(k, op=dist.ReduceOp.MAX)
         kernel_ms = float(k.item())
 
@@ -174,6 +181,8 @@ def main():
                 "note": "integer-ALU bound before HBM: 6 x 64-bit multiplies per base (MurmurHash3_x64_128), see DESIGN.md",
             },
         }
+        if rehearse:
+            out["rehearsal"] = "all ranks on cuda:0 over gloo: flow check only, NOT a measurement"
         if allreduce_ms is not None:
             out["count_allreduce_ms"] = round(allreduce_ms, 3)
         if n_gpus == 1 and not args.no_cpu_baseline:
