@@ -25,6 +25,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 UNIT, W, SEED, READ_LEN = 31, 11, 42, 150
+N_CU = 256
+CLOCK_HZ = 2.4e9
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
@@ -147,10 +149,21 @@ def main():
         avg_kernel_s = kernel_ms / 1e3 / max(launches, 1)
         achieved = bases_per_launch * 1.0 / avg_kernel_s / 1e9  # 1 algorithmic byte per base
         traffic = None
+        valu = None
         tp = os.path.join(ROOT, "profiles", "traffic.json")  # written from a separate rocprofv3 --pmc run, see DESIGN.md
         if os.path.exists(tp):
             try:
-                traffic = int(json.load(open(tp))["hbm_bytes_per_base"] * bases_per_launch)  # PMC bytes per base x this run's bases per launch
+                prof = json.load(open(tp))
+                traffic = int(prof["hbm_bytes_per_base"] * bases_per_launch)  # PMC bytes per base x this run's bases per launch
+                # second ceiling: VALU issue.  A wave64 instruction occupies a SIMD16 for 4 cycles, so the
+                # nominal peak is CUs x 4 SIMDs x clock / 4 wave-instructions per second (some simple ops retire faster,
+                # which is how the fraction can pass 1).
+                winstr = prof["valu_wave_instr_per_base"] * bases_per_launch
+                peak_winstr = N_CU * 4 * CLOCK_HZ / 4.0
+                valu = {"wave_instr_per_launch": int(winstr), "achieved_Ginstr_s": round(winstr / avg_kernel_s / 1e9, 1),
+                        "peak_Ginstr_s": round(peak_winstr / 1e9, 1), "frac": round(winstr / avg_kernel_s / peak_winstr, 3),
+                        "lane_instr_per_base": round(prof["valu_wave_instr_per_base"] * 64, 1),
+                        "source": "SQ_INSTS_VALU, profiles/r01_pmc_summary.txt; 256 CUs x 4 SIMD16 at 2.4 GHz"}
             except Exception:
                 traffic = None
         out = {
@@ -183,6 +196,15 @@ def main():
         }
         if rehearse:
             out["rehearsal"] = "all ranks on cuda:0 over gloo: flow check only, NOT a measurement"
+        if valu is not None:
+            out["roofline"]["valu"] = valu
+        if n_gpus == 1:
+            try:
+                rd, cp = ctx.probe_hbm(8 << 30, 5)
+                out["roofline"]["peak_measured"] = {"read_GBps": round(rd, 1), "copy_GBps": round(cp, 1),
+                                                    "note": "this device, 8 GiB buffers: read-only stream kernel / DtoD copy (read+write bytes)"}
+            except Exception as e:  # a probe failure must not lose the bench line
+                out["roofline"]["peak_measured"] = {"error": str(e)}
         if allreduce_ms is not None:
             out["count_allreduce_ms"] = round(allreduce_ms, 3)
         if n_gpus == 1 and not args.no_cpu_baseline:

@@ -1,0 +1,207 @@
+// Packed super-k-mer records for the multi-GPU bucket exchange.
+//
+// A super-k-mer (reference record: include/super_kmer_view.hpp:20-24 — minimizer, mm_pos, size) stands for `size`
+// consecutive k-mers = size + k - 1 bases.  What travels between GPUs is its sequence, 2 bits per base, in a fixed
+// 16-byte record, routed by the hash of its minimizer — every occurrence of a canonical k-mer has the same minimizer
+// value, hence the same owner, so the owner can count k-mers exactly with no further exchange:
+//
+//   rec[0]  bases 0..31, first base in the most significant pair (kmer_view.hpp:194 packing)
+//   rec[1]  bases 32..59 in bits 63..8 (same order), bits 7..0 = size (number of k-mers, 1 .. k-m+1)
+//
+// so size + k - 1 <= 60 bases (k = 31, m = 15: at most 47).  8 B/k-mer become ~1.8 B/base on the links.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <rocprim/device/device_scan.hpp>
+
+#include "../../include/biolib_amd.h"
+
+extern int bl_set_error(int code, const char* msg);  // bl_capi.hip
+extern hipStream_t bl_ctx_stream(bl_ctx* ctx);
+extern int bl_ctx_device(bl_ctx* ctx);
+
+namespace {
+
+constexpr int MAX_PARTS = 64;
+constexpr int MAX_BASES = 60;
+
+#define SK_HIP(call)                                                                                                             \
+    do {                                                                                                                         \
+        hipError_t e_ = (call);                                                                                                  \
+        if (e_ != hipSuccess) return bl_set_error(e_ == hipErrorOutOfMemory ? BL_ERR_OOM : BL_ERR_HIP, hipGetErrorString(e_));    \
+    } while (0)
+
+__device__ __forceinline__ unsigned code_of(unsigned char c) { return ((c >> 1) ^ (c >> 2)) & 3u; }  // A0 C1 G2 T/U3 (constants.hpp:12-21)
+
+__device__ __forceinline__ unsigned base_at(unsigned long long hi, unsigned long long lo, int i)
+{
+    return i < 32 ? (unsigned)(hi >> (62 - 2 * i)) & 3u : (unsigned)(lo >> (62 - 2 * (i - 32))) & 3u;
+}
+
+__global__ __launch_bounds__(256) void pack_kernel(const unsigned char* __restrict__ bases, unsigned long long n_bases,
+                                                   const unsigned long long* __restrict__ first_pos, const unsigned char* __restrict__ sizes,
+                                                   unsigned long long n, int k, ulonglong2* __restrict__ out)
+{
+    const unsigned long long g = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n) return;
+    const unsigned long long p = first_pos[g];
+    const int size = sizes[g];
+    int nb = size + k - 1;
+    if (p + (unsigned long long)nb > n_bases) nb = p < n_bases ? (int)(n_bases - p) : 0;  // never read past the batch (a caller error; the record is then short)
+    unsigned long long hi = 0, lo = 0;
+    const int n_hi = nb < 32 ? nb : 32;
+    for (int i = 0; i < n_hi; ++i) hi = (hi << 2) | code_of(bases[p + i]);
+    if (n_hi < 32) hi <<= 2 * (32 - n_hi);
+    for (int i = 32; i < nb; ++i) lo = (lo << 2) | code_of(bases[p + i]);
+    if (nb > 32) lo <<= 64 - 2 * (nb - 32);
+    out[g] = make_ulonglong2(hi, (lo & ~0xffULL) | (unsigned long long)size);
+}
+
+__global__ void owner_count_kernel(const unsigned long long* hashes, unsigned long long n, unsigned parts, unsigned long long* counts)
+{
+    __shared__ unsigned int hist[MAX_PARTS];
+    if (threadIdx.x < MAX_PARTS) hist[threadIdx.x] = 0;
+    __syncthreads();
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * blockDim.x)
+        atomicAdd(&hist[hashes[i] % parts], 1u);
+    __syncthreads();
+    if (threadIdx.x < parts && hist[threadIdx.x]) atomicAdd(&counts[threadIdx.x], (unsigned long long)hist[threadIdx.x]);
+}
+
+__global__ void owner_scatter_kernel(const unsigned long long* hashes, const ulonglong2* recs, unsigned long long n, unsigned parts,
+                                     unsigned long long* cursor, ulonglong2* out)
+{
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * blockDim.x) {
+        const unsigned long long at = atomicAdd(&cursor[hashes[i] % parts], 1ull);
+        out[at] = recs[i];
+    }
+}
+
+__global__ void sizes_kernel(const ulonglong2* recs, unsigned long long n, unsigned long long* sizes)
+{
+    const unsigned long long g = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g < n) sizes[g] = recs[g].y & 0xffULL;
+}
+
+__global__ __launch_bounds__(256) void expand_kernel(const ulonglong2* __restrict__ recs, const unsigned long long* __restrict__ offsets,
+                                                     unsigned long long n, int k, int canonical, unsigned long long* __restrict__ out)
+{
+    const unsigned long long g = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n) return;
+    const unsigned long long hi = recs[g].x, lo = recs[g].y;
+    const int size = (int)(lo & 0xffULL);
+    const unsigned long long mask = k == 32 ? ~0ULL : ((1ULL << (2 * k)) - 1);
+    const int shift = 2 * (k - 1);
+    unsigned long long fwd = 0, rc = 0;
+    for (int i = 0; i < k - 1; ++i) {  // kmer_view.hpp:190-199, started from the packed codes
+        const unsigned long long c = base_at(hi, lo, i);
+        fwd = ((fwd << 2) | c) & mask;
+        rc = (rc >> 2) | ((3ULL ^ c) << shift);
+    }
+    unsigned long long* dst = out + offsets[g];
+    for (int j = 0; j < size; ++j) {
+        const unsigned long long c = base_at(hi, lo, k - 1 + j);
+        fwd = ((fwd << 2) | c) & mask;
+        rc = (rc >> 2) | ((3ULL ^ c) << shift);
+        dst[j] = canonical ? (fwd < rc ? fwd : rc) : fwd;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int bl_pack_super_kmers(bl_ctx* ctx, const bl_batch* batch, const uint64_t* d_first_pos, const uint8_t* d_sizes, uint64_t n_groups, uint32_t k,
+                        uint32_t m, uint64_t* d_records)
+{
+    if (!ctx || !batch || (n_groups && (!d_first_pos || !d_sizes || !d_records))) return bl_set_error(BL_ERR_INVALID, "NULL argument");
+    if (k < 1 || k > 32 || m < 1 || m > k || 2 * k - m > MAX_BASES) return bl_set_error(BL_ERR_INVALID, "need 1 <= m <= k <= 32 and 2k - m <= 60 (bases per packed record)");
+    if (n_groups == 0) return BL_OK;
+    SK_HIP(hipSetDevice(bl_ctx_device(ctx)));
+    hipStream_t s = bl_ctx_stream(ctx);
+    hipLaunchKernelGGL(pack_kernel, dim3((unsigned)((n_groups + 255) / 256)), dim3(256), 0, s, static_cast<const unsigned char*>(bl_batch_device_bases(batch)),
+                       (unsigned long long)bl_batch_n_bases(batch), reinterpret_cast<const unsigned long long*>(d_first_pos), d_sizes,
+                       (unsigned long long)n_groups, (int)k, reinterpret_cast<ulonglong2*>(d_records));
+    SK_HIP(hipGetLastError());
+    return BL_OK;
+}
+
+int bl_partition_records(bl_ctx* ctx, const uint64_t* d_hashes, const uint64_t* d_records, uint64_t n, uint32_t parts, uint64_t* d_out, uint64_t* counts)
+{
+    if (!ctx || !counts || parts == 0 || parts > MAX_PARTS || (n && (!d_hashes || !d_records || !d_out)))
+        return bl_set_error(BL_ERR_INVALID, "bad argument (1 <= parts <= 64)");
+    for (uint32_t b = 0; b < parts; ++b) counts[b] = 0;
+    if (n == 0) return BL_OK;
+    SK_HIP(hipSetDevice(bl_ctx_device(ctx)));
+    hipStream_t s = bl_ctx_stream(ctx);
+    unsigned long long* d_counts = nullptr;
+    SK_HIP(hipMalloc(&d_counts, 2 * MAX_PARTS * sizeof(unsigned long long)));
+    hipError_t e = hipMemsetAsync(d_counts, 0, 2 * MAX_PARTS * sizeof(unsigned long long), s);
+    const unsigned blocks = (unsigned)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+    unsigned long long host[MAX_PARTS] = {0}, cursor[MAX_PARTS] = {0};
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(owner_count_kernel, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const unsigned long long*>(d_hashes), (unsigned long long)n, parts, d_counts);
+        e = hipMemcpyAsync(host, d_counts, parts * sizeof(unsigned long long), hipMemcpyDeviceToHost, s);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    unsigned long long run = 0;
+    for (uint32_t b = 0; b < parts; ++b) {
+        cursor[b] = run;
+        run += host[b];
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(d_counts + MAX_PARTS, cursor, parts * sizeof(unsigned long long), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(owner_scatter_kernel, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const unsigned long long*>(d_hashes),
+                           reinterpret_cast<const ulonglong2*>(d_records), (unsigned long long)n, parts, d_counts + MAX_PARTS, reinterpret_cast<ulonglong2*>(d_out));
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(d_counts);
+    if (e != hipSuccess) return bl_set_error(BL_ERR_HIP, hipGetErrorString(e));
+    for (uint32_t b = 0; b < parts; ++b) counts[b] = host[b];
+    return BL_OK;
+}
+
+int bl_expand_super_kmers(bl_ctx* ctx, const uint64_t* d_records, uint64_t n_groups, uint32_t k, uint32_t flags, uint64_t* d_kmers, uint64_t capacity,
+                          uint64_t* n_kmers)
+{
+    if (!ctx || !n_kmers || (n_groups && !d_records)) return bl_set_error(BL_ERR_INVALID, "NULL argument");
+    if (k < 1 || k > 32) return bl_set_error(BL_ERR_INVALID, "need 1 <= k <= 32");
+    *n_kmers = 0;
+    if (n_groups == 0) return BL_OK;
+    SK_HIP(hipSetDevice(bl_ctx_device(ctx)));
+    hipStream_t s = bl_ctx_stream(ctx);
+    unsigned long long *sizes = nullptr, *offsets = nullptr;
+    void* tmp = nullptr;
+    size_t bytes = 0;
+    const unsigned blocks = (unsigned)((n_groups + 255) / 256);
+    hipError_t e = hipMalloc(&sizes, 2 * n_groups * sizeof(unsigned long long));
+    if (e != hipSuccess) return bl_set_error(BL_ERR_OOM, hipGetErrorString(e));
+    offsets = sizes + n_groups;
+    hipLaunchKernelGGL(sizes_kernel, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const ulonglong2*>(d_records), (unsigned long long)n_groups, sizes);
+    e = rocprim::exclusive_scan(nullptr, bytes, sizes, offsets, 0ull, n_groups, rocprim::plus<unsigned long long>(), s);
+    if (e == hipSuccess) e = hipMalloc(&tmp, bytes ? bytes : 16);
+    if (e == hipSuccess) e = rocprim::exclusive_scan(tmp, bytes, sizes, offsets, 0ull, n_groups, rocprim::plus<unsigned long long>(), s);
+    unsigned long long last[2] = {0, 0};
+    if (e == hipSuccess) e = hipMemcpyAsync(&last[0], offsets + n_groups - 1, 8, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(&last[1], sizes + n_groups - 1, 8, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    int rc = BL_OK;
+    if (e == hipSuccess) {
+        *n_kmers = last[0] + last[1];
+        if (*n_kmers > capacity || (!d_kmers && *n_kmers)) {
+            rc = bl_set_error(BL_ERR_CAPACITY, "expanded k-mers exceed the capacity of d_kmers (n_kmers holds the need)");
+        } else {
+            hipLaunchKernelGGL(expand_kernel, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const ulonglong2*>(d_records), offsets, (unsigned long long)n_groups,
+                               (int)k, (flags & BL_FLAG_CANONICAL) ? 1 : 0, reinterpret_cast<unsigned long long*>(d_kmers));
+            e = hipGetLastError();
+            if (e == hipSuccess) e = hipStreamSynchronize(s);
+        }
+    }
+    (void)hipFree(sizes);
+    if (tmp) (void)hipFree(tmp);
+    if (e != hipSuccess) return bl_set_error(e == hipErrorOutOfMemory ? BL_ERR_OOM : BL_ERR_HIP, hipGetErrorString(e));
+    return rc;
+}
+
+}  // extern "C"

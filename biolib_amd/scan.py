@@ -147,6 +147,35 @@ class Context:
         check(self._lib.bl_count_sorted_u64(self._h, C.c_void_p(keys.data_ptr()), n, C.c_void_p(uniq.data_ptr()), C.c_void_p(mult.data_ptr()), C.byref(runs)))
         return uniq[: runs.value], mult[: runs.value]
 
+    def partition_records(self, hashes, records, parts, n=None):
+        """(bucketed copy of the 16-byte records[:n], sizes[parts]): bucket b = records with hashes[i] % parts == b"""
+        import torch
+
+        n = records.shape[0] if n is None else int(n)
+        out = torch.empty((max(n, 1), 2), dtype=torch.int64, device=self.torch_device)
+        counts = (C.c_uint64 * int(parts))()
+        check(self._lib.bl_partition_records(self._h, C.c_void_p(hashes.data_ptr()), C.c_void_p(records.data_ptr()), n, int(parts), C.c_void_p(out.data_ptr()), counts))
+        return out[:n], [int(c) for c in counts]
+
+    def expand_super_kmers(self, records, k, canonical=True, n=None):
+        """the k-mers (device tensor) the packed super-k-mer records stand for, group after group"""
+        n = records.shape[0] if n is None else int(n)
+        need = C.c_uint64()
+        flags = FLAG_CANONICAL if canonical else 0
+        rc = self._lib.bl_expand_super_kmers(self._h, C.c_void_p(records.data_ptr()), n, int(k), flags, None, 0, C.byref(need))
+        if rc not in (0, capi.BL_ERR_CAPACITY):
+            check(rc)
+        out = self.empty_u64(need.value)
+        if need.value:
+            check(self._lib.bl_expand_super_kmers(self._h, C.c_void_p(records.data_ptr()), n, int(k), flags, C.c_void_p(out.data_ptr()), need.value, C.byref(need)))
+        return out[: need.value]
+
+    def probe_hbm(self, n_bytes=8 << 30, iters=5):
+        """(read GB/s, copy GB/s) sustained by this device: read-only stream kernel and DtoD copy"""
+        r, c = C.c_double(), C.c_double()
+        check(self._lib.bl_probe_hbm(self._h, int(n_bytes), int(iters), C.byref(r), C.byref(c)))
+        return r.value, c.value
+
     # ---- device arrays (torch plumbing)
     def empty_u64(self, n):
         import torch
@@ -299,6 +328,28 @@ class Batch:
         else:
             out.update(values=_host_u64(v, cnt), positions=_host_u64(p, cnt), hashes=_host_u64(h, cnt))
         return out
+
+    def super_kmer_records(self, k, m, seed=0, canonical=False, first=0, n=0):
+        """(records int64[n,2], minimizer hashes int64[n]) on the device: the packed super-k-mers of the range"""
+        import torch
+
+        span = self._span(first, n)
+        c = self.ctx
+
+        def run(cap):
+            fp, hs, sz = c.empty_u64(cap), c.empty_u64(cap), c.empty_u8(cap)
+            r = Result()
+            try:
+                self.super_kmers_raw(k, m, seed, _flags(canonical, False, True), first, n, None, fp, None, sz, hs, cap, r)
+            finally:
+                self._last_count = r.count
+            cnt = int(r.count)
+            recs = torch.empty((max(cnt, 1), 2), dtype=torch.int64, device=c.torch_device)
+            check(self._lib.bl_pack_super_kmers(c._h, self._h, C.c_void_p(fp.data_ptr()), C.c_void_p(sz.data_ptr()), cnt, int(k), int(m), C.c_void_p(recs.data_ptr())))
+            c.sync()
+            return recs[:cnt], hs[:cnt]
+
+        return self._with_capacity(int(span * 2.4 / (k - m + 2)) + 4096, run)
 
     def super_kmers(self, k, m, seed=0, canonical=False, first=0, n=0, capacity=None):
         span = self._span(first, n)

@@ -198,6 +198,24 @@ int bl_partition_u64(bl_ctx* ctx, const uint64_t* d_keys, uint64_t n, uint32_t p
 int bl_sort_u64(bl_ctx* ctx, uint64_t* d_keys, uint64_t n);
 int bl_count_sorted_u64(bl_ctx* ctx, const uint64_t* d_sorted, uint64_t n, uint64_t* d_unique, uint32_t* d_counts, uint64_t* n_unique);
 
+/* Super-k-mer bucket exchange (record of reference super_kmer_view.hpp:20-24 made self-contained).
+ * bl_pack_super_kmers: one 16-byte record per group of bl_scan_super_kmers — d_records[2g] = bases 0..31 of the group's
+ *   size + k - 1 bases (2 bits each, first base most significant), d_records[2g+1] = bases 32.. in bits 63..8, size in
+ *   bits 7..0.  Needs 2k - m <= 60.
+ * bl_partition_records: reorder 16-byte records into `parts` (<= 64) contiguous buckets by d_hashes[g] % parts (the
+ *   minimizer hash the scan returned = the owner rank); counts[b] (host) = records in bucket b.
+ * bl_expand_super_kmers: records -> their k-mers (canonical with BL_FLAG_CANONICAL), group after group;
+ *   BL_ERR_CAPACITY with *n_kmers = need when d_kmers is too small. */
+int bl_pack_super_kmers(bl_ctx* ctx, const bl_batch* batch, const uint64_t* d_first_pos, const uint8_t* d_sizes, uint64_t n_groups, uint32_t k,
+                        uint32_t m, uint64_t* d_records);
+int bl_partition_records(bl_ctx* ctx, const uint64_t* d_hashes, const uint64_t* d_records, uint64_t n, uint32_t parts, uint64_t* d_out, uint64_t* counts);
+int bl_expand_super_kmers(bl_ctx* ctx, const uint64_t* d_records, uint64_t n_groups, uint32_t k, uint32_t flags, uint64_t* d_kmers, uint64_t capacity,
+                          uint64_t* n_kmers);
+
+/* Measurement helper: sustained HBM rates of THIS device — a read-only streaming kernel over n_bytes and a
+ * device-to-device copy (read + write bytes counted), `iters` repetitions each; bench.py reports them next to the 8 TB/s spec. */
+int bl_probe_hbm(bl_ctx* ctx, uint64_t n_bytes, int iters, double* read_gbps, double* copy_gbps);
+
 /* Device-side parser: copy raw FASTA / FASTQ TEXT (already in host memory, e.g. a read()/mmap of the file) to the GPU
  * and build the batch there: newline index, line classification, prefix sums, gather of the sequence lines.  Same
  * sequences as bl_reader_* for the regular layouts it accepts — FASTQ with exactly 4 lines per record, FASTA with any

@@ -169,3 +169,93 @@ def test_exchange_and_count_single_rank_rccl(ctx):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def _np_pack(seq, fp, sz, k):
+    """numpy restatement of the 16-byte packed super-k-mer record"""
+    code = np.zeros(256, np.uint64)
+    for ch, c in zip(b"ACGTUacgtu", (0, 1, 2, 3, 3, 0, 1, 2, 3, 3)):
+        code[ch] = c
+    out = np.zeros((len(fp), 2), np.uint64)
+    for g, (p, s) in enumerate(zip(fp.tolist(), sz.tolist())):
+        nb = s + k - 1
+        c = code[seq[p:p + nb]]
+        hi = 0
+        for i in range(min(nb, 32)):
+            hi |= int(c[i]) << (62 - 2 * i)
+        lo = s
+        for i in range(32, nb):
+            lo |= int(c[i]) << (62 - 2 * (i - 32))
+        out[g] = (hi, lo)
+    return out
+
+
+@pytest.mark.parametrize("k,m,canon", [(31, 15, True), (31, 15, False), (32, 4, True), (21, 11, True), (5, 5, True), (16, 1, False)])
+def test_super_kmer_records_pack_and_expand(ctx, k, m, canon):
+    n, L = 120_000, 1500
+    seq = O.synth(31, n)
+    seq[np.random.default_rng(k).integers(0, n, 25)] = ord("N")
+    offs = O.fixed_offsets(n, L)
+    b = ctx.upload(seq, offs)
+    mn, fp, mp, sz, hs = O.super_kmers(seq, offs, k, m, 9, canon)
+    recs, hashes = b.super_kmer_records(k, m, seed=9, canonical=canon)
+    assert recs.shape[0] == len(mn) and np.array_equal(hashes.cpu().numpy().view(np.uint64), hs)
+    assert np.array_equal(recs.cpu().numpy().view(np.uint64), _np_pack(seq, fp, sz, k))
+    # expansion = the k-mers of each group, group after group = the oracle's units at first_pos .. first_pos+size-1
+    vals, ok = O.units(seq, offs, k, canon)
+    idx = np.concatenate([np.arange(p, p + s) for p, s in zip(fp.tolist(), sz.tolist())]) if len(fp) else np.zeros(0, np.int64)
+    assert np.all(ok[idx] != 0)
+    got = ctx.expand_super_kmers(recs, k, canonical=canon)
+    assert np.array_equal(got.cpu().numpy().view(np.uint64), vals[idx])
+    # routing: buckets are the records whose minimizer hash % parts == b
+    for parts in (1, 3, 8):
+        out, counts = ctx.partition_records(hashes, recs, parts)
+        got_r = out.cpu().numpy().view(np.uint64)
+        owner = hs % np.uint64(parts)
+        assert counts == np.bincount(owner.astype(np.int64), minlength=parts).tolist()
+        edges = np.concatenate([[0], np.cumsum(counts)])
+        exp = _np_pack(seq, fp, sz, k)
+        for bkt in range(parts):
+            a = got_r[edges[bkt]:edges[bkt + 1]]
+            e = exp[owner == bkt]
+            assert np.array_equal(a[np.lexsort((a[:, 1], a[:, 0]))], e[np.lexsort((e[:, 1], e[:, 0]))])
+
+
+def test_super_kmer_record_limits(ctx):
+    import biolib_amd as B
+
+    b = ctx.synth(1, 10_000, 100)
+    with pytest.raises(B.BiolibError):
+        b.super_kmer_records(32, 3)  # 2k - m = 61 bases do not fit a record
+
+
+def test_count_kmers_via_super_kmers_single_gpu(ctx):
+    """scan -> pack -> (route) -> expand -> sort -> count equals the multiset of canonical k-mers of the oracle;
+    with a world-1 RCCL group the all-to-all path runs too"""
+    import torch
+    import torch.distributed as dist
+
+    from biolib_amd.shard import count_kmers_via_super_kmers, exchange
+
+    n, L = 3_000_000, 150
+    b = ctx.synth(77, n, L)
+    seq = O.synth(77, n)
+    vals, ok = O.units(seq, O.fixed_offsets(n, L), 15, True)          # 4^15/2 canonical 15-mers over 2.7 M: repeats exist
+    eu, ec = np.unique(vals[ok != 0], return_counts=True)
+    u, c = count_kmers_via_super_kmers(ctx, b, 15, 9, seed=42, canonical=True)
+    assert np.array_equal(u.cpu().numpy().view(np.uint64), eu) and np.array_equal(c.cpu().numpy().astype(np.int64), ec) and ec.max() > 1
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29534")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        recs, hashes = b.super_kmer_records(15, 9, seed=42, canonical=True)
+        bucketed, counts = ctx.partition_records(hashes, recs, 1)
+        inbox = exchange(bucketed, counts)
+        assert inbox.shape == recs.shape
+        u2, c2 = ctx.sort_count(ctx.expand_super_kmers(inbox, 15, canonical=True))
+        assert torch.equal(u2, u) and torch.equal(c2, c)
+    finally:
+        if created:
+            dist.destroy_process_group()

@@ -140,3 +140,40 @@ def test_two_rank_exchange_and_count(tmp_path):
     gc = np.concatenate([p["c"] for p in parts])
     order = np.argsort(gu)
     assert np.array_equal(gu[order], u) and np.array_equal(gc[order], c) and c.max() > 1
+
+
+RECORD_WORKER = textwrap.dedent("""
+    import os, sys
+    sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+    import numpy as np, torch, torch.distributed as dist
+    from biolib_amd.shard import exchange
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    rng = np.random.default_rng(100 + rank)
+    n = 5000 + 777 * rank
+    recs = rng.integers(0, 2**62, (n, 2)).astype(np.int64)
+    recs[:, 1] = (recs[:, 1] & ~0xff) | rank                         # tag the source rank in the size byte
+    owner = (recs[:, 0].view(np.uint64) % np.uint64(world)).astype(np.int64)
+    order = np.argsort(owner, kind="stable")
+    inbox = exchange(torch.from_numpy(recs[order].copy()), np.bincount(owner, minlength=world).tolist()).numpy()
+    assert inbox.shape[1] == 2 and np.all(inbox[:, 0].view(np.uint64) % np.uint64(world) == rank)
+    np.save(os.path.join({out!r}, f"inbox{{rank}}.npy"), inbox)
+    np.save(os.path.join({out!r}, f"sent{{rank}}.npy"), recs)
+    dist.destroy_process_group()
+""")
+
+
+def test_two_rank_record_exchange(tmp_path):
+    script = tmp_path / "record_worker.py"
+    script.write_text(RECORD_WORKER.format(root=ROOT, out=str(tmp_path)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29521", str(script)], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    sent = np.concatenate([np.load(tmp_path / f"sent{r}.npy") for r in range(2)])
+    got = np.concatenate([np.load(tmp_path / f"inbox{r}.npy") for r in range(2)])
+    key = lambda a: a[np.lexsort((a[:, 1], a[:, 0]))]
+    assert np.array_equal(key(sent), key(got))                       # every record arrived exactly once
+    for r in range(2):                                               # grouped by source rank inside an inbox
+        src = np.load(tmp_path / f"inbox{r}.npy")[:, 1] & 0xff
+        assert np.all(np.diff(src) >= 0)
