@@ -78,7 +78,7 @@ __device__ __forceinline__ void count_tile(const ScanParams& p, TileShared<MODE,
     const int64_t q0 = p.origin + (int64_t)tile * p.stride;
     phase_load<MODE, W>(p, sh, tid, q0);
     {   // hand the packed codes to pass 2 (0.26 B/base instead of re-reading and re-encoding 1 B/base there)
-        const int needed = wave_chunk0(p, NWAVE - 1) + WCHUNK;
+        const int needed = staged_chunks(p);
         uint32_t* sc = p.slots_c + (size_t)tile * NCHUNK;
         if (tid < needed) sc[tid] = sh.codes[tid];  // own LDS entries: no barrier needed
         if (TPB + tid < needed) sc[TPB + tid] = sh.codes[TPB + tid];
@@ -131,7 +131,7 @@ __device__ __forceinline__ void emit_tile(const ScanParams& p, TileShared<MODE, 
     const size_t slot = (size_t)tile * p.stride;
     const unsigned long long cnt = p.tile_counts[tile];
     const unsigned long long base = p.tile_base[tile] + p.block_base[tile / SCAN_BLK];
-    const int needed = wave_chunk0(p, NWAVE - 1) + WCHUNK;
+    const int needed = staged_chunks(p);
     const uint32_t* sc = p.slots_c + (size_t)tile * NCHUNK;
     const uint32_t c0 = tid < needed ? sc[tid] : 0;
     const uint32_t c1 = TPB + tid < needed ? sc[TPB + tid] : 0;
@@ -168,7 +168,10 @@ __global__ __launch_bounds__(TPB, (MODE == MODE_SYNCMER || W == 0 ? 2 : (W <= 11
     __shared__ TileShared<MODE, W> sh;
     ScanParams p = pin;
     if (U != 0) p.unit = U;
-    if (W != 0) p.w = W;
+    if (W != 0) {
+        p.w = W;
+        p.stride = NWAVE * (64 * S - 16 * ((W + 15) / 16));  // plan_scan's value, as a constant
+    }
     if (C >= 0) p.canonical = C;
     if (blockIdx.x < g.count) count_tile<MODE, W>(p, sh, g.first + blockIdx.x, threadIdx.x);
 }

@@ -117,10 +117,23 @@ BL_DEV int64_t wave_origin(const ScanParams& p, int64_t q0, int wv) { return q0 
 // first staged chunk of wave `wv` inside the flat per-tile arrays
 BL_DEV int wave_chunk0(const ScanParams& p, int wv) { return wv * (p.stride / NWAVE / 16); }
 
+// Chunks of the flat per-tile arrays that hold data some OWNED window depends on: the last wave's lanes read codes up to
+// chunk lane+2 <= 65 and good/start bits up to position S + unit + w of their last owning lane.  For the three tuned
+// configurations this is <= TPB chunks, so one staging pass per thread suffices (the generic bound WCHUNK needs a
+// second pass that only 8 lanes of wave 0 use but the whole wave executes).  Entries beyond it keep stale LDS
+// contents; only lanes that own nothing look at them.
+BL_DEV int staged_chunks(const ScanParams& p)
+{
+    const int wchunks = p.stride / NWAVE / 16;
+    int per_wave = (wchunks - 1) + (S + p.unit + p.w) / 16 + 1;
+    per_wave = per_wave < 66 ? 66 : (per_wave > WCHUNK ? WCHUNK : per_wave);
+    return wave_chunk0(p, NWAVE - 1) + per_wave;  // <= NCHUNK
+}
+
 template <int MODE, int W>
 BL_DEV void phase_load(const ScanParams& p, TileShared<MODE, W>& sh, int tid, int64_t q0)
 {
-    const int needed = wave_chunk0(p, NWAVE - 1) + WCHUNK;  // <= NCHUNK; the last wave's halo ends the tile
+    const int needed = staged_chunks(p);
     if (tid < needed) stage_chunk(p, sh.codes, sh.flags, tid, q0);
     if (TPB + tid < needed) stage_chunk(p, sh.codes, sh.flags, TPB + tid, q0);  // a few lanes of wave 0 only
 }

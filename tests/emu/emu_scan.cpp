@@ -52,7 +52,7 @@ void run_tiles(ScanParams p, unsigned long long* result)
             std::memset(st.data(), 0x5A, st.size() * sizeof(ThreadState));
             const int64_t q0 = p.origin + (int64_t)tile * p.stride;
             for (int tid = 0; tid < TPB; ++tid) phase_load<MODE, W>(p, *sh, tid, q0);
-            for (int c = 0; c < wave_chunk0(p, NWAVE - 1) + WCHUNK; ++c) sc[tile * NCHUNK + c] = sh->codes[c];  // codes spill
+            for (int c = 0; c < staged_chunks(p); ++c) sc[tile * NCHUNK + c] = sh->codes[c];  // codes spill
             for (int tid = 0; tid < TPB; ++tid) phase_hash<MODE, W>(p, *sh, tid, st[tid]);
             if (MODE == MODE_SYNCMER) {
                 for (int tid = 0; tid < TPB; ++tid) phase_sync_fwd<MODE, W>(p, *sh, tid, st[tid], st.data(), &af[tid * (S + 1)]);
@@ -93,7 +93,7 @@ void run_tiles(ScanParams p, unsigned long long* result)
             if (n_s == 0 && n_e == 0) continue;
             std::memset(sh, 0xA5, sizeof(*sh));
             const int64_t q0 = p.origin + (int64_t)tile * p.stride;
-            for (int c = 0; c < wave_chunk0(p, NWAVE - 1) + WCHUNK; ++c) sh->codes[c] = sc[tile * NCHUNK + c];  // pass 2 reloads the codes
+            for (int c = 0; c < staged_chunks(p); ++c) sh->codes[c] = sc[tile * NCHUNK + c];  // pass 2 reloads the codes
             for (uint32_t r = 0; r < n_s; ++r) {
                 sh->list_a[r] = sa[tile * p.stride + r];
                 if (MODE == MODE_SUPERKMER) sh->list_j[r] = sj[tile * p.stride + r];
