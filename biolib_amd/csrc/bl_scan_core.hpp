@@ -190,37 +190,72 @@ BL_DEV uint64_t pairrev64(uint64_t x)
 // ------------------------------------------------------------------------------------------------
 // The rolling state of kmer_view.hpp:190-199 for one thread, started from packed codes instead of
 // a warm-up loop.  c0:c1:c2 are the codes of the thread's 48 bases (big-endian pairs).
+// Kept as explicit 32-bit halves: the 64-bit C++ forms of the two updates compile to 11 VALU instructions per
+// base on gfx950 (64-bit shifts, a redundant low mask), the halves below to 8 (v_bfe, v_lshl_or, 2 x v_alignbit,
+// v_and, v_lshrrev, shift + v_and_or) — 3 % of the whole scan.
 struct Roller {
-    uint64_t fwd, rc, mask;
-    uint32_t next16;  // the 16 bases following the first unit-1, big-endian
-    int shift;
+    uint32_t flo, fhi;   // forward unit, first base most significant (kmer_view.hpp:194)
+    uint32_t rlo, rhi;   // reverse complement (kmer_view.hpp:195)
+    uint32_t next16;     // the 16 bases following the first unit-1, big-endian pairs
+    uint32_t ncode;      // ~next16: the complements (3 ^ c) of those bases
+    int unit;
 };
+BL_DEV uint64_t roller_fwd(const Roller& r) { return ((uint64_t)r.fhi << 32) | r.flo; }
+BL_DEV uint64_t roller_rc(const Roller& r) { return ((uint64_t)r.rhi << 32) | r.rlo; }
+
+// low 32 bits of (hi:lo) >> n, 0 < n < 32: one v_alignbit_b32
+BL_DEV uint32_t funnel_shr(uint32_t hi, uint32_t lo, int n)
+{
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(BL_CPU_EMU)
+    return __builtin_amdgcn_alignbit(hi, lo, n);
+#else
+    return (uint32_t)((((uint64_t)hi << 32) | lo) >> n);
+#endif
+}
 
 BL_DEV void roller_start(Roller& r, uint32_t c0, uint32_t c1, uint32_t c2, int unit)
 {
     const uint64_t A = ((uint64_t)c0 << 32) | c1;  // bases 0..31
     const uint64_t B = ((uint64_t)c1 << 32) | c2;  // bases 16..47
     const int pre = unit - 1;                      // bases already inside the registers
-    r.mask = unit == 32 ? ~0ULL : ((1ULL << (2 * unit)) - 1);
-    r.shift = 2 * pre;
-    if (pre == 0) {
-        r.fwd = 0;
-        r.rc = 0;
-    } else {
-        r.fwd = A >> (64 - 2 * pre);
-        // reference state after `pre` bases: latest base at `shift`, older ones 2 bits lower each
-        uint64_t little = pairrev64(r.fwd) >> (64 - 2 * pre);        // base i at bit 2i
+    uint64_t fwd = 0, rc = 0;
+    if (pre != 0) {
+        fwd = A >> (64 - 2 * pre);
+        // reference state after `pre` bases: latest base at 2*(unit-1), older ones 2 bits lower each
+        uint64_t little = pairrev64(fwd) >> (64 - 2 * pre);          // base i at bit 2i
         little ^= (pre == 32) ? ~0ULL : ((1ULL << (2 * pre)) - 1);   // complement (3 ^ c)
-        r.rc = little << 2;
+        rc = little << 2;
     }
+    r.flo = (uint32_t)fwd;
+    r.fhi = (uint32_t)(fwd >> 32);
+    r.rlo = (uint32_t)rc;
+    r.rhi = (uint32_t)(rc >> 32);
     r.next16 = pre < 16 ? (uint32_t)((A << (2 * pre)) >> 32) : (uint32_t)((B << (2 * (pre - 16))) >> 32);
+    r.ncode = ~r.next16;
+    r.unit = unit;
 }
 
 BL_DEV void roller_step(Roller& r, int s)  // s = 0..15, compile-time after unrolling
 {
-    const uint64_t c = (r.next16 >> (30 - 2 * s)) & 3u;
-    r.fwd = ((r.fwd << 2) | c) & r.mask;                 // kmer_view.hpp:194
-    r.rc = (r.rc >> 2) | ((3ULL ^ c) << r.shift);        // kmer_view.hpp:195
+    const int at = 30 - 2 * s;                       // bit position of base s inside next16 / ncode
+    const uint32_t c = (r.next16 >> at) & 3u;
+    const int top = 2 * (r.unit - 1);                // where the complement of the new base enters rc
+    if (r.unit > 16) {
+        // fwd = ((fwd << 2) | c) & mask
+        const uint32_t nhi = funnel_shr(r.fhi, r.flo, 30);
+        r.flo = (r.flo << 2) | c;
+        r.fhi = r.unit == 32 ? nhi : (nhi & ((1u << (2 * r.unit - 32)) - 1u));
+        // rc = (rc >> 2) | ((3 ^ c) << top)
+        const int t = top - 32;
+        const uint32_t x = t >= at ? (r.ncode << (t - at)) : (r.ncode >> (at - t));
+        r.rlo = funnel_shr(r.rhi, r.rlo, 2);
+        r.rhi = (x & (3u << t)) | (r.rhi >> 2);
+    } else {
+        const uint32_t m = r.unit == 16 ? ~0u : ((1u << (2 * r.unit)) - 1u);
+        r.flo = ((r.flo << 2) | c) & m;
+        const uint32_t x = top >= at ? (r.ncode << (top - at)) : (r.ncode >> (at - top));
+        r.rlo = (x & (3u << top)) | (r.rlo >> 2);
+    }
 }
 
 // unit starting at tile-relative base `pos`, straight from the staged codes (used when a record is

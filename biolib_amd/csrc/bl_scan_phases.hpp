@@ -172,16 +172,17 @@ BL_DEV void phase_hash(const ScanParams& p, TileShared<MODE, W>& sh, int tid, Th
         for (int s = 0; s < S; ++s) {
             roller_step(r, s);
             roller_step(rk, s);
-            st.h[s] = murmur64(r.fwd, p.seed);
-            st.h2[s] = murmur64(r.rc, p.seed);
-            if (p.canonical && rk.rc < rk.fwd) strand |= 1u << s;  // kmer_view.hpp:196
+            st.h[s] = murmur64(roller_fwd(r), p.seed);
+            st.h2[s] = murmur64(roller_rc(r), p.seed);
+            if (p.canonical && roller_rc(rk) < roller_fwd(rk)) strand |= 1u << s;  // kmer_view.hpp:196
         }
         st.strand = strand;
     } else {
         BL_UNROLL
         for (int s = 0; s < S; ++s) {
             roller_step(r, s);
-            const uint64_t v = (p.canonical && r.rc < r.fwd) ? r.rc : r.fwd;  // minimizer_view.hpp:236-238
+            const uint64_t fw = roller_fwd(r), rv = roller_rc(r);
+            const uint64_t v = (p.canonical && rv < fw) ? rv : fw;  // minimizer_view.hpp:236-238
             st.h[s] = murmur64(v, p.seed);
         }
     }
@@ -568,7 +569,8 @@ BL_DEV void kmer_thread(const KmerParams& p, const uint32_t* codes, const uint32
     BL_UNROLL
     for (int s = 0; s < S; ++s) {
         roller_step(r, s);
-        const uint64_t v = (p.canonical && r.rc < r.fwd) ? r.rc : r.fwd;
+        const uint64_t fw = roller_fwd(r), rv = roller_rc(r);
+        const uint64_t v = (p.canonical && rv < fw) ? rv : fw;
         const uint64_t h = murmur64(v, p.seed);
         const int64_t j = j0 + s;
         bool ok = ((valid >> s) & 1) && j >= p.first && j < p.end;
