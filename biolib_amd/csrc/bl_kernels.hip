@@ -91,7 +91,7 @@ __device__ __forceinline__ void count_tile(const ScanParams& p, TileShared<MODE,
 
     uint32_t packed;
     if (MODE == MODE_SYNCMER) {
-        uint8_t af[S + 1];
+        uint32_t af[S + 1];
         phase_sync_fwd<MODE, W>(p, sh, tid, st, nullptr, af);
         if (W == 0 && p.canonical) {
             __syncthreads();
@@ -489,3 +489,13 @@ hipError_t launch_start_bits_offsets(uint32_t* bits, const uint64_t* offsets, ui
 }
 
 }  // namespace bl
+
+#ifdef BL_EXPERIMENT_COUNT_FALLBACK
+extern "C" unsigned long long bl_dbg_read_fallbacks()
+{
+    unsigned long long v = 0;
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(&v, HIP_SYMBOL(bl::bl_dbg_fallbacks), sizeof(v));
+    return v;
+}
+#endif

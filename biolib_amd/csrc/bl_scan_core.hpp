@@ -192,12 +192,11 @@ BL_DEV uint64_t pairrev64(uint64_t x)
 // a warm-up loop.  c0:c1:c2 are the codes of the thread's 48 bases (big-endian pairs).
 // Kept as explicit 32-bit halves: the 64-bit C++ forms of the two updates compile to 11 VALU instructions per
 // base on gfx950 (64-bit shifts, a redundant low mask), the halves below to 8 (v_bfe, v_lshl_or, 2 x v_alignbit,
-// v_and, v_lshrrev, shift + v_and_or) — 3 % of the whole scan.
+// v_and, v_lshrrev, v_xor, v_lshl_or) — 3 % of the whole scan.
 struct Roller {
     uint32_t flo, fhi;   // forward unit, first base most significant (kmer_view.hpp:194)
     uint32_t rlo, rhi;   // reverse complement (kmer_view.hpp:195)
     uint32_t next16;     // the 16 bases following the first unit-1, big-endian pairs
-    uint32_t ncode;      // ~next16: the complements (3 ^ c) of those bases
     int unit;
 };
 BL_DEV uint64_t roller_fwd(const Roller& r) { return ((uint64_t)r.fhi << 32) | r.flo; }
@@ -231,13 +230,12 @@ BL_DEV void roller_start(Roller& r, uint32_t c0, uint32_t c1, uint32_t c2, int u
     r.rlo = (uint32_t)rc;
     r.rhi = (uint32_t)(rc >> 32);
     r.next16 = pre < 16 ? (uint32_t)((A << (2 * pre)) >> 32) : (uint32_t)((B << (2 * (pre - 16))) >> 32);
-    r.ncode = ~r.next16;
     r.unit = unit;
 }
 
 BL_DEV void roller_step(Roller& r, int s)  // s = 0..15, compile-time after unrolling
 {
-    const int at = 30 - 2 * s;                       // bit position of base s inside next16 / ncode
+    const int at = 30 - 2 * s;                       // bit position of base s inside next16
     const uint32_t c = (r.next16 >> at) & 3u;
     const int top = 2 * (r.unit - 1);                // where the complement of the new base enters rc
     if (r.unit > 16) {
@@ -246,15 +244,12 @@ BL_DEV void roller_step(Roller& r, int s)  // s = 0..15, compile-time after unro
         r.flo = (r.flo << 2) | c;
         r.fhi = r.unit == 32 ? nhi : (nhi & ((1u << (2 * r.unit - 32)) - 1u));
         // rc = (rc >> 2) | ((3 ^ c) << top)
-        const int t = top - 32;
-        const uint32_t x = t >= at ? (r.ncode << (t - at)) : (r.ncode >> (at - t));
         r.rlo = funnel_shr(r.rhi, r.rlo, 2);
-        r.rhi = (x & (3u << t)) | (r.rhi >> 2);
+        r.rhi = ((c ^ 3u) << (top - 32)) | (r.rhi >> 2);
     } else {
         const uint32_t m = r.unit == 16 ? ~0u : ((1u << (2 * r.unit)) - 1u);
         r.flo = ((r.flo << 2) | c) & m;
-        const uint32_t x = top >= at ? (r.ncode << (top - at)) : (r.ncode >> (at - top));
-        r.rlo = (x & (3u << top)) | (r.rlo >> 2);
+        r.rlo = ((c ^ 3u) << top) | (r.rlo >> 2);
     }
 }
 
@@ -341,42 +336,88 @@ BL_DEV uint32_t window_valid_mask(Bits128 good, Bits128 start, int span)
 // LEFT = true : leftmost minimum wins ties (minimizer_view.hpp:283,374)
 // LEFT = false: rightmost minimum wins ties (reverse-strand syncmers)
 template <int NW, int W, bool LEFT>
-BL_DEV void window_argmin(const uint64_t* e, uint8_t* a)
+BL_DEV void window_argmin(const uint64_t* e, uint32_t* a)
 {
     BL_UNROLL
     for (int base = 0; base < NW; base += W) {
         // suffix minima of block e[base .. base+W-1], right to left
         uint64_t sv[W];
-        uint8_t si[W];
+        uint32_t si[W];
         sv[W - 1] = e[base + W - 1];
-        si[W - 1] = (uint8_t)(base + W - 1);
+        si[W - 1] = (uint32_t)(base + W - 1);
         BL_UNROLL
         for (int i = W - 2; i >= 0; --i) {
             const uint64_t x = e[base + i];
             const bool take = LEFT ? (x <= sv[i + 1]) : (x < sv[i + 1]);
             sv[i] = take ? x : sv[i + 1];
-            si[i] = take ? (uint8_t)(base + i) : si[i + 1];
+            si[i] = take ? (uint32_t)(base + i) : si[i + 1];
         }
         a[base] = si[0];
         // prefix minima of the following block, combined on the fly
         uint64_t pv = 0;
-        uint8_t pi = 0;
+        uint32_t pi = 0;
         BL_UNROLL
         for (int i = 1; i < W; ++i) {
             if (base + i >= NW) break;
             const uint64_t x = e[base + W - 1 + i];
             if (i == 1) {
                 pv = x;
-                pi = (uint8_t)(base + W);
+                pi = (uint32_t)(base + W);
             } else {
                 const bool take = LEFT ? (x < pv) : (x <= pv);
                 pv = take ? x : pv;
-                pi = take ? (uint8_t)(base + W - 1 + i) : pi;
+                pi = take ? (uint32_t)(base + W - 1 + i) : pi;
             }
             const bool right = LEFT ? (pv < sv[i]) : (pv <= sv[i]);
             a[base + i] = right ? pi : si[i];
         }
     }
 }
+
+
+// Fast form of the same argmin on 32-bit PACKED keys: key[x] = (top 26 bits of the hash) << 6 | tag, tag = x for
+// LEFT (smaller tag wins a tie of the prefix = leftmost) and 63 - x otherwise.  One v_min_u32 per step gives value
+// and position at once (the 64-bit form costs a compare, two value selects, and a re-compare + select for the
+// index).  It is exact unless two operands of some step agree in their 26-bit prefix; every step therefore also
+// folds (a ^ b) into a running minimum, and the caller re-runs the 64-bit form when that minimum is below 64
+// (probability ~1e-6 per window on random hashes; certain on repeats, which is why the exact form stays).
+// Returns the minimum xor distance seen.  NW + W - 1 <= 64 elements.
+template <int NW, int W, bool LEFT>
+BL_DEV uint32_t window_argmin_packed(const uint32_t* key, uint32_t* a)
+{
+    uint32_t dmin = ~0u;
+    BL_UNROLL
+    for (int base = 0; base < NW; base += W) {
+        uint32_t sv[W];
+        sv[W - 1] = key[base + W - 1];
+        BL_UNROLL
+        for (int i = W - 2; i >= 0; --i) {
+            const uint32_t x = key[base + i], d = x ^ sv[i + 1];
+            sv[i] = x < sv[i + 1] ? x : sv[i + 1];
+            dmin = d < dmin ? d : dmin;
+        }
+        a[base] = LEFT ? (sv[0] & 63u) : 63u - (sv[0] & 63u);
+        uint32_t pv = 0;
+        BL_UNROLL
+        for (int i = 1; i < W; ++i) {
+            if (base + i >= NW) break;
+            const uint32_t x = key[base + W - 1 + i];
+            if (i == 1) {
+                pv = x;
+            } else {
+                const uint32_t d = x ^ pv;
+                pv = x < pv ? x : pv;
+                dmin = d < dmin ? d : dmin;
+            }
+            const uint32_t d2 = pv ^ sv[i];
+            const uint32_t r = pv < sv[i] ? pv : sv[i];
+            dmin = d2 < dmin ? d2 : dmin;
+            a[base + i] = LEFT ? (r & 63u) : 63u - (r & 63u);
+        }
+    }
+    return dmin;
+}
+
+BL_DEV uint32_t packed_key(uint32_t hash_hi, int x, bool left) { return (hash_hi & ~63u) | (uint32_t)(left ? x : 63 - x); }
 
 }  // namespace bl

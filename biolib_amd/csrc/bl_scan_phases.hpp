@@ -257,6 +257,73 @@ BL_DEV void gather_halo(const ThreadState* all, int tid, const ThreadState& st, 
 #endif
 }
 
+// High dwords only (the packed-key argmin needs nothing else): one DPP move per element instead of two.
+template <int NE, bool SECOND>
+BL_DEV void gather_halo_hi(const ThreadState* all, int tid, const ThreadState& st, uint32_t* e)
+{
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(BL_CPU_EMU)
+    (void)all;
+    (void)tid;
+    uint32_t cur[S];
+    BL_UNROLL
+    for (int x = 0; x < S; ++x) cur[x] = (uint32_t)((SECOND ? st.h2[x] : st.h[x]) >> 32);
+    BL_UNROLL
+    for (int hop = 0; hop < (NE + S - 1) / S; ++hop) {
+        BL_UNROLL
+        for (int x = 0; x < S; ++x) {
+            if (hop * S + x < NE || (hop + 1) * S + x < NE || (hop + 2) * S + x < NE || (hop + 3) * S + x < NE)
+                cur[x] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cur[x], 0x130, 0xf, 0xf, false);
+            if (hop * S + x < NE) e[(hop + 1) * S + x] = cur[x];
+        }
+    }
+#else
+    const int lane = tid & 63;
+    for (int x = 0; x < NE; ++x) {
+        const int nb = lane + 1 + (x >> 4);
+        e[S + x] = nb < 64 ? (uint32_t)((SECOND ? all[tid + 1 + (x >> 4)].h2[x & 15] : all[tid + 1 + (x >> 4)].h[x & 15]) >> 32) : 0xDEADBEEFu;
+    }
+    (void)st;
+#endif
+}
+
+// true in every lane of the wave if the predicate holds in any of them (the emulation decides per thread, which
+// gives the same results: the exact form agrees with the packed form wherever the packed form is valid)
+BL_DEV bool wave_any(bool pred)
+{
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(BL_CPU_EMU)
+    return __builtin_amdgcn_ballot_w64(pred) != 0;
+#else
+    return pred;
+#endif
+}
+
+#ifdef BL_EXPERIMENT_COUNT_FALLBACK
+__device__ unsigned long long bl_dbg_fallbacks;
+#endif
+// Window argmins of one lane: packed 32-bit keys first, the exact 64-bit form when a prefix tie was seen anywhere
+// in the wave among lanes that own windows.
+template <int NW, int W, bool LEFT, bool SECOND>
+BL_DEV void lane_window_argmin(const ThreadState* all, int tid, const ThreadState& st, bool owns, uint32_t* a)
+{
+    uint32_t key[S + W];
+    BL_UNROLL
+    for (int s = 0; s < S; ++s) key[s] = (uint32_t)((SECOND ? st.h2[s] : st.h[s]) >> 32);
+    gather_halo_hi<W, SECOND>(all, tid, st, key);
+    BL_UNROLL
+    for (int x = 0; x < NW + W - 1; ++x) key[x] = packed_key(key[x], x, LEFT);
+    const uint32_t dmin = window_argmin_packed<NW, W, LEFT>(key, a);
+    if (wave_any(owns && dmin < 64u)) {
+#ifdef BL_EXPERIMENT_COUNT_FALLBACK
+        if ((tid & 63) == 0) atomicAdd(&bl_dbg_fallbacks, 1ull);
+#endif
+        uint64_t e[S + W];
+        BL_UNROLL
+        for (int s = 0; s < S; ++s) e[s] = SECOND ? st.h2[s] : st.h[s];
+        gather_halo<W, SECOND>(all, tid, st, e);
+        window_argmin<NW, W, LEFT>(e, a);
+    }
+}
+
 // bit s set <=> lo <= s < hi, for s in 0..S
 BL_DEV uint32_t range_mask(int64_t lo, int64_t hi)
 {
@@ -267,7 +334,7 @@ BL_DEV uint32_t range_mask(int64_t lo, int64_t hi)
 
 // runtime-w fallback: argmin by direct scan of the LDS hashes (slow path for unlisted window sizes)
 template <int MODE, int W, bool LEFT>
-BL_DEV void window_argmin_lds(const TileShared<MODE, W>& sh, int tid, int w, int nw, uint8_t* a)
+BL_DEV void window_argmin_lds(const TileShared<MODE, W>& sh, int tid, int w, int nw, uint32_t* a)
 {
     const int wbase = tid & ~63;  // first thread of this wave
     for (int i = 0; i < nw; ++i) {
@@ -280,7 +347,7 @@ BL_DEV void window_argmin_lds(const TileShared<MODE, W>& sh, int tid, int w, int
             const bool take = x == 0 || (LEFT ? v < best : v <= best);
             if (take) { best = v; arg = i + x; }
         }
-        a[i] = (uint8_t)arg;
+        a[i] = (uint32_t)arg;
     }
 }
 
@@ -300,15 +367,18 @@ BL_DEV uint32_t phase_window(const ScanParams& p, const TileShared<MODE, W>& sh,
 {
     const int wv = tid >> 6, lane = tid & 63;
     const int w = W ? W : p.w;
-    uint8_t a[S + 1];
+    uint32_t a[S + 1];
     uint32_t below = 0x1ffffu;  // w = 1 with a hash threshold (hash_sampler): bit s = hash of unit s is below it
-    if (W) {
-        uint64_t e[S + (W ? W : 1)];
+    if (W > 1) {
+        lane_window_argmin<S + 1, (W > 1 ? W : 2), true, false>(all, tid, st, owned_mask(p, tid & 63) != 0, a);
+    } else if (W == 1) {
+        uint64_t e[S + 1];
         BL_UNROLL
         for (int s = 0; s < S; ++s) e[s] = st.h[s];
-        gather_halo<(W ? W : 1), false>(all, tid, st, e);
-        window_argmin<S + 1, (W ? W : 1), true>(e, a);
-        if (W == 1 && p.use_threshold) {
+        gather_halo<1, false>(all, tid, st, e);
+        BL_UNROLL
+        for (int s = 0; s <= S; ++s) a[s] = (uint32_t)s;
+        if (p.use_threshold) {
             below = 0;
             BL_UNROLL
             for (int s = 0; s <= S; ++s)
@@ -353,14 +423,13 @@ BL_DEV uint32_t phase_window(const ScanParams& p, const TileShared<MODE, W>& sh,
 // `pass` is only used by the runtime-w fallback, which republishes the LDS hashes between the two.
 template <int MODE, int W>
 BL_DEV void phase_sync_fwd(const ScanParams& p, const TileShared<MODE, W>& sh, int tid, ThreadState& st, const ThreadState* all,
-                           uint8_t* af)
+                           uint32_t* af)
 {
-    if (W) {
-        uint64_t e[S + (W ? W : 1)];
+    if (W > 1) {
+        lane_window_argmin<S, (W > 1 ? W : 2), true, false>(all, tid, st, owned_mask(p, tid & 63) != 0, af);
+    } else if (W == 1) {
         BL_UNROLL
-        for (int s = 0; s < S; ++s) e[s] = st.h[s];
-        gather_halo<(W ? W : 1), false>(all, tid, st, e);
-        window_argmin<S, (W ? W : 1), true>(e, af);
+        for (int s = 0; s < S; ++s) af[s] = (uint32_t)s;
     } else {
         window_argmin_lds<MODE, W, true>(sh, tid, p.w, S, af);
     }
@@ -368,19 +437,18 @@ BL_DEV void phase_sync_fwd(const ScanParams& p, const TileShared<MODE, W>& sh, i
 
 template <int MODE, int W>
 BL_DEV uint32_t phase_sync_rev(const ScanParams& p, const TileShared<MODE, W>& sh, int tid, int64_t q0, ThreadState& st,
-                               const ThreadState* all, const uint8_t* af)
+                               const ThreadState* all, const uint32_t* af)
 {
     const int wv = tid >> 6, lane = tid & 63;
     const int w = W ? W : p.w;
     const int k = p.unit + w - 1;
-    uint8_t ar[S + 1];
+    uint32_t ar[S + 1];
     if (p.canonical) {
-        if (W) {
-            uint64_t e[S + (W ? W : 1)];
+        if (W > 1) {
+            lane_window_argmin<S, (W > 1 ? W : 2), false, true>(all, tid, st, owned_mask(p, tid & 63) != 0, ar);
+        } else if (W == 1) {
             BL_UNROLL
-            for (int s = 0; s < S; ++s) e[s] = st.h2[s];
-            gather_halo<(W ? W : 1), true>(all, tid, st, e);
-            window_argmin<S, (W ? W : 1), false>(e, ar);
+            for (int s = 0; s < S; ++s) ar[s] = (uint32_t)s;
         } else {
             window_argmin_lds<MODE, W, false>(sh, tid, w, S, ar);
         }

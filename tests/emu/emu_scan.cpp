@@ -46,7 +46,7 @@ void run_tiles(ScanParams p, unsigned long long* result)
         auto* sh = new TileShared<MODE, W>();
         std::vector<ThreadState> st(TPB);
         std::vector<uint32_t> packed(TPB), excl(TPB);
-        std::vector<uint8_t> af(TPB * (S + 1));
+        std::vector<uint32_t> af(TPB * (S + 1));
         for (size_t tile = 0; tile < nt; ++tile) {
             std::memset(sh, 0xA5, sizeof(*sh));  // poison: nothing may depend on stale LDS contents
             std::memset(st.data(), 0x5A, st.size() * sizeof(ThreadState));

@@ -132,6 +132,11 @@ def _random_case(rng, n, flavour):
         for p in rng.integers(0, max(n, 1), n // 300 + 1):
             if n:
                 seq[p] = ord("ACGT"[int(rng.integers(4))])
+    if flavour == "mixed_repeats" and n:  # random sequence with tandem-repeat islands: some waves hit hash ties, most do not
+        for p in rng.integers(0, n, n // 2000 + 2):
+            motif = np.frombuffer([b"A", b"CA", b"TTG", b"ACGTACGA", b"GATTACAGATTACC"][int(rng.integers(5))], np.uint8)
+            ln = min(int(rng.integers(20, 3000)), n - int(p))
+            seq[p:p + ln] = np.resize(motif, ln)
     if flavour in ("breaks", "ragged_breaks") and n:
         for p in rng.integers(0, n, n // 150 + 1):
             seq[p] = ord("NnRY-"[int(rng.integers(5))])
@@ -148,7 +153,7 @@ def _random_case(rng, n, flavour):
     return seq, offs
 
 
-@pytest.mark.parametrize("flavour", ["plain", "breaks", "ragged", "ragged_breaks", "reads", "lowcomplexity", "case"])
+@pytest.mark.parametrize("flavour", ["plain", "breaks", "ragged", "ragged_breaks", "reads", "lowcomplexity", "mixed_repeats", "case"])
 def test_all_scans_vs_oracle_random(ctx, flavour):
     import zlib
     rng = np.random.default_rng(zlib.crc32(flavour.encode()))
