@@ -37,6 +37,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--gbp", type=float, default=50.0, help="Gbp per GPU (BASELINE config: 50)")
     ap.add_argument("--chunk-reads", type=int, default=10_000_000, help="reads per scan range (<= 2^31 bases)")
+    ap.add_argument("--lanes", type=int, default=2, choices=(1, 2),
+                    help="execution lanes of the context: 2 = the record pass of one range runs beside the hashing pass of the next")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -68,7 +70,7 @@ def main():
 
     dev = local_rank if (world > 1 and not rehearse) else 0
     torch.cuda.set_device(dev)
-    ctx = biolib_amd.Context(dev, torch_stream=False)  # own streams: consecutive scans alternate between two lanes and overlap
+    ctx = biolib_amd.Context(dev, torch_stream=False, lanes=args.lanes)  # own streams; outputs below are double-buffered
 
     n_reads = int(args.gbp * 1e9) // READ_LEN
     n_bases = n_reads * READ_LEN
@@ -158,11 +160,15 @@ def main():
                 # second ceiling: VALU issue.  A wave64 instruction occupies a SIMD16 for 4 cycles, so the
                 # nominal peak is CUs x 4 SIMDs x clock / 4 wave-instructions per second (some simple ops retire faster,
                 # which is how the fraction can pass 1).
-                winstr = prof["valu_wave_instr_per_base"] * bases_per_launch
+                per_base = prof["valu_wave_instr_per_base"]
+                if args.lanes == 2:  # the record pass of the previous range shares the SIMDs with this kernel: count its instructions too
+                    per_base += prof.get("emit_valu_wave_instr_per_base", 0.0)
+                winstr = per_base * bases_per_launch
                 peak_winstr = N_CU * 4 * CLOCK_HZ / 4.0
                 valu = {"wave_instr_per_launch": int(winstr), "achieved_Ginstr_s": round(winstr / avg_kernel_s / 1e9, 1),
                         "peak_Ginstr_s": round(peak_winstr / 1e9, 1), "frac": round(winstr / avg_kernel_s / peak_winstr, 3),
-                        "lane_instr_per_base": round(prof["valu_wave_instr_per_base"] * 64, 1),
+                        "lane_instr_per_base": round(per_base * 64, 1),
+                        "kernels": "scan_count + co-running scan_emit" if args.lanes == 2 else "scan_count",
                         "source": "SQ_INSTS_VALU, profiles/r01_pmc_summary.txt; 256 CUs x 4 SIMD16 at 2.4 GHz"}
             except Exception:
                 traffic = None
@@ -182,7 +188,7 @@ def main():
             "config": {
                 "workload": f"minimizer_view k=31 w=11 (canonical 31-mer units, window 11, seed 42) over {args.gbp:g} Gbp of 150 bp short reads per GPU",
                 "bases_per_gpu": n_bases, "read_len": READ_LEN, "reads_per_gpu": n_reads, "ranges_per_step": len(ranges),
-                "bases_per_launch": int(bases_per_launch), "outputs": "value,position,hash (u64 each) materialised in HBM",
+                "bases_per_launch": int(bases_per_launch), "outputs": "value,position,hash (u64 each) materialised in HBM", "lanes": args.lanes,
                 "sharding": f"{n_gpus} independent shard(s), seed 42+rank",
             },
             "records_per_step": total_count,
@@ -191,7 +197,9 @@ def main():
                 "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5),
                 "traffic": traffic, "kernel": "bl::scan_count_kernel<MODE_MINIMIZER,W=11,U=31,C=1> (pass 1 of 2)", "avg_kernel_ms": round(avg_kernel_s * 1e3, 4),
                 "launches_timed": launches, "algorithmic_bytes_per_launch": int(bases_per_launch),
-                "note": "integer-ALU bound before HBM: 6 x 64-bit multiplies per base (MurmurHash3_x64_128), see DESIGN.md",
+                "note": "integer-ALU bound before HBM: 6 x 64-bit multiplies per base (MurmurHash3_x64_128), see DESIGN.md"
+                        + ("; with 2 lanes this kernel's duration includes sharing the SIMDs with the previous range's scan_emit_kernel "
+                           "(alone: --lanes 1, profiles/r01_bench_1gpu_lanes1.json)" if args.lanes == 2 else ""),
             },
         }
         if rehearse:

@@ -57,10 +57,12 @@ struct Pending {
 
 }  // namespace
 
-// One execution lane: a stream plus the scratch its scans use.  With BL_LANES=2 and the context's own
-// streams, consecutive asynchronous scans alternate between two lanes so that the record pass of one
-// scan can overlap the hashing pass of the next; measured on MI355X this gains nothing (both passes
-// are issue-bound), so the default is one lane.  A borrowed caller stream always uses lane 0.
+// One execution lane: a stream plus the scratch its scans use.  With two lanes (bl_ctx_set_lanes / BL_LANES=2) and the
+// context's own streams, consecutive asynchronous scans alternate between the lanes and are staggered by an event: a
+// scan's pass 1 starts when the previous scan's pass 1 has finished, i.e. beside that scan's pass 2.  Pass 1 is bound by
+// VALU issue and leaves HBM idle, pass 2 is bound by HBM writes: together they run at the VALU rate of their combined
+// instruction count (measured on MI355X: 328 -> 345 Gbp/s on the C3 workload).  Consecutive scans then run concurrently,
+// so they must not share output arrays.  Default: one lane.  A borrowed caller stream always uses lane 0.
 struct Lane {
     hipStream_t own = nullptr;
     unsigned char* ws = nullptr;  // [hdr 256 B][shards][result]
@@ -72,6 +74,8 @@ struct Lane {
     uint64_t* last_buf = nullptr;  // super-k-mer scratch
     size_t last_cap = 0;
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    hipEvent_t ev_count_done = nullptr;  // two-lane mode: recorded after this lane's pass-1 kernel
+    bool count_recorded = false;
 
     unsigned long long* shards() const { return reinterpret_cast<unsigned long long*>(ws + HDR_BYTES); }
     unsigned long long* result() const { return reinterpret_cast<unsigned long long*>(ws + HDR_BYTES + SHARD_BYTES); }
@@ -82,7 +86,8 @@ struct bl_ctx {
     Lane lanes[2];
     Lane* cur = nullptr;               // lane of the scan being issued / issued last
     int next_lane = 0;
-    int n_lanes = 1;                   // 2 (env BL_LANES=2): consecutive async scans alternate lanes (measured: no gain)
+    int n_lanes = 1;                   // 2: consecutive async scans alternate lanes, staggered (bl_ctx_set_lanes, env BL_LANES)
+    uint32_t emit_lds_per_wg = 25600;  // two-lane mode: LDS footprint pass-2 workgroups are padded to (caps their residency per CU)
     hipStream_t user_stream = nullptr; // borrowed (bl_ctx_set_stream)
     hipStream_t stream = nullptr;      // stream of `cur`
     unsigned long long* pinned = nullptr;  // RING * RESULT_WORDS
@@ -333,6 +338,7 @@ int bl_ctx_create(int device, bl_ctx** out)
     for (Lane& l : c->lanes) {
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&l.own, hipStreamNonBlocking);
         if (e == hipSuccess) e = hipEventCreate(&l.ev_start);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&l.ev_count_done, hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreate(&l.ev_stop);
     }
     if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&c->pinned), (size_t)RING * RESULT_WORDS * sizeof(unsigned long long), hipHostMallocDefault);
@@ -349,7 +355,20 @@ int bl_ctx_create(int device, bl_ctx** out)
     c->cur = &c->lanes[0];
     c->stream = c->lanes[0].own;
     if (const char* e = std::getenv("BL_LANES")) c->n_lanes = std::atoi(e) == 2 ? 2 : 1;
+    if (const char* e = std::getenv("BL_EMIT_LDS")) c->emit_lds_per_wg = (uint32_t)std::atoi(e);
     *out = c;
+    return BL_OK;
+}
+
+// 1 or 2 execution lanes for contexts that run on their own streams (see Lane above); takes effect from the next scan
+int bl_ctx_set_lanes(bl_ctx* c, int n)
+{
+    if (!c || (n != 1 && n != 2)) return fail(BL_ERR_INVALID, "bl_ctx_set_lanes: need a context and n = 1 or 2");
+    int rc = sync_ctx(c);
+    if (rc != BL_OK) return rc;
+    c->n_lanes = n;
+    c->next_lane = 0;
+    c->lanes[0].count_recorded = c->lanes[1].count_recorded = false;
     return BL_OK;
 }
 
@@ -367,6 +386,7 @@ int bl_ctx_destroy(bl_ctx* c)
         if (l.slot_buf) (void)hipFree(l.slot_buf);
         if (l.last_buf) (void)hipFree(l.last_buf);
         if (l.ev_start) (void)hipEventDestroy(l.ev_start);
+        if (l.ev_count_done) (void)hipEventDestroy(l.ev_count_done);
         if (l.ev_stop) (void)hipEventDestroy(l.ev_stop);
         if (l.own) (void)hipStreamDestroy(l.own);
     }
@@ -640,15 +660,26 @@ static int scan_windows(int mode, bl_ctx* c, const bl_batch* b, uint64_t first, 
     // groups with a running carry; one group is what is used)
     const bl::GroupRange all{0, (uint32_t)p.n_tiles};
     unsigned long long* carry = reinterpret_cast<unsigned long long*>(c->cur->ws);  // header word, zeroed by begin_scan
+    const bool staggered = c->n_lanes == 2 && !c->user_stream;
+    if (staggered) {
+        // two lanes: this scan's pass 1 starts when the other lane's pass 1 has finished, so that it runs beside the
+        // other lane's pass 2 (HBM-write bound) instead of beside its pass 1 (both ALU bound: nothing to gain)
+        Lane* other = c->cur == &c->lanes[0] ? &c->lanes[1] : &c->lanes[0];
+        if (other->count_recorded) BL_HIP(hipStreamWaitEvent(c->stream, other->ev_count_done, 0));
+    }
     rc = kernel_event(c, true);
     if (rc != BL_OK) return rc;
     hipError_t e = bl::launch_scan_count(mode, p, all, c->stream);  // pass 1: the dominant kernel (timed alone)
     if (e != hipSuccess) return fail(BL_ERR_HIP, std::string("scan_count_kernel: ") + hipGetErrorString(e));
+    if (staggered) {
+        BL_HIP(hipEventRecord(c->cur->ev_count_done, c->stream));
+        c->cur->count_recorded = true;
+    }
     rc = kernel_event(c, false);
     if (rc != BL_OK) return rc;
     e = bl::launch_tile_scan(p, all, block_tot, carry, c->stream);
     if (e != hipSuccess) return fail(BL_ERR_HIP, std::string("tile_scan: ") + hipGetErrorString(e));
-    e = bl::launch_scan_emit(mode, p, all, c->stream);  // pass 2
+    e = bl::launch_scan_emit(mode, p, all, c->stream, staggered ? c->emit_lds_per_wg : 0);  // pass 2
     if (e != hipSuccess) return fail(BL_ERR_HIP, std::string("scan_emit_kernel: ") + hipGetErrorString(e));
     return BL_OK;
 }

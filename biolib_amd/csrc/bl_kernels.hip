@@ -420,14 +420,24 @@ hipError_t launch_scan_count(int mode, const ScanParams& p, GroupRange g, hipStr
 }
 
 // pass 2 over the tiles of group g (its prefix scan must have run)
-hipError_t launch_scan_emit(int mode, const ScanParams& p, GroupRange g, hipStream_t stream)
+// lds_per_wg: when non-zero, pad the workgroup's LDS footprint up to this many bytes with (unused) dynamic LDS.  Its only
+// purpose is to cap how many emit workgroups a CU holds when the pass runs beside the next scan's pass 1 (two-lane
+// contexts): uncapped, the memory-bound emit waves crowd the ALU-bound pass out of the SIMDs (349 vs 364 Gbp/s measured).
+template <int MODE>
+static void launch_emit_mode(const ScanParams& p, GroupRange g, hipStream_t stream, uint32_t lds_per_wg)
+{
+    const uint32_t have = (uint32_t)sizeof(TileShared<MODE, 1>);
+    const uint32_t pad = lds_per_wg > have ? lds_per_wg - have : 0;
+    hipLaunchKernelGGL((scan_emit_kernel<MODE>), dim3(g.count), dim3(TPB), pad, stream, p, g);
+}
+
+hipError_t launch_scan_emit(int mode, const ScanParams& p, GroupRange g, hipStream_t stream, uint32_t lds_per_wg)
 {
     if (g.count == 0) return hipSuccess;
-    const dim3 grid(g.count), block(TPB);
     switch (mode) {
-        case MODE_MINIMIZER: hipLaunchKernelGGL((scan_emit_kernel<MODE_MINIMIZER>), grid, block, 0, stream, p, g); break;
-        case MODE_SUPERKMER: hipLaunchKernelGGL((scan_emit_kernel<MODE_SUPERKMER>), grid, block, 0, stream, p, g); break;
-        case MODE_SYNCMER: hipLaunchKernelGGL((scan_emit_kernel<MODE_SYNCMER>), grid, block, 0, stream, p, g); break;
+        case MODE_MINIMIZER: launch_emit_mode<MODE_MINIMIZER>(p, g, stream, lds_per_wg); break;
+        case MODE_SUPERKMER: launch_emit_mode<MODE_SUPERKMER>(p, g, stream, lds_per_wg); break;
+        case MODE_SYNCMER: launch_emit_mode<MODE_SYNCMER>(p, g, stream, lds_per_wg); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

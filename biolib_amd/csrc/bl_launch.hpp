@@ -5,7 +5,7 @@
 
 namespace bl {
 hipError_t launch_scan_count(int mode, const ScanParams& p, GroupRange g, hipStream_t stream);
-hipError_t launch_scan_emit(int mode, const ScanParams& p, GroupRange g, hipStream_t stream);
+hipError_t launch_scan_emit(int mode, const ScanParams& p, GroupRange g, hipStream_t stream, uint32_t lds_per_wg = 0);
 hipError_t launch_tile_scan(const ScanParams& p, GroupRange g, unsigned long long* block_tot, unsigned long long* carry, hipStream_t stream);
 hipError_t launch_kmers(const KmerParams& p, int n_blocks, hipStream_t stream);
 hipError_t launch_reduce_shards(const unsigned long long* shards, unsigned long long* result, uint32_t add_mask, hipStream_t stream);

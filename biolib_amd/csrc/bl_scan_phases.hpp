@@ -257,32 +257,29 @@ BL_DEV void gather_halo(const ThreadState* all, int tid, const ThreadState& st, 
 #endif
 }
 
-// High dwords only (the packed-key argmin needs nothing else): one DPP move per element instead of two.
-template <int NE, bool SECOND>
-BL_DEV void gather_halo_hi(const ThreadState* all, int tid, const ThreadState& st, uint32_t* e)
+// Packed keys of the lanes that follow: a lane's own keys carry the tags 0..15 (63..48 when the rightmost wins), the
+// element x of the lane `hop` lanes further on is this lane's element 16*hop + x, so its tag moves by 16 per hop —
+// one DPP move and one add per element (the compiler may fuse them into v_add_u32_dpp).
+template <int NE, bool LEFT>
+BL_DEV void gather_halo_keys(uint32_t* key)
 {
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(BL_CPU_EMU)
-    (void)all;
-    (void)tid;
     uint32_t cur[S];
     BL_UNROLL
-    for (int x = 0; x < S; ++x) cur[x] = (uint32_t)((SECOND ? st.h2[x] : st.h[x]) >> 32);
+    for (int x = 0; x < S; ++x) cur[x] = key[x];
     BL_UNROLL
     for (int hop = 0; hop < (NE + S - 1) / S; ++hop) {
         BL_UNROLL
         for (int x = 0; x < S; ++x) {
-            if (hop * S + x < NE || (hop + 1) * S + x < NE || (hop + 2) * S + x < NE || (hop + 3) * S + x < NE)
-                cur[x] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cur[x], 0x130, 0xf, 0xf, false);
-            if (hop * S + x < NE) e[(hop + 1) * S + x] = cur[x];
+            if (hop * S + x < NE || (hop + 1) * S + x < NE || (hop + 2) * S + x < NE || (hop + 3) * S + x < NE) {
+                const uint32_t nb = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cur[x], 0x130, 0xf, 0xf, false);
+                cur[x] = LEFT ? nb + 16u : nb - 16u;
+            }
+            if (hop * S + x < NE) key[(hop + 1) * S + x] = cur[x];
         }
     }
 #else
-    const int lane = tid & 63;
-    for (int x = 0; x < NE; ++x) {
-        const int nb = lane + 1 + (x >> 4);
-        e[S + x] = nb < 64 ? (uint32_t)((SECOND ? all[tid + 1 + (x >> 4)].h2[x & 15] : all[tid + 1 + (x >> 4)].h[x & 15]) >> 32) : 0xDEADBEEFu;
-    }
-    (void)st;
+    (void)key;  // the emulation builds the keys from the neighbours' states (lane_window_argmin)
 #endif
 }
 
@@ -307,10 +304,19 @@ BL_DEV void lane_window_argmin(const ThreadState* all, int tid, const ThreadStat
 {
     uint32_t key[S + W];
     BL_UNROLL
-    for (int s = 0; s < S; ++s) key[s] = (uint32_t)((SECOND ? st.h2[s] : st.h[s]) >> 32);
-    gather_halo_hi<W, SECOND>(all, tid, st, key);
-    BL_UNROLL
-    for (int x = 0; x < NW + W - 1; ++x) key[x] = packed_key(key[x], x, LEFT);
+    for (int s = 0; s < S; ++s) key[s] = packed_key((uint32_t)((SECOND ? st.h2[s] : st.h[s]) >> 32), s, LEFT);
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(BL_CPU_EMU)
+    gather_halo_keys<W, LEFT>(key);
+#else
+    {
+        const int lane = tid & 63;
+        for (int x = 0; x < W; ++x) {
+            const int nb = lane + 1 + (x >> 4);
+            const uint32_t hi = nb < 64 ? (uint32_t)((SECOND ? all[tid + 1 + (x >> 4)].h2[x & 15] : all[tid + 1 + (x >> 4)].h[x & 15]) >> 32) : 0xDEADBEEFu;
+            key[S + x] = packed_key(hi, S + x, LEFT);
+        }
+    }
+#endif
     const uint32_t dmin = window_argmin_packed<NW, W, LEFT>(key, a);
     if (wave_any(owns && dmin < 64u)) {
 #ifdef BL_EXPERIMENT_COUNT_FALLBACK

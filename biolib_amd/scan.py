@@ -24,7 +24,7 @@ def _flags(canonical=False, drop_last=False, sync=False):
 class Context:
     """One context per (process, GPU): owns the stream-ordered workspace of the scans."""
 
-    def __init__(self, device=0, torch_stream=True):
+    def __init__(self, device=0, torch_stream=True, lanes=1):
         import torch
 
         if not torch.cuda.is_available():
@@ -42,6 +42,9 @@ class Context:
             with torch.cuda.device(self.device):
                 s = torch.cuda.current_stream(self.device).cuda_stream
             check(self._lib.bl_ctx_set_stream(self._h, C.c_void_p(s)))
+        elif lanes != 1:
+            # own streams only: consecutive asynchronous scans overlap (they must not share output arrays)
+            check(self._lib.bl_ctx_set_lanes(self._h, int(lanes)))
 
     def close(self):
         if getattr(self, "_h", None):

@@ -263,12 +263,14 @@ def test_large_batch_properties_and_oracle_digest(ctx):
     assert part["count"] == cnt and sy["count"] > cnt
 
 
-def test_async_scans_on_internal_lanes():
-    """With the context's own streams, consecutive asynchronous scans alternate between two lanes and
-    overlap; results and outputs are valid after ctx.sync() and equal the synchronous ones."""
+@pytest.mark.parametrize("lanes", [1, 2])
+def test_async_scans_on_internal_lanes(lanes):
+    """With the context's own streams and two lanes, consecutive asynchronous scans alternate between two streams
+    (staggered: pass 2 of one beside pass 1 of the next); results and outputs are valid after ctx.sync() and
+    equal the synchronous ones.  Mixed scan kinds share the lanes."""
     import biolib_amd as B
 
-    c = B.Context(0, torch_stream=False)
+    c = B.Context(0, torch_stream=False, lanes=lanes)
     n = 12_000_000
     b = c.synth(5, n, 150)
     cuts = [(i * 2_000_000, 2_000_000) for i in range(6)]
@@ -286,4 +288,6 @@ def test_async_scans_on_internal_lanes():
     hsh = np.concatenate([h[: int(r.count)].cpu().numpy().view(np.uint64) for (v, p, h), r in zip(outs, res)])
     assert np.array_equal(pos, whole["positions"]) and np.array_equal(hsh, whole["hashes"])
     assert int(sk.count) == b.syncmers(31, 11, 0, 20, canonical=True, positions=False)["count"]
+    with pytest.raises(B.BiolibError):
+        B.capi.check(c._lib.bl_ctx_set_lanes(c._h, 3))
     c.close()
