@@ -10,8 +10,9 @@ import biolib_amd as B
 import oracle_lib as O
 
 gbp = float(sys.argv[1]) if len(sys.argv) > 1 else 12.0
-ctx = B.Context(0, torch_stream=False)
-out = {}
+lanes = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+ctx = B.Context(0, torch_stream=False, lanes=lanes)
+out = {"lanes": lanes}
 CH = 1_500_000_000
 
 def timed(fn, n_bases, reps=3):
