@@ -58,7 +58,10 @@ __device__ __forceinline__ void spill_list(uint16_t* dst, const uint16_t* src, u
 {
     uint32_t* d32 = reinterpret_cast<uint32_t*>(dst);
     const uint32_t* s32 = reinterpret_cast<const uint32_t*>(src);
-    for (uint32_t i = tid; i < (n + 1) / 2; i += TPB) d32[i] = s32[i];
+    const uint32_t nd = (n + 1) / 2;  // ~260 for a tile of short reads: one store per thread, a second for a few
+    if ((uint32_t)tid < nd) d32[tid] = s32[tid];
+#pragma unroll 1
+    for (uint32_t i = TPB + tid; i < nd; i += TPB) d32[i] = s32[i];
 }
 
 __device__ __forceinline__ void fill_list(uint16_t* dst, const uint16_t* src, uint32_t n, int tid)

@@ -152,7 +152,20 @@ BL_DEV uint32_t byte_perm(uint32_t hi, uint32_t lo, uint32_t sel)
 #endif
 }
 
-BL_DEV void encode4(uint32_t d, uint32_t& code8, uint32_t& bad4)
+// true in every lane of the wave if the predicate holds in any of them (the CPU emulation decides per thread: every
+// use below picks between a fast form and an exact form that agree wherever the fast form is valid)
+BL_DEV bool wave_any(bool pred)
+{
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(BL_CPU_EMU)
+    return __builtin_amdgcn_ballot_w64(pred) != 0;
+#else
+    return pred;
+#endif
+}
+
+// four bases: code8 = their 2-bit codes (first base most significant), diff = a word whose byte b is non-zero
+// iff base b is not one of ACGTUacgtu
+BL_DEV void encode4(uint32_t d, uint32_t& code8, uint32_t& diff)
 {
     // per byte: x = (c >> 1) & 3; x ^= x >> 1   -> A/a 0, C/c 1, G/g 2, T/t/U/u 3
     uint32_t x = (d >> 1) & 0x03030303u;
@@ -160,24 +173,30 @@ BL_DEV void encode4(uint32_t d, uint32_t& code8, uint32_t& bad4)
     // validity: rebuild the lowercase letter the code stands for and compare with (c | 0x20);
     // 'u' (0x75) differs from 't' (0x74) in bit 0 only, which is forgiven where code == 3
     const uint32_t lut = 0x74676361u;  // bytes 0..3 = 'a','c','g','t'
-    uint32_t expect = byte_perm(lut, lut, x);
-    uint32_t diff = (d | 0x20202020u) ^ expect;
-    diff &= ~((x & (x >> 1)) & 0x01010101u);
-    uint32_t nz = (((diff & 0x7f7f7f7fu) + 0x7f7f7f7fu) | diff) & 0x80808080u;  // bit 7 of each non-zero byte
-    bad4 = ((nz >> 7) * 0x00204081u >> 21) & 0xfu;  // gather bits 0,8,16,24 -> bits 0..3 (byte 0 -> bit 0)
+    const uint32_t expect = byte_perm(lut, lut, x);
+    diff = ((d | 0x20202020u) ^ expect) & ~((x & (x >> 1)) & 0x01010101u);
     // gather the four 2-bit codes, byte 0 (first base) most significant
     code8 = (x * 0x40100401u) >> 24;
 }
 
+// bit b set iff byte b of diff is non-zero
+BL_DEV uint32_t bad_bits4(uint32_t diff)
+{
+    const uint32_t nz = (((diff & 0x7f7f7f7fu) + 0x7f7f7f7fu) | diff) & 0x80808080u;  // bit 7 of each non-zero byte
+    return ((nz >> 7) * 0x00204081u >> 21) & 0xfu;  // gather bits 0,8,16,24 -> bits 0..3 (byte 0 -> bit 0)
+}
+
 BL_DEV void encode16(const uint32_t d[4], uint32_t& code, uint32_t& bad)
 {
-    uint32_t c0, c1, c2, c3, b0, b1, b2, b3;
-    encode4(d[0], c0, b0);
-    encode4(d[1], c1, b1);
-    encode4(d[2], c2, b2);
-    encode4(d[3], c3, b3);
+    uint32_t c0, c1, c2, c3, f0, f1, f2, f3;
+    encode4(d[0], c0, f0);
+    encode4(d[1], c1, f1);
+    encode4(d[2], c2, f2);
+    encode4(d[3], c3, f3);
     code = (c0 << 24) | (c1 << 16) | (c2 << 8) | c3;
-    bad = b0 | (b1 << 4) | (b2 << 8) | (b3 << 12);
+    bad = 0;
+    // breaks are rare in sequencing data: the per-base bit gather runs only for waves that hold one
+    if (wave_any((f0 | f1 | f2 | f3) != 0)) bad = bad_bits4(f0) | (bad_bits4(f1) << 4) | (bad_bits4(f2) << 8) | (bad_bits4(f3) << 12);
 }
 
 // reverse the order of the 32 two-bit pairs of x

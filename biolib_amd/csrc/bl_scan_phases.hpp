@@ -283,17 +283,6 @@ BL_DEV void gather_halo_keys(uint32_t* key)
 #endif
 }
 
-// true in every lane of the wave if the predicate holds in any of them (the emulation decides per thread, which
-// gives the same results: the exact form agrees with the packed form wherever the packed form is valid)
-BL_DEV bool wave_any(bool pred)
-{
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(BL_CPU_EMU)
-    return __builtin_amdgcn_ballot_w64(pred) != 0;
-#else
-    return pred;
-#endif
-}
-
 #ifdef BL_EXPERIMENT_COUNT_FALLBACK
 __device__ unsigned long long bl_dbg_fallbacks;
 #endif
