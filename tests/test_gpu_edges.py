@@ -166,3 +166,37 @@ def test_one_gbp_properties(ctx):
     k2 = b.kmers_raw(31, 0, B.FLAG_CANONICAL | B.FLAG_SYNC, first=half, n=n - half)
     kw = b.kmers_raw(31, 0, B.FLAG_CANONICAL | B.FLAG_SYNC)
     assert k1.count + k2.count == kw.count == (n // L) * (L - 30) and (k1.xor_hash ^ k2.xor_hash) == kw.xor_hash
+
+
+def test_full_baseline_size_composition():
+    """BASELINE C3 at its full size (333,333,333 reads x 150 bp = 50 Gbp on one GPU): the scan of the whole shard in
+    34 ranges and in 26 differently cut ranges must agree on count and on all three XOR digests (range composition is
+    exact on read boundaries), with two lanes in flight; density and k-mer totals match the closed forms."""
+    import biolib_amd as B
+
+    c = B.Context(0, torch_stream=False, lanes=2)
+    L, n_reads = 150, 333_333_333
+    n = L * n_reads
+    b = c.synth(42, n, L)
+
+    def scan(reads_per_range):
+        res = []
+        for a in range(0, n_reads, reads_per_range):
+            m = min(reads_per_range, n_reads - a)
+            res.append(b.minimizers_raw(31, 11, 42, B.FLAG_CANONICAL, first=a * L, n=m * L))
+        c.sync()
+        assert all(r.status == 0 for r in res)
+        cnt = sum(int(r.count) for r in res)
+        xv = xh = xp = 0
+        for r in res:
+            xv ^= int(r.xor_value); xh ^= int(r.xor_hash); xp ^= int(r.xor_pos)
+        return cnt, xv, xh, xp
+
+    a = scan(10_000_000)
+    d = scan(13_000_001)  # 1.95e9 positions per range: just under the 2^31 limit
+    assert a == d
+    windows = n_reads * (L - 41 + 1)
+    assert abs(a[0] / windows - 2 / 12) < 0.01          # random minimizers: 2/(w+1) per window
+    k = b.kmers_raw(31, 0, B.FLAG_CANONICAL | B.FLAG_SYNC, first=0, n=13_333_333 * L)
+    assert k.count == 13_333_333 * (L - 30)
+    c.close()
