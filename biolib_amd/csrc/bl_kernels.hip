@@ -12,11 +12,17 @@ namespace bl {
 
 __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, int lane)
 {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t o = __shfl_up(v, d, 64);
-        if (lane >= d) v += o;
-    }
+    // six DPP steps (the sequence LLVM's atomic optimizer uses on gfx9): inside each row of 16 lanes by row_shr 1, 2,
+    // 4, 8, then lane 15 of every row into the following row (row_bcast15, rows 1 and 3), then lane 31 into the upper
+    // half (row_bcast31, rows 2 and 3).  Lanes without a source add the `old` operand, 0.  (The __shfl_up form costs
+    // ~40 VALU per lane around its ds_bpermute's, 2.5 per base.)
+    (void)lane;
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);  // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);  // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);  // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);  // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);  // row_bcast15 -> rows 1, 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);  // row_bcast31 -> rows 2, 3
     return v;
 }
 
