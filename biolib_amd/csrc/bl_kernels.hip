@@ -43,7 +43,7 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
 // exclusive scan over the workgroup of a value that packs two 16-bit counters (sums stay < 65536)
 __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* wave_tot, int tid, uint32_t& total)
 {
-    const int lane = tid & 63, wv = tid >> 6;
+    const int lane = tid & 63, wv = wave_index(tid);
     const uint32_t incl = wave_incl_scan_u32(v, lane);
     if (lane == 63) wave_tot[wv] = incl;
     __syncthreads();

@@ -111,6 +111,17 @@ BL_DEV uint32_t codes_of(const Vec16& v)
     return code;
 }
 
+// index of the thread's wave inside the workgroup, as a value the compiler knows to be wave-uniform (scalar registers
+// and scalar arithmetic for everything derived from it: chunk bases, wave origins, list tags)
+BL_DEV int wave_index(int tid)
+{
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(BL_CPU_EMU)
+    return __builtin_amdgcn_readfirstlane(tid >> 6);
+#else
+    return tid >> 6;
+#endif
+}
+
 // global position of the first hashed position of wave `wv` of the tile that starts at q0
 BL_DEV int64_t wave_origin(const ScanParams& p, int64_t q0, int wv) { return q0 + (int64_t)wv * (p.stride / NWAVE); }
 
@@ -157,7 +168,7 @@ BL_DEV void gather_flags(const uint32_t* flags, int lane, Bits128& good, Bits128
 template <int MODE, int W>
 BL_DEV void phase_hash(const ScanParams& p, TileShared<MODE, W>& sh, int tid, ThreadState& st)
 {
-    const int wv = tid >> 6, lane = tid & 63;
+    const int wv = wave_index(tid), lane = tid & 63;
     const uint32_t* wcodes = sh.codes + wave_chunk0(p, wv);
     const uint32_t c0 = wcodes[lane], c1 = wcodes[lane + 1], c2 = wcodes[lane + 2];
     Roller r;
@@ -360,7 +371,7 @@ template <int MODE, int W>
 BL_DEV uint32_t phase_window(const ScanParams& p, const TileShared<MODE, W>& sh, int tid, int64_t q0, ThreadState& st,
                              const ThreadState* all)
 {
-    const int wv = tid >> 6, lane = tid & 63;
+    const int wv = wave_index(tid), lane = tid & 63;
     const int w = W ? W : p.w;
     uint32_t a[S + 1];
     uint32_t below = 0x1ffffu;  // w = 1 with a hash threshold (hash_sampler): bit s = hash of unit s is below it
@@ -396,7 +407,11 @@ BL_DEV uint32_t phase_window(const ScanParams& p, const TileShared<MODE, W>& sh,
             valid &= ~last;
         }
     }
-    const uint32_t inrange = range_mask(p.win_first - j0, p.win_end - j0);
+    // all but the first and last tiles of a range lie inside it: decide that once per wave, with scalar arithmetic
+    const int64_t wj0 = wave_origin(p, q0, wv);
+    const bool inside = wj0 >= p.win_first && wj0 + WH + 1 <= p.win_end;
+    uint32_t inrange = 0x1ffffu;
+    if (!inside) inrange = range_mask(p.win_first - j0, p.win_end - j0);
     if (MODE == MODE_SUPERKMER) valid &= inrange;
     uint32_t differ = 0;  // bit s: argmin of window s+1 is a different occurrence than window s
     uint32_t apk[4] = {0, 0, 0, 0};
@@ -434,7 +449,7 @@ template <int MODE, int W>
 BL_DEV uint32_t phase_sync_rev(const ScanParams& p, const TileShared<MODE, W>& sh, int tid, int64_t q0, ThreadState& st,
                                const ThreadState* all, const uint32_t* af)
 {
-    const int wv = tid >> 6, lane = tid & 63;
+    const int wv = wave_index(tid), lane = tid & 63;
     const int w = W ? W : p.w;
     const int k = p.unit + w - 1;
     uint32_t ar[S + 1];
@@ -452,7 +467,10 @@ BL_DEV uint32_t phase_sync_rev(const ScanParams& p, const TileShared<MODE, W>& s
     gather_flags(sh.flags + wave_chunk0(p, wv), lane, good, start);
     const uint32_t valid = window_valid_mask(good, start, k) & 0xffffu;
     const int64_t j0 = wave_origin(p, q0, wv) + 16 * (int64_t)lane;
-    const uint32_t keepable = valid & owned_mask(p, lane) & range_mask(p.win_first - j0, p.win_end - j0);
+    const int64_t wj0 = wave_origin(p, q0, wv);
+    uint32_t inrange = 0x1ffffu;
+    if (!(wj0 >= p.win_first && wj0 + WH + 1 <= p.win_end)) inrange = range_mask(p.win_first - j0, p.win_end - j0);
+    const uint32_t keepable = valid & owned_mask(p, lane) & inrange;
     uint32_t emit = 0;
     BL_UNROLL
     for (int s = 0; s < S; ++s) {
@@ -479,7 +497,7 @@ BL_DEV uint32_t phase_sync_rev(const ScanParams& p, const TileShared<MODE, W>& s
 template <int MODE, int W>
 BL_DEV void phase_list(TileShared<MODE, W>& sh, int tid, const ThreadState& st, uint32_t excl_s, uint32_t excl_e)
 {
-    const int wv = tid >> 6, lane = tid & 63;
+    const int wv = wave_index(tid), lane = tid & 63;
     const uint32_t tag = (uint32_t)wv << 12;  // which wave's staged codes the record refers to
     uint32_t m = st.emit;
     uint32_t r = excl_s;
