@@ -187,6 +187,12 @@ extern "C" int bl_batch_from_text(bl_ctx* ctx, const char* text, uint64_t n_byte
     if (n_bytes == 0) return bl_batch_upload(ctx, "", 0, nullptr, 0, out);
     const bool fastq = text[0] == '@';
     if (!fastq && text[0] != '>') return bl_set_error(BL_ERR_INVALID, "text starts with neither '>' nor '@': use bl_reader_* for irregular files");
+    // a '>' that is the very last byte of the file and alone on its line opens no record in the reference reader (kseq meets
+    // end of file while looking for the name and reports end of input): drop it
+    if (!fastq && text[n_bytes - 1] == '>' && (n_bytes == 1 || text[n_bytes - 2] == '\n')) {
+        --n_bytes;
+        if (n_bytes == 0) return bl_batch_upload(ctx, "", 0, nullptr, 0, out);
+    }
     const bool open_last_line = text[n_bytes - 1] != '\n';  // the last line has no terminator: a virtual one is added
 
     hipStream_t s = bl_ctx_stream(ctx);

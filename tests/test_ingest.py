@@ -129,3 +129,74 @@ def test_device_side_parser_large_fastq_and_wrapped_fasta():
     keep = exp_fp < coffs[5]
     assert np.array_equal(got["first_pos"], exp_fp[keep]) and np.array_equal(got["sizes"], exp_sz[keep])
     ctx.close()
+
+
+# ---- fuzz: mutated inputs, the reference's reader as the judge -------------------------------------------------
+def _ref_read(path):
+    """(seqs list) the REFERENCE reader returns for the file, or None when it reports an error"""
+    import ctypes as C
+
+    R = O.ref()
+    R.ref_kseq_read_all.restype = C.c_long
+    R.ref_kseq_read_all.argtypes = [C.c_char_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64]
+    cap = 1 << 16
+    bases = np.zeros(cap, np.uint8)
+    offs = np.zeros(4096, np.uint64)
+    names = np.zeros(cap, np.uint8)
+    n = R.ref_kseq_read_all(str(path).encode(), O._ptr(bases), cap, O._ptr(offs), 4095, O._ptr(names), cap)
+    if n < 0:
+        return None
+    return [bytes(bases[int(offs[i]):int(offs[i + 1])]) for i in range(n)]
+
+
+@pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref not built")
+def test_fuzz_host_reader_vs_reference_reader(tmp_path):
+    """600 mutated FASTA/FASTQ texts: the library's host reader returns exactly what the reference's kseq returns,
+    and fails exactly where it fails"""
+    import biolib_amd
+    from ingest_fuzz import cases
+
+    for i, text in enumerate(cases(11, 600)):
+        path = tmp_path / "f.txt"
+        path.write_bytes(text)
+        exp = _ref_read(path)
+        try:
+            got = [s for _, s in biolib_amd.Reader(path).records()]
+        except biolib_amd.BiolibError:
+            got = None
+        assert got == exp, (i, text)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref not built")
+def test_fuzz_device_parser_vs_reference_reader(tmp_path):
+    """the device-side parser either refuses a text or returns exactly the reference reader's sequences — never a
+    silent mis-parse, never a fault"""
+    import biolib_amd
+    from ingest_fuzz import cases
+
+    ctx = biolib_amd.Context(0)
+    accepted = 0
+    rounds = int(os.environ.get("BL_FUZZ_ROUNDS", "1"))  # more seeds for an exploratory run
+    texts = [t for r in range(rounds) for t in cases(12 + r, 400)]
+    for i, text in enumerate(texts):
+        path = tmp_path / "f.txt"
+        path.write_bytes(text)
+        exp = _ref_read(path)
+        try:
+            b = ctx.from_text(text)
+        except biolib_amd.BiolibError:
+            continue
+        accepted += 1
+        assert exp is not None, (i, text)
+        assert b.n_seqs == len(exp) and bytes(b.download()) == b"".join(exp), (i, text)
+        # sequence boundaries: every base is its own unit, windows of 2 never cross a boundary
+        seq_all = np.frombuffer(b"".join(exp), np.uint8)
+        offs = np.concatenate([[0], np.cumsum([len(s) for s in exp])]).astype(np.uint64)
+        if len(seq_all):
+            v, p, h = O.minimizers(seq_all, offs, 1, 2, 0, False, brute=False)
+            got = b.minimizers(1, 2)
+            assert np.array_equal(got["positions"], p), (i, text)
+        b.close()
+    assert accepted >= 80  # the unmutated texts and the harmless mutations
+    ctx.close()
