@@ -4,6 +4,8 @@
   (3) size-independent properties at sizes the oracle cannot finish quickly (range unions,
       sortedness, digest-of-digests).
 Bit-exact everywhere: integer / index work has no tolerance."""
+import os
+
 import numpy as np
 import pytest
 
@@ -291,3 +293,35 @@ def test_async_scans_on_internal_lanes(lanes):
     with pytest.raises(B.BiolibError):
         B.capi.check(c._lib.bl_ctx_set_lanes(c._h, 3))
     c.close()
+
+
+def test_random_parameters_vs_oracle(ctx):
+    """random (unit, w, seed, strand, read layout) combinations on small inputs with breaks and repeats: minimizers,
+    super-k-mers, syncmers and hash samples bit-identical to the oracle (covers the generic runtime-w kernels as well
+    as the templated window sizes)"""
+    rng = np.random.default_rng(20260)
+    for it in range(60 * int(os.environ.get("BL_FUZZ_ROUNDS", "1"))):  # more rounds for an exploratory run
+        n = int(rng.integers(50, 20_000))
+        flavour = ["plain", "breaks", "ragged", "reads", "mixed_repeats", "lowcomplexity"][int(rng.integers(6))]
+        seq, offs = _random_case(rng, n, flavour)
+        b = ctx.upload(seq, offs)
+        unit, w = int(rng.integers(1, 33)), int(rng.choice([1, 2, 3, 5, 8, 11, 16, 17, 21, 32, 33, 48, 64]))
+        seed, canon = int(rng.integers(0, 2**40)), bool(rng.integers(2))
+        v, p, h = O.minimizers(seq, offs, unit, w, seed, canon, brute=False)
+        got = b.minimizers(unit, w, seed=seed, canonical=canon)
+        assert got["count"] == len(v), (it, flavour, n, unit, w, canon)
+        assert np.array_equal(got["positions"], p) and np.array_equal(got["values"], v) and np.array_equal(got["hashes"], h), (it, flavour, unit, w)
+        m = int(rng.integers(1, 33))
+        k = int(min(m + rng.integers(0, 40), 95, m + 63))
+        mn, fp, mp, sz, hs = O.super_kmers(seq, offs, k, m, seed, canon)
+        g = b.super_kmers(k, m, seed=seed, canonical=canon)
+        assert g["count"] == len(mn), (it, flavour, n, k, m, canon)
+        assert np.array_equal(g["first_pos"], fp) and np.array_equal(g["sizes"], sz) and np.array_equal(g["mm_pos"], mp) and np.array_equal(g["minimizers"], mn)
+        kk = int(rng.integers(2, 33))
+        s = int(rng.integers(max(1, kk - 31), kk + 1))
+        a, e = int(rng.integers(0, kk - s + 1)), int(rng.integers(0, kk - s + 1))
+        drop = bool(rng.integers(2))
+        cnt, pos = O.syncmers(seq, offs, kk, s, a, e, canon, drop_last=drop)
+        gs = b.syncmers(kk, s, a, e, canonical=canon, drop_last=drop)
+        assert gs["count"] == cnt and np.array_equal(gs["positions"], pos), (it, flavour, n, kk, s, a, e, canon, drop)
+        b.close()
