@@ -114,31 +114,15 @@ int bl_jaccard_sorted_u64(bl_ctx* ctx, const uint64_t* d_a, uint64_t na, const u
 #include <rocprim/device/device_run_length_encode.hpp>
 #include "bl_scan_core.hpp"
 
+#include "bl_partition.hpp"
+
 namespace {
 
-constexpr int MAX_PARTS = 64;
-
-__global__ void bucket_count_kernel(const unsigned long long* keys, unsigned long long n, uint32_t parts, uint32_t seed, unsigned long long* counts)
-{
-    __shared__ unsigned int hist[MAX_PARTS];
-    if (threadIdx.x < MAX_PARTS) hist[threadIdx.x] = 0;
-    __syncthreads();
-    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * blockDim.x)
-        atomicAdd(&hist[bl::murmur64(keys[i], seed) % parts], 1u);
-    __syncthreads();
-    if (threadIdx.x < parts && hist[threadIdx.x]) atomicAdd(&counts[threadIdx.x], (unsigned long long)hist[threadIdx.x]);
-}
-
-// cursor[b] starts at the bucket's offset; order inside a bucket is arbitrary (the buckets get sorted afterwards)
-__global__ void bucket_scatter_kernel(const unsigned long long* keys, unsigned long long n, uint32_t parts, uint32_t seed,
-                                      unsigned long long* cursor, unsigned long long* out)
-{
-    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * blockDim.x) {
-        const unsigned long long k = keys[i];
-        const unsigned long long at = atomicAdd(&cursor[bl::murmur64(k, seed) % parts], 1ull);
-        out[at] = k;
-    }
-}
+struct KeyHashOwner {
+    const unsigned long long* keys;
+    uint32_t seed;
+    __device__ uint32_t operator()(unsigned long long i, uint32_t parts) const { return blpart::bucket_of(bl::murmur64(keys[i], seed), parts); }
+};
 
 }  // namespace
 
@@ -146,30 +130,13 @@ extern "C" {
 
 int bl_partition_u64(bl_ctx* ctx, const uint64_t* d_keys, uint64_t n, uint32_t parts, uint64_t seed, uint64_t* d_out, uint64_t* counts)
 {
-    if (!ctx || !counts || parts == 0 || parts > MAX_PARTS || (n && (!d_keys || !d_out))) return bl_set_error(BL_ERR_INVALID, "bad argument (1 <= parts <= 64)");
+    if (!ctx || !counts || parts == 0 || parts > blpart::MAX_PARTS || (n && (!d_keys || !d_out))) return bl_set_error(BL_ERR_INVALID, "bad argument (1 <= parts <= 64)");
     SET_HIP(hipSetDevice(bl_ctx_device(ctx)));
-    hipStream_t s = bl_ctx_stream(ctx);
-    unsigned long long* d_counts = nullptr;
-    SET_HIP(hipMalloc(&d_counts, 2 * MAX_PARTS * sizeof(unsigned long long)));
-    hipError_t e = hipMemsetAsync(d_counts, 0, 2 * MAX_PARTS * sizeof(unsigned long long), s);
-    const unsigned blocks = (unsigned)std::min<uint64_t>((n + 255) / 256 + 1, 256 * 8);
-    unsigned long long host[MAX_PARTS] = {0}, cursor[MAX_PARTS] = {0};
-    if (e == hipSuccess && n) {
-        hipLaunchKernelGGL(bucket_count_kernel, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const unsigned long long*>(d_keys), n, parts, (uint32_t)seed, d_counts);
-        e = hipMemcpyAsync(host, d_counts, parts * sizeof(unsigned long long), hipMemcpyDeviceToHost, s);
-        if (e == hipSuccess) e = hipStreamSynchronize(s);
-        unsigned long long run = 0;
-        for (uint32_t b = 0; b < parts; ++b) { cursor[b] = run; run += host[b]; }
-        if (e == hipSuccess) e = hipMemcpyAsync(d_counts + MAX_PARTS, cursor, parts * sizeof(unsigned long long), hipMemcpyHostToDevice, s);
-        if (e == hipSuccess) {
-            hipLaunchKernelGGL(bucket_scatter_kernel, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const unsigned long long*>(d_keys), n, parts, (uint32_t)seed,
-                               d_counts + MAX_PARTS, reinterpret_cast<unsigned long long*>(d_out));
-            e = hipGetLastError();
-        }
-        if (e == hipSuccess) e = hipStreamSynchronize(s);
-    }
-    (void)hipFree(d_counts);
-    if (e != hipSuccess) return bl_set_error(BL_ERR_HIP, hipGetErrorString(e));
+    const unsigned long long* keys = reinterpret_cast<const unsigned long long*>(d_keys);
+    unsigned long long host[blpart::MAX_PARTS];
+    const hipError_t e = blpart::partition(keys, (unsigned long long)n, parts, KeyHashOwner{keys, (uint32_t)seed}, reinterpret_cast<unsigned long long*>(d_out), host,
+                                           bl_ctx_stream(ctx));
+    if (e != hipSuccess) return bl_set_error(e == hipErrorOutOfMemory ? BL_ERR_OOM : BL_ERR_HIP, hipGetErrorString(e));
     for (uint32_t b = 0; b < parts; ++b) counts[b] = host[b];
     return BL_OK;
 }

@@ -15,6 +15,7 @@
 #include <rocprim/device/device_scan.hpp>
 
 #include "../../include/biolib_amd.h"
+#include "bl_partition.hpp"
 
 extern int bl_set_error(int code, const char* msg);  // bl_capi.hip
 extern hipStream_t bl_ctx_stream(bl_ctx* ctx);
@@ -57,25 +58,10 @@ __global__ __launch_bounds__(256) void pack_kernel(const unsigned char* __restri
     out[g] = make_ulonglong2(hi, (lo & ~0xffULL) | (unsigned long long)size);
 }
 
-__global__ void owner_count_kernel(const unsigned long long* hashes, unsigned long long n, unsigned parts, unsigned long long* counts)
-{
-    __shared__ unsigned int hist[MAX_PARTS];
-    if (threadIdx.x < MAX_PARTS) hist[threadIdx.x] = 0;
-    __syncthreads();
-    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * blockDim.x)
-        atomicAdd(&hist[hashes[i] % parts], 1u);
-    __syncthreads();
-    if (threadIdx.x < parts && hist[threadIdx.x]) atomicAdd(&counts[threadIdx.x], (unsigned long long)hist[threadIdx.x]);
-}
-
-__global__ void owner_scatter_kernel(const unsigned long long* hashes, const ulonglong2* recs, unsigned long long n, unsigned parts,
-                                     unsigned long long* cursor, ulonglong2* out)
-{
-    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * blockDim.x) {
-        const unsigned long long at = atomicAdd(&cursor[hashes[i] % parts], 1ull);
-        out[at] = recs[i];
-    }
-}
+struct HashArrayOwner {
+    const unsigned long long* hashes;
+    __device__ uint32_t operator()(unsigned long long i, uint32_t parts) const { return blpart::bucket_of(hashes[i], parts); }
+};
 
 __global__ void sizes_kernel(const ulonglong2* recs, unsigned long long n, unsigned long long* sizes)
 {
@@ -130,34 +116,12 @@ int bl_partition_records(bl_ctx* ctx, const uint64_t* d_hashes, const uint64_t* 
 {
     if (!ctx || !counts || parts == 0 || parts > MAX_PARTS || (n && (!d_hashes || !d_records || !d_out)))
         return bl_set_error(BL_ERR_INVALID, "bad argument (1 <= parts <= 64)");
-    for (uint32_t b = 0; b < parts; ++b) counts[b] = 0;
-    if (n == 0) return BL_OK;
     SK_HIP(hipSetDevice(bl_ctx_device(ctx)));
-    hipStream_t s = bl_ctx_stream(ctx);
-    unsigned long long* d_counts = nullptr;
-    SK_HIP(hipMalloc(&d_counts, 2 * MAX_PARTS * sizeof(unsigned long long)));
-    hipError_t e = hipMemsetAsync(d_counts, 0, 2 * MAX_PARTS * sizeof(unsigned long long), s);
-    const unsigned blocks = (unsigned)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
-    unsigned long long host[MAX_PARTS] = {0}, cursor[MAX_PARTS] = {0};
-    if (e == hipSuccess) {
-        hipLaunchKernelGGL(owner_count_kernel, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const unsigned long long*>(d_hashes), (unsigned long long)n, parts, d_counts);
-        e = hipMemcpyAsync(host, d_counts, parts * sizeof(unsigned long long), hipMemcpyDeviceToHost, s);
-    }
-    if (e == hipSuccess) e = hipStreamSynchronize(s);
-    unsigned long long run = 0;
-    for (uint32_t b = 0; b < parts; ++b) {
-        cursor[b] = run;
-        run += host[b];
-    }
-    if (e == hipSuccess) e = hipMemcpyAsync(d_counts + MAX_PARTS, cursor, parts * sizeof(unsigned long long), hipMemcpyHostToDevice, s);
-    if (e == hipSuccess) {
-        hipLaunchKernelGGL(owner_scatter_kernel, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const unsigned long long*>(d_hashes),
-                           reinterpret_cast<const ulonglong2*>(d_records), (unsigned long long)n, parts, d_counts + MAX_PARTS, reinterpret_cast<ulonglong2*>(d_out));
-        e = hipGetLastError();
-    }
-    if (e == hipSuccess) e = hipStreamSynchronize(s);
-    (void)hipFree(d_counts);
-    if (e != hipSuccess) return bl_set_error(BL_ERR_HIP, hipGetErrorString(e));
+    unsigned long long host[MAX_PARTS];
+    const hipError_t e = blpart::partition(reinterpret_cast<const ulonglong2*>(d_records), (unsigned long long)n, parts,
+                                           HashArrayOwner{reinterpret_cast<const unsigned long long*>(d_hashes)}, reinterpret_cast<ulonglong2*>(d_out), host,
+                                           bl_ctx_stream(ctx));
+    if (e != hipSuccess) return bl_set_error(e == hipErrorOutOfMemory ? BL_ERR_OOM : BL_ERR_HIP, hipGetErrorString(e));
     for (uint32_t b = 0; b < parts; ++b) counts[b] = host[b];
     return BL_OK;
 }

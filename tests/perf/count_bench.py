@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Stage timings of the partitioned k-mer counter on ONE GPU: scan -> pack -> bucket split ->
+(all-to-all skipped: world 1) -> expand -> sort -> run-length count.  Checked against the oracle on a sample."""
+import json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import torch
+import biolib_amd as B
+import oracle_lib as O
+
+gbp = float(sys.argv[1]) if len(sys.argv) > 1 else 1.5
+k, m, L = 31, 15, 150
+ctx = B.Context(0)
+n = int(gbp * 1e9) // L * L
+b = ctx.synth(42, n, L)
+out = {"bases": n, "k": k, "m": m}
+
+def timed(name, fn):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    r = fn()
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    out[name + "_ms"] = round(dt * 1e3, 2); out[name + "_Gbp_s"] = round(n / dt / 1e9, 1)
+    return r
+
+for rep in range(2):  # second pass = warm numbers
+    recs, hashes = timed("scan_pack", lambda: b.super_kmer_records(k, m, seed=42, canonical=True))
+    bucketed, counts = timed("bucket_split_8", lambda: ctx.partition_records(hashes, recs, 8))
+    kmers = timed("expand", lambda: ctx.expand_super_kmers(bucketed, k, canonical=True))
+    u, c = timed("sort_count", lambda: ctx.sort_count(kmers))
+out["super_kmers"] = int(recs.shape[0]); out["kmers"] = int(kmers.numel()); out["distinct"] = int(u.numel())
+out["record_bytes_per_base"] = round(16 * recs.shape[0] / n, 3)
+out["whole_chain_Gbp_s"] = round(n / sum(out[s + "_ms"] for s in ("scan_pack", "bucket_split_8", "expand", "sort_count")) * 1e-6, 1)
+# parity on a sample: the multiset of canonical k-mers of the first 20,000 reads
+s = 20_000 * L
+sb = ctx.upload(b.download(0, s), O.fixed_offsets(s, L))
+r2, _ = sb.super_kmer_records(k, m, seed=42, canonical=True)
+u2, c2 = ctx.sort_count(ctx.expand_super_kmers(r2, k, canonical=True))
+vals, ok = O.units(b.download(0, s), O.fixed_offsets(s, L), k, True)
+eu, ec = np.unique(vals[ok != 0], return_counts=True)
+out["parity_sample"] = bool(np.array_equal(u2.cpu().numpy().view(np.uint64), eu) and np.array_equal(c2.cpu().numpy().astype(np.int64), ec))
+print(json.dumps(out))
