@@ -90,13 +90,19 @@ def exchange(bucketed, counts, group=None):
     import torch.distributed as dist
 
     counts = [int(c) for c in counts]
-    send = torch.tensor(counts, dtype=torch.int64, device=bucketed.device)
+    # RCCL ("nccl") moves device tensors directly over xGMI; under gloo (CPU tests, one-GPU rehearsals) device tensors are
+    # staged through the host
+    staged = bucketed.is_cuda and dist.get_backend(group) == "gloo"
+    wire = bucketed[: sum(counts)].contiguous()
+    if staged:
+        wire = wire.cpu()
+    send = torch.tensor(counts, dtype=torch.int64, device=wire.device)
     recv = torch.empty_like(send)
     dist.all_to_all_single(recv, send, group=group)
     recv_sizes = [int(x) for x in recv.cpu().tolist()]
-    inbox = torch.empty((sum(recv_sizes),) + tuple(bucketed.shape[1:]), dtype=bucketed.dtype, device=bucketed.device)
-    dist.all_to_all_single(inbox, bucketed[: sum(counts)].contiguous(), output_split_sizes=recv_sizes, input_split_sizes=counts, group=group)
-    return inbox
+    inbox = torch.empty((sum(recv_sizes),) + tuple(wire.shape[1:]), dtype=wire.dtype, device=wire.device)
+    dist.all_to_all_single(inbox, wire, output_split_sizes=recv_sizes, input_split_sizes=counts, group=group)
+    return inbox.to(bucketed.device) if staged else inbox
 
 
 def count_kmers_via_super_kmers(ctx, batch, k, m, seed=0, canonical=True, group=None):

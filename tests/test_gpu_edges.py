@@ -200,3 +200,38 @@ def test_full_baseline_size_composition():
     k = b.kmers_raw(31, 0, B.FLAG_CANONICAL | B.FLAG_SYNC, first=0, n=13_333_333 * L)
     assert k.count == 13_333_333 * (L - 30)
     c.close()
+
+
+def test_bench_two_rank_flow_on_one_gpu():
+    """bench.py under torch.distributed.run with two ranks (rehearsal mode: both on this GPU, gloo): one JSON line from
+    rank 0, whole-job aggregate over both shards, digests reduced across ranks"""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    import biolib_amd as B
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BL_BENCH_REHEARSE="1", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29547", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--gbp", "1.5"],
+                         capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    lines = [x for x in out.stdout.splitlines() if x.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["vs_baseline"] is None and "rehearsal" in d and d["value"] > 0
+    assert "cpu_baseline" not in d and d["roofline"]["bound"] == "hbm"
+    # the reduced digest = the two shards (seed 42 and 43) scanned directly
+    c = B.Context(0)
+    n = d["config"]["bases_per_gpu"]
+    cnt, xh = 0, 0
+    for seed in (42, 43):
+        b = c.synth(seed, n, 150)
+        r = b.minimizers_raw(31, 11, 42, B.FLAG_CANONICAL | B.FLAG_SYNC)
+        cnt += int(r.count)
+        xh ^= int(r.xor_hash)
+        b.close()
+    assert d["records_per_step"] == cnt and d["xor_hash"] == xh
+    c.close()

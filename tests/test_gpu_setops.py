@@ -259,3 +259,54 @@ def test_count_kmers_via_super_kmers_single_gpu(ctx):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+TWO_RANK_COUNTER = r"""
+import os, sys
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+import numpy as np, torch, torch.distributed as dist
+import biolib_amd as B
+from biolib_amd.shard import shard_reads, count_kmers_via_super_kmers
+dist.init_process_group("gloo")                      # two ranks on ONE GPU: RCCL refuses that, gloo stages through the host
+rank, world = dist.get_rank(), dist.get_world_size()
+ctx = B.Context(0)
+L, n_reads, k, m = 150, 40_000, 21, 11
+first, cnt = shard_reads(n_reads, world, rank)
+import oracle_lib as O
+whole = O.synth(5, n_reads * L)
+whole[::997] = ord("N")
+seq = whole[first * L:(first + cnt) * L]
+b = ctx.upload(seq, O.fixed_offsets(len(seq), L))
+u, c = count_kmers_via_super_kmers(ctx, b, k, m, seed=3, canonical=True)
+np.savez(os.path.join({out!r}, f"rank{{rank}}.npz"), u=u.cpu().numpy().view(np.uint64), c=c.cpu().numpy())
+ctx.close()
+dist.destroy_process_group()
+"""
+
+
+def test_two_rank_counter_on_one_gpu(tmp_path):
+    """the whole distributed counter with world_size 2 (both ranks on this GPU, gloo for the exchange): scan -> pack ->
+    route by minimizer hash -> all-to-all -> expand -> sort -> count; the union over ranks is the exact global count and
+    no k-mer appears on two ranks"""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(HERE)
+    script = tmp_path / "counter.py"
+    script.write_text(TWO_RANK_COUNTER.format(root=root, out=str(tmp_path)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29541", str(script)], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    L, n_reads, k = 150, 40_000, 21
+    whole = O.synth(5, n_reads * L)
+    whole[::997] = ord("N")
+    vals, ok = O.units(whole, O.fixed_offsets(len(whole), L), k, True)
+    eu, ec = np.unique(vals[ok != 0], return_counts=True)
+    parts = [np.load(tmp_path / f"rank{r}.npz") for r in range(2)]
+    assert len(np.intersect1d(parts[0]["u"], parts[1]["u"])) == 0
+    gu = np.concatenate([p["u"] for p in parts])
+    gc = np.concatenate([p["c"] for p in parts]).astype(np.int64)
+    order = np.argsort(gu)
+    assert np.array_equal(gu[order], eu) and np.array_equal(gc[order], ec)
+    assert min(len(p["u"]) for p in parts) > 0.3 * len(eu)   # both ranks own a fair share
