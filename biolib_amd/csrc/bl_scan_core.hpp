@@ -401,7 +401,8 @@ BL_DEV void window_argmin(const uint64_t* e, uint32_t* a)
 // folds (a ^ b) into a running minimum, and the caller re-runs the 64-bit form when that minimum is below 64
 // (probability ~1e-6 per window on random hashes; certain on repeats, which is why the exact form stays).
 // Returns the minimum xor distance seen.  NW + W - 1 <= 64 elements.
-template <int NW, int W, bool LEFT>
+// RAW: leave the whole minimum key in a[] (position in its low 6 bits, hash bits above) for callers that mask anyway.
+template <int NW, int W, bool LEFT, bool RAW = false>
 BL_DEV uint32_t window_argmin_packed(const uint32_t* key, uint32_t* a)
 {
     uint32_t dmin = ~0u;
@@ -415,7 +416,7 @@ BL_DEV uint32_t window_argmin_packed(const uint32_t* key, uint32_t* a)
             sv[i] = x < sv[i + 1] ? x : sv[i + 1];
             dmin = d < dmin ? d : dmin;
         }
-        a[base] = LEFT ? (sv[0] & 63u) : 63u - (sv[0] & 63u);
+        a[base] = RAW ? sv[0] : (LEFT ? (sv[0] & 63u) : 63u - (sv[0] & 63u));
         uint32_t pv = 0;
         BL_UNROLL
         for (int i = 1; i < W; ++i) {
@@ -431,7 +432,7 @@ BL_DEV uint32_t window_argmin_packed(const uint32_t* key, uint32_t* a)
             const uint32_t d2 = pv ^ sv[i];
             const uint32_t r = pv < sv[i] ? pv : sv[i];
             dmin = d2 < dmin ? d2 : dmin;
-            a[base + i] = LEFT ? (r & 63u) : 63u - (r & 63u);
+            a[base + i] = RAW ? r : (LEFT ? (r & 63u) : 63u - (r & 63u));
         }
     }
     return dmin;

@@ -299,7 +299,7 @@ __device__ unsigned long long bl_dbg_fallbacks;
 #endif
 // Window argmins of one lane: packed 32-bit keys first, the exact 64-bit form when a prefix tie was seen anywhere
 // in the wave among lanes that own windows.
-template <int NW, int W, bool LEFT, bool SECOND>
+template <int NW, int W, bool LEFT, bool SECOND, bool RAW = false>
 BL_DEV void lane_window_argmin(const ThreadState* all, int tid, const ThreadState& st, bool owns, uint32_t* a)
 {
     uint32_t key[S + W];
@@ -317,7 +317,7 @@ BL_DEV void lane_window_argmin(const ThreadState* all, int tid, const ThreadStat
         }
     }
 #endif
-    const uint32_t dmin = window_argmin_packed<NW, W, LEFT>(key, a);
+    const uint32_t dmin = window_argmin_packed<NW, W, LEFT, RAW && LEFT>(key, a);
     if (wave_any(owns && dmin < 64u)) {
 #ifdef BL_EXPERIMENT_COUNT_FALLBACK
         if ((tid & 63) == 0) atomicAdd(&bl_dbg_fallbacks, 1ull);
@@ -376,7 +376,7 @@ BL_DEV uint32_t phase_window(const ScanParams& p, const TileShared<MODE, W>& sh,
     uint32_t a[S + 1];
     uint32_t below = 0x1ffffu;  // w = 1 with a hash threshold (hash_sampler): bit s = hash of unit s is below it
     if (W > 1) {
-        lane_window_argmin<S + 1, (W > 1 ? W : 2), true, false>(all, tid, st, owned_mask(p, tid & 63) != 0, a);
+        lane_window_argmin<S + 1, (W > 1 ? W : 2), true, false, true>(all, tid, st, owned_mask(p, tid & 63) != 0, a);
     } else if (W == 1) {
         uint64_t e[S + 1];
         BL_UNROLL
@@ -413,12 +413,23 @@ BL_DEV uint32_t phase_window(const ScanParams& p, const TileShared<MODE, W>& sh,
     uint32_t inrange = 0x1ffffu;
     if (!inside) inrange = range_mask(p.win_first - j0, p.win_end - j0);
     if (MODE == MODE_SUPERKMER) valid &= inrange;
-    uint32_t differ = 0;  // bit s: argmin of window s+1 is a different occurrence than window s
-    uint32_t apk[4] = {0, 0, 0, 0};
+    // a[s] holds the argmin of window s in its low 6 bits (the packed form leaves hash bits above them).  Four at a
+    // time: apk[j] = bytes a[4j+1..4j+4] (what the list phase reads), prv[j] = bytes a[4j..4j+3]; differ bit s = the two
+    // bytes at s disagree = argmin of window s+1 is a different occurrence than that of window s.
+    constexpr uint32_t IDX = W > 1 ? 0x3fu : 0x7fu;  // templated windows: 6-bit tags under hash bits; runtime w: plain indices < 16 + 64
+    uint32_t apk[4], differ = 0;
     BL_UNROLL
-    for (int s = 0; s < S; ++s) {
-        if (a[s + 1] != a[s]) differ |= 1u << s;
-        apk[s >> 2] |= (uint32_t)a[s + 1] << (8 * (s & 3));
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t lo2 = byte_perm(a[4 * j + 2], a[4 * j + 1], 0x0c0c0400u);  // byte 0 <- a[4j+1], byte 1 <- a[4j+2]
+        const uint32_t hi2 = byte_perm(a[4 * j + 4], a[4 * j + 3], 0x04000c0cu);  // byte 2 <- a[4j+3], byte 3 <- a[4j+4]
+        apk[j] = (lo2 | hi2) & (IDX * 0x01010101u);
+    }
+    BL_UNROLL
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t prv = j ? funnel_shr(apk[j], apk[j - 1], 24) : ((apk[0] << 8) | (a[0] & IDX));
+        const uint32_t x = apk[j] ^ prv;                                    // bytes < 128
+        const uint32_t nz = ((x + 0x7f7f7f7fu) >> 7) & 0x01010101u;         // 1 in every non-zero byte
+        differ |= ((nz * 0x01020408u) >> 24) << (4 * j);                    // byte b -> bit b
     }
     st.apk0 = ((uint64_t)apk[1] << 32) | apk[0];  // register pairs: no data movement
     st.apk1 = ((uint64_t)apk[3] << 32) | apk[2];
