@@ -278,9 +278,10 @@ BL_DEV uint64_t extract_unit(const uint32_t* codes, int pos, int unit, int canon
 {
     const int ch = pos >> 4, off = pos & 15;
     const uint64_t A = ((uint64_t)codes[ch] << 32) | codes[ch + 1];
-    const uint64_t B = ((uint64_t)codes[ch + 1] << 32) | codes[ch + 2];
     // 96 bits of pairs starting at chunk ch; take `unit` pairs from pair offset `off`
-    uint64_t top = (A << (2 * off)) | (off ? (B << 32 >> (64 - 2 * off)) : 0);  // 32 bases from `off`
+    // 32 bases from `off`; the third chunk contributes its top 2*off bits (none for off = 0: shifted out in two steps,
+    // which keeps the expression branch-free for the per-record loop of pass 2)
+    uint64_t top = (A << (2 * off)) | (uint64_t)((codes[ch + 2] >> 1) >> (31 - 2 * off));
     uint64_t fwd = unit == 32 ? top : (top >> (64 - 2 * unit));
     if (!canonical) return fwd;
     uint64_t rc = pairrev64(fwd) >> (64 - 2 * unit);

@@ -586,10 +586,11 @@ BL_DEV void stream_store(T* dst, T v)
 #endif
 }
 
-template <int MODE>
+// CHECK = false: the caller has established that the whole tile fits below the capacity
+template <int MODE, bool CHECK = true>
 BL_DEV void emit_store(const ScanParams& p, const Record& rec, uint64_t g)
 {
-    if (g >= p.capacity) return;
+    if (CHECK && g >= p.capacity) return;
     if (MODE == MODE_SYNCMER) {
         if (p.out_pos) stream_store(&p.out_pos[g], rec.pos);
         return;
@@ -620,9 +621,16 @@ template <int MODE, int W>
 BL_DEV void phase_emit(const ScanParams& p, const TileShared<MODE, W>& sh, int tid, int64_t q0, uint32_t n_s, uint32_t n_e,
                        uint64_t base_s, uint64_t base_e, Digest& dg)
 {
-    for (uint32_t r = tid; r < n_s; r += TPB) {
-        const Record rec = emit_prepare<MODE, W>(p, sh, q0, r, dg);
-        emit_store<MODE>(p, rec, base_s + r);
+    if (base_s + n_s <= p.capacity) {  // the usual case, uniform for the workgroup: no per-record capacity test
+        for (uint32_t r = tid; r < n_s; r += TPB) {
+            const Record rec = emit_prepare<MODE, W>(p, sh, q0, r, dg);
+            emit_store<MODE, false>(p, rec, base_s + r);
+        }
+    } else {
+        for (uint32_t r = tid; r < n_s; r += TPB) {
+            const Record rec = emit_prepare<MODE, W>(p, sh, q0, r, dg);
+            emit_store<MODE, true>(p, rec, base_s + r);
+        }
     }
     emit_ends<MODE, W>(p, sh, tid, q0, n_e, base_e);
 }
