@@ -26,6 +26,24 @@ __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, int lane)
     return v;
 }
 
+// XOR of v over the wave, valid in LANE 63 ONLY (the inclusive-scan DPP sequence of wave_incl_scan_u32 with xor): the
+// per-tile digest fold of pass 2 runs this three times per wave; the butterfly of shuffles cost ~100 VALU there.
+__device__ __forceinline__ uint32_t wave_xor_to_last_u32(uint32_t v)
+{
+    v ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);
+    v ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);
+    v ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);
+    v ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);
+    v ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);
+    v ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);
+    return v;
+}
+
+__device__ __forceinline__ unsigned long long wave_xor_to_last_u64(unsigned long long v)
+{
+    return ((unsigned long long)wave_xor_to_last_u32((uint32_t)(v >> 32)) << 32) | wave_xor_to_last_u32((uint32_t)v);
+}
+
 __device__ __forceinline__ unsigned long long wave_xor_u64(unsigned long long v)
 {
 #pragma unroll
@@ -198,8 +216,8 @@ __global__ __launch_bounds__(TPB) void scan_emit_kernel(const ScanParams p, Grou
     __syncthreads();
     if (tid < 4) sh.dig[tid] = 0;
     __syncthreads();
-    const unsigned long long xv = wave_xor_u64(dg.xv), xh = wave_xor_u64(dg.xh), xp = wave_xor_u64(dg.xp);
-    if ((tid & 63) == 0) {
+    const unsigned long long xv = wave_xor_to_last_u64(dg.xv), xh = wave_xor_to_last_u64(dg.xh), xp = wave_xor_to_last_u64(dg.xp);
+    if ((tid & 63) == 63) {
         atomicXor(&sh.dig[1], xv);
         atomicXor(&sh.dig[2], xh);
         atomicXor(&sh.dig[3], xp);
