@@ -92,6 +92,7 @@ __device__ __forceinline__ void fill_list(uint16_t* dst, const uint16_t* src, ui
 {
     uint32_t* d32 = reinterpret_cast<uint32_t*>(dst);
     const uint32_t* s32 = reinterpret_cast<const uint32_t*>(src);
+#pragma unroll 1
     for (uint32_t i = tid; i < (n + 1) / 2; i += TPB) d32[i] = s32[i];
 }
 
@@ -172,7 +173,8 @@ __device__ __forceinline__ void emit_tile(const ScanParams& p, TileShared<MODE, 
     if (tid < needed) sh.codes[tid] = c0;
     if (TPB + tid < needed) sh.codes[TPB + tid] = c1;
     reinterpret_cast<uint32_t*>(sh.list_a)[tid] = la;
-    for (uint32_t i = TPB + tid; i < (n_s + 1) / 2; i += TPB) reinterpret_cast<uint32_t*>(sh.list_a)[i] = sa32[i];
+#pragma unroll 1
+    for (uint32_t i = TPB + tid; i < (n_s + 1) / 2; i += TPB) reinterpret_cast<uint32_t*>(sh.list_a)[i] = sa32[i];  // rarely more than one round
     if (MODE == MODE_SUPERKMER) {
         fill_list(sh.list_j, p.slots_j + slot, n_s, tid);
         fill_list(sh.list_e, p.slots_e + slot, n_e, tid);
