@@ -61,7 +61,7 @@ struct Pending {
 // context's own streams, consecutive asynchronous scans alternate between the lanes and are staggered by an event: a
 // scan's pass 1 starts when the previous scan's pass 1 has finished, i.e. beside that scan's pass 2.  Pass 1 is bound by
 // VALU issue and leaves HBM idle, pass 2 is bound by HBM writes: together they run at the VALU rate of their combined
-// instruction count (measured on MI355X: 341 -> 377 Gbp/s on the C3 workload; pass-2 residency is capped, see launch_scan_emit).  Consecutive scans then run concurrently,
+// instruction count (measured on MI355X: 346 -> 387 Gbp/s on the C3 workload; pass-2 residency is capped, see launch_scan_emit).  Consecutive scans then run concurrently,
 // so they must not share output arrays.  Default: one lane.  A borrowed caller stream always uses lane 0.
 struct Lane {
     hipStream_t own = nullptr;

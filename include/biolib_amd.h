@@ -86,7 +86,7 @@ int bl_ctx_destroy(bl_ctx* ctx);
 int bl_ctx_set_stream(bl_ctx* ctx, void* hip_stream);
 int bl_ctx_sync(bl_ctx* ctx);
 /* Execution lanes of a context that runs on its own streams: with n = 2 consecutive asynchronous scans alternate between two
- * streams, staggered so that the record pass of one scan runs beside the hashing pass of the next (+10 % on MI355X).  Scans in
+ * streams, staggered so that the record pass of one scan runs beside the hashing pass of the next (+12 % on MI355X).  Scans in
  * flight together must not share output arrays.  n = 1 (default) keeps scans strictly ordered.  Ignored on a borrowed stream. */
 int bl_ctx_set_lanes(bl_ctx* ctx, int n);
 
