@@ -121,6 +121,10 @@ def main():
     xor_hash = 0
     for r in step_res:
         xor_hash ^= int(r.xor_hash)
+    # every timed step scanned the same shard: its ranges must report the same counts and digests each time
+    for k in range(args.steps - 1):
+        for a, b in zip(all_res[k * len(ranges):(k + 1) * len(ranges)], step_res):
+            assert (a.count, a.xor_hash, a.xor_pos, a.xor_value) == (b.count, b.xor_hash, b.xor_pos, b.xor_value), "steps disagree"
 
     t_max = elapsed
     total_count = count
