@@ -103,6 +103,9 @@ def test_device_side_parser_large_fastq_and_wrapped_fasta():
     n_reads = 200_000
     lens = rng.integers(30, 251, n_reads)
     seq = O.synth(5, int(lens.sum()))
+    seq[rng.integers(0, len(seq), len(seq) // 1000)] = ord("N")         # breaks, as real reads have them
+    low = rng.integers(0, len(seq), len(seq) // 20)
+    seq[low] |= 0x20                                                     # soft-masked (lower-case) bases
     offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
     parts = []
     for i in range(n_reads):
