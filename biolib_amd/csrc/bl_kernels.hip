@@ -426,6 +426,17 @@ static hipError_t launch_count_mode(const ScanParams& p, GroupRange g, hipStream
         hipLaunchKernelGGL((scan_count_kernel<MODE, 21, 11, 1>), grid, block, 0, stream, p, g);
         return hipGetLastError();
     }
+    if (MODE != MODE_SYNCMER) {
+        // more window sizes in registers for the minimizer / super-k-mer scans: the widths of minimap2's presets
+        // (k15 w10, k19 w19, k15/k19 w5); every other width runs the LDS-scan fallback (2-8x slower, W = 0)
+        constexpr int M2 = MODE == MODE_SYNCMER ? MODE_MINIMIZER : MODE;  // never instantiated for syncmers
+        switch (p.w) {
+            case 5: hipLaunchKernelGGL((scan_count_kernel<M2, 5, 0, -1>), grid, block, 0, stream, p, g); return hipGetLastError();
+            case 10: hipLaunchKernelGGL((scan_count_kernel<M2, 10, 0, -1>), grid, block, 0, stream, p, g); return hipGetLastError();
+            case 19: hipLaunchKernelGGL((scan_count_kernel<M2, 19, 0, -1>), grid, block, 0, stream, p, g); return hipGetLastError();
+            default: break;
+        }
+    }
     switch (p.w) {
         case 1: hipLaunchKernelGGL((scan_count_kernel<MODE, 1, 0, -1>), grid, block, 0, stream, p, g); break;
         case 11: hipLaunchKernelGGL((scan_count_kernel<MODE, 11, 0, -1>), grid, block, 0, stream, p, g); break;

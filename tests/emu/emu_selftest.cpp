@@ -70,7 +70,7 @@ static void check_case(const Case& c, std::mt19937_64& rng)
     unsigned long long res[8];
 
     struct MM { unsigned unit, w; uint64_t seed; int canon; };
-    const MM mms[] = {{31, 11, 42, 1}, {15, 17, 42, 1}, {11, 21, 0, 0}, {5, 4, 1, 1}, {32, 2, 9, 1}, {8, 1, 3, 0}, {1, 1, 0, 1},
+    const MM mms[] = {{31, 11, 42, 1}, {15, 17, 42, 1}, {15, 10, 7, 1}, {19, 19, 8, 1}, {21, 5, 9, 0}, {11, 21, 0, 0}, {5, 4, 1, 1}, {32, 2, 9, 1}, {8, 1, 3, 0}, {1, 1, 0, 1},
                       {32, 64, 5, 1}, {21, 33, 6, 0}, {3, 16, 7, 1}, {16, 17, 8, 0}};
     for (const MM& m : mms) {
         // whole batch
@@ -103,7 +103,7 @@ static void check_case(const Case& c, std::mt19937_64& rng)
     }
 
     struct SK { unsigned k, m; uint64_t seed; int canon; };
-    const SK sks[] = {{31, 15, 42, 1}, {21, 8, 0, 0}, {31, 31, 5, 1}, {31, 21, 1, 1}, {21, 11, 2, 0}, {32, 1, 3, 1}, {40, 9, 4, 1}};
+    const SK sks[] = {{31, 15, 42, 1}, {21, 8, 0, 0}, {24, 15, 6, 1}, {27, 9, 7, 1}, {19, 15, 8, 0}, {31, 31, 5, 1}, {31, 21, 1, 1}, {21, 11, 2, 0}, {32, 1, 3, 1}, {40, 9, 4, 1}};
     for (const SK& k : sks) {
         size_t cnt = blo_super_kmers(s, c.offsets.data(), n_seqs, k.k, k.m, k.seed, k.canon, ov.data(), of.data(), om.data(), os.data(),
                                      oh.data(), cap);

@@ -162,12 +162,13 @@ def test_all_scans_vs_oracle_random(ctx, flavour):
     for n in (0, 1, 40, 41, 4079, 4081, 20_000, 131_072 + 17):
         seq, offs = _random_case(rng, n, flavour)
         b = ctx.upload(seq, offs)
-        for (unit, w, seed, canon) in ((31, 11, 42, 1), (15, 17, 1, 0), (11, 21, 0, 1), (20, 7, 5, 1), (32, 64, 2, 1), (4, 1, 3, 0)):
+        for (unit, w, seed, canon) in ((31, 11, 42, 1), (15, 17, 1, 0), (11, 21, 0, 1), (20, 7, 5, 1), (32, 64, 2, 1), (4, 1, 3, 0), (15, 10, 6, 1), (19, 19, 7, 1),
+                                       (21, 5, 8, 0)):
             v, p, h = O.minimizers(seq, offs, unit, w, seed, canon, brute=False)
             got = b.minimizers(unit, w, seed=seed, canonical=bool(canon))
             assert got["count"] == len(v), (flavour, n, unit, w)
             assert np.array_equal(got["values"], v) and np.array_equal(got["positions"], p) and np.array_equal(got["hashes"], h)
-        for (k, m, seed, canon) in ((31, 15, 42, 1), (21, 8, 0, 0), (40, 9, 4, 1)):
+        for (k, m, seed, canon) in ((31, 15, 42, 1), (21, 8, 0, 0), (40, 9, 4, 1), (24, 15, 6, 1), (27, 9, 7, 0), (19, 15, 8, 1)):
             mn, fp, mp, sz, hs = O.super_kmers(seq, offs, k, m, seed, canon)
             got = b.super_kmers(k, m, seed=seed, canonical=bool(canon))
             assert got["count"] == len(mn) == got["aux"], (flavour, n, k, m)
@@ -305,7 +306,7 @@ def test_random_parameters_vs_oracle(ctx):
         flavour = ["plain", "breaks", "ragged", "reads", "mixed_repeats", "lowcomplexity"][int(rng.integers(6))]
         seq, offs = _random_case(rng, n, flavour)
         b = ctx.upload(seq, offs)
-        unit, w = int(rng.integers(1, 33)), int(rng.choice([1, 2, 3, 5, 8, 11, 16, 17, 21, 32, 33, 48, 64]))
+        unit, w = int(rng.integers(1, 33)), int(rng.choice([1, 2, 3, 5, 8, 10, 11, 16, 17, 19, 21, 32, 33, 48, 64]))
         seed, canon = int(rng.integers(0, 2**40)), bool(rng.integers(2))
         v, p, h = O.minimizers(seq, offs, unit, w, seed, canon, brute=False)
         got = b.minimizers(unit, w, seed=seed, canonical=canon)
