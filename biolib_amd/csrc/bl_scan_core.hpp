@@ -439,6 +439,50 @@ BL_DEV uint32_t window_argmin_packed(const uint32_t* key, uint32_t* a)
     return dmin;
 }
 
+// Runtime window size w, P < w <= 2P, P a power of two (template): a sparse table inside the lane.  log2(P) doubling
+// levels turn key[i] into the minimum over [i, i+P); window i is then min(key[i], key[i + w - P]).  Keys are packed
+// (top 25 hash bits | 7-bit position tag, leftmost wins a prefix tie); the return value is the smallest xor distance
+// between two DIFFERENT operands, as in window_argmin_packed (below 128 = a prefix tie = not exact).
+// key: NW + 2P - 1 entries; entries from NW + w - 1 on are never part of a wanted window and must be pads with
+// distinct prefixes (pad_key).  a[i] = the whole minimum key (position in the low 7 bits).
+template <int NW, int P>
+BL_DEV uint32_t window_argmin_doubling(uint32_t* key, int w, uint32_t* a)
+{
+    constexpr int NE = NW + 2 * P - 1;
+    uint32_t dmin = ~0u;
+    BL_UNROLL
+    for (int q = 1; q < P; q <<= 1) {  // after this level key[i] covers [i, i + 2q): disjoint operands, tags differ
+        BL_UNROLL
+        for (int i = 0; i + 2 * q <= NE; ++i) {
+            const uint32_t x = key[i], y = key[i + q], d = x ^ y;
+            key[i] = x < y ? x : y;
+            dmin = d < dmin ? d : dmin;
+        }
+    }
+    // t[i] = key[i + (w - P)]: shift by (w - P - 1) through log2(P) conditional stages, then by one
+    uint32_t t[NW + P];
+    BL_UNROLL
+    for (int i = 0; i < NW + P; ++i) t[i] = key[i];
+    const int sh = w - P - 1;  // 0 .. P-1
+    BL_UNROLL
+    for (int b = P >> 1; b >= 1; b >>= 1) {  // stage b needs t[i + b] for i < NW + b (what the later stages still read)
+        if (sh & b) {
+            BL_UNROLL
+            for (int i = 0; i < NW + b; ++i) t[i] = t[i + b];
+        }
+    }
+    BL_UNROLL
+    for (int i = 0; i < NW; ++i) {  // the two ranges overlap when w < 2P: the same element on both sides gives d = 0
+        const uint32_t x = key[i], y = t[i + 1], d = (x ^ y) - 1u;
+        a[i] = x < y ? x : y;
+        dmin = d < dmin ? d : dmin;
+    }
+    return dmin;
+}
+
+BL_DEV uint32_t packed_key7(uint32_t hash_hi, int x) { return (hash_hi & ~127u) | (uint32_t)x; }
+BL_DEV uint32_t pad_key7(int x) { return ((0x1ffffffu - (uint32_t)x) << 7) | (uint32_t)x; }
+
 BL_DEV uint32_t packed_key(uint32_t hash_hi, int x, bool left) { return (hash_hi & ~63u) | (uint32_t)(left ? x : 63 - x); }
 
 }  // namespace bl

@@ -357,6 +357,27 @@ BL_DEV void window_argmin_lds(const TileShared<MODE, W>& sh, int tid, int w, int
     }
 }
 
+// Runtime window size, fast form (minimizer / super-k-mer scans of the W = 0 kernels): the lane's NW + w - 1 hashes are
+// in LDS already (phase_hash, W == 0), their high dwords become packed keys and window_argmin_doubling<P> finds the
+// argmins in registers; a prefix tie in an owning lane sends the wave through the exact LDS scan (window_argmin_lds).
+template <int MODE, int W, int NW, int P>
+BL_DEV void lane_window_argmin_generic(const TileShared<MODE, W>& sh, int tid, int w, bool owns, uint32_t* a)
+{
+    constexpr int NE = NW + 2 * P - 1;
+    const int lane = tid & 63, wbase = tid & ~63;
+    const uint32_t* hash32 = reinterpret_cast<const uint32_t*>(&sh.hash[0][0]);
+    uint32_t key[NE];
+    BL_UNROLL
+    for (int x = 0; x < NE; ++x) {
+        int pos = 16 * lane + x;        // wave-relative position
+        pos = pos < WH ? pos : WH - 1;  // beyond the wave tile: never part of an owned window
+        const uint32_t hi = hash32[2 * ((pos & 15) * (W == 0 ? TPB : 1) + wbase + (pos >> 4)) + 1];
+        key[x] = (x < NW + P || x < NW + w - 1) ? packed_key7(hi, x) : pad_key7(x);  // x < NW + P is always wanted (w > P)
+    }
+    const uint32_t dmin = window_argmin_doubling<NW, P>(key, w, a);
+    if (wave_any(owns && dmin < 128u)) window_argmin_lds<MODE, W, true>(sh, tid, w, NW, a);
+}
+
 // bit s: lane owns wave position 16*lane + s
 BL_DEV uint32_t owned_mask(const ScanParams& p, int lane)
 {
@@ -390,6 +411,14 @@ BL_DEV uint32_t phase_window(const ScanParams& p, const TileShared<MODE, W>& sh,
             for (int s = 0; s <= S; ++s)
                 if (e[s] < p.hash_below) below |= 1u << s;
         }
+    } else if (w >= 2) {
+        const bool owns = owned_mask(p, tid & 63) != 0;
+        if (w <= 2) lane_window_argmin_generic<MODE, W, S + 1, 1>(sh, tid, w, owns, a);
+        else if (w <= 4) lane_window_argmin_generic<MODE, W, S + 1, 2>(sh, tid, w, owns, a);
+        else if (w <= 8) lane_window_argmin_generic<MODE, W, S + 1, 4>(sh, tid, w, owns, a);
+        else if (w <= 16) lane_window_argmin_generic<MODE, W, S + 1, 8>(sh, tid, w, owns, a);
+        else if (w <= 32) lane_window_argmin_generic<MODE, W, S + 1, 16>(sh, tid, w, owns, a);
+        else lane_window_argmin_generic<MODE, W, S + 1, 32>(sh, tid, w, owns, a);
     } else {
         window_argmin_lds<MODE, W, true>(sh, tid, w, S + 1, a);
     }
