@@ -115,7 +115,7 @@ __device__ __forceinline__ void count_tile(const ScanParams& p, TileShared<MODE,
 
     ThreadState st;
     phase_hash<MODE, W>(p, sh, tid, st);
-    if (W == 0) __syncthreads();  // runtime-w fallback exchanges hashes through LDS
+    if (W == 0 && MODE == MODE_SYNCMER) __syncthreads();  // runtime-w syncmers exchange hashes through LDS
 
     uint32_t packed;
     if (MODE == MODE_SYNCMER) {
@@ -192,12 +192,12 @@ __device__ __forceinline__ void emit_tile(const ScanParams& p, TileShared<MODE, 
 // parameter block is copied and the fields overwritten with constants, which the inlined phases fold
 // (constant shifts and masks in the roller, no strand selects).  U = 0 / C = -1: taken from the arguments.
 template <int MODE, int W, int U, int C>
-__global__ __launch_bounds__(TPB, (MODE == MODE_SYNCMER || W == 0 ? 2 : (W <= 11 ? 5 : 4))) void scan_count_kernel(const ScanParams pin, GroupRange g)
+__global__ __launch_bounds__(TPB, (MODE == MODE_SYNCMER || W == 0 || (MODE == MODE_SUPERKMER && W < 0) ? 2 : (W < 0 ? 3 : (W <= 11 ? 5 : 4)))) void scan_count_kernel(const ScanParams pin, GroupRange g)
 {
     __shared__ TileShared<MODE, W> sh;
     ScanParams p = pin;
     if (U != 0) p.unit = U;
-    if (W != 0) {
+    if (W > 0) {
         p.w = W;
         p.stride = NWAVE * (64 * S - 16 * ((W + 15) / 16));  // plan_scan's value, as a constant
     }
@@ -442,7 +442,16 @@ static hipError_t launch_count_mode(const ScanParams& p, GroupRange g, hipStream
         case 11: hipLaunchKernelGGL((scan_count_kernel<MODE, 11, 0, -1>), grid, block, 0, stream, p, g); break;
         case 17: hipLaunchKernelGGL((scan_count_kernel<MODE, 17, 0, -1>), grid, block, 0, stream, p, g); break;
         case 21: hipLaunchKernelGGL((scan_count_kernel<MODE, 21, 0, -1>), grid, block, 0, stream, p, g); break;
-        default: hipLaunchKernelGGL((scan_count_kernel<MODE, 0, 0, -1>), grid, block, 0, stream, p, g); break;
+        default:
+            if (MODE == MODE_SYNCMER) {  // runtime-w syncmers: the LDS scan
+                hipLaunchKernelGGL((scan_count_kernel<MODE, 0, 0, -1>), grid, block, 0, stream, p, g);
+            } else {                     // runtime-w minimizers / super-k-mers: sparse-table argmin, one kernel per size group
+                constexpr int M2 = MODE == MODE_SYNCMER ? MODE_MINIMIZER : MODE;
+                if (p.w <= 16) hipLaunchKernelGGL((scan_count_kernel<M2, -8, 0, -1>), grid, block, 0, stream, p, g);
+                else if (p.w <= 32) hipLaunchKernelGGL((scan_count_kernel<M2, -16, 0, -1>), grid, block, 0, stream, p, g);
+                else hipLaunchKernelGGL((scan_count_kernel<M2, -32, 0, -1>), grid, block, 0, stream, p, g);
+            }
+            break;
     }
     return hipGetLastError();
 }

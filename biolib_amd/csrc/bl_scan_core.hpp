@@ -445,37 +445,73 @@ BL_DEV uint32_t window_argmin_packed(const uint32_t* key, uint32_t* a)
 // between two DIFFERENT operands, as in window_argmin_packed (below 128 = a prefix tie = not exact).
 // key: NW + 2P - 1 entries; entries from NW + w - 1 on are never part of a wanted window and must be pads with
 // distinct prefixes (pad_key).  a[i] = the whole minimum key (position in the low 7 bits).
+// acc = min(acc, d), opaque to the optimizer: left as plain C++ the long chain of minima is reassociated into a tree
+// whose leaves (one xor per step of a level) are then all alive at once — 155-256 VGPRs instead of ~90
+BL_DEV void fold_min(uint32_t& acc, uint32_t d)
+{
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(BL_CPU_EMU)
+    asm("v_min_u32_e32 %0, %1, %0" : "+v"(acc) : "v"(d));
+#else
+    acc = d < acc ? d : acc;
+#endif
+}
+
+// one doubling level with a compile-time stride (a loop over q = 1, 2, 4 .. is not unrolled by the compiler, which
+// turns key[] into a dynamically indexed array)
+template <int NE, int Q>
+BL_DEV void doubling_level(uint32_t* key, uint32_t& dmin)
+{
+    BL_UNROLL
+    for (int i = 0; i + 2 * Q <= NE; ++i) {
+        const uint32_t x = key[i], y = key[i + Q];
+        key[i] = x < y ? x : y;
+        fold_min(dmin, x ^ y);
+    }
+}
+
+template <int N, int B>
+BL_DEV void shift_stage(uint32_t* t, int sh)  // t[i] = t[i + B] for i < N when bit B of sh is set
+{
+    if (sh & B) {
+        BL_UNROLL
+        for (int i = 0; i < N; ++i) t[i] = t[i + B];
+    }
+}
+
 template <int NW, int P>
 BL_DEV uint32_t window_argmin_doubling(uint32_t* key, int w, uint32_t* a)
 {
     constexpr int NE = NW + 2 * P - 1;
     uint32_t dmin = ~0u;
-    BL_UNROLL
-    for (int q = 1; q < P; q <<= 1) {  // after this level key[i] covers [i, i + 2q): disjoint operands, tags differ
+    // after level q key[i] covers [i, i + 2q): disjoint operands, tags differ
+    if (P > 1) doubling_level<NE, 1>(key, dmin);
+    if (P > 2) doubling_level<NE, 2>(key, dmin);
+    if (P > 4) doubling_level<NE, 4>(key, dmin);
+    if (P > 8) doubling_level<NE, 8>(key, dmin);
+    if (P > 16) doubling_level<NE, 16>(key, dmin);
+    // t[i] = key[i + (w - P - 1)]: the shift amount, 0 .. P-1, is applied bit by bit (uniform branches over register
+    // moves); the first stage reads key[] directly so that t[] needs NW + P/2 entries only
+    constexpr int H = P > 1 ? P / 2 : 0;
+    constexpr int NT = NW + (H ? H : 1);
+    uint32_t t[NT];
+    const int sh = w - P - 1;
+    if (H && (sh & H)) {
         BL_UNROLL
-        for (int i = 0; i + 2 * q <= NE; ++i) {
-            const uint32_t x = key[i], y = key[i + q], d = x ^ y;
-            key[i] = x < y ? x : y;
-            dmin = d < dmin ? d : dmin;
-        }
+        for (int i = 0; i < NT; ++i) t[i] = key[i + H];
+    } else {
+        BL_UNROLL
+        for (int i = 0; i < NT; ++i) t[i] = key[i];
     }
-    // t[i] = key[i + (w - P)]: shift by (w - P - 1) through log2(P) conditional stages, then by one
-    uint32_t t[NW + P];
-    BL_UNROLL
-    for (int i = 0; i < NW + P; ++i) t[i] = key[i];
-    const int sh = w - P - 1;  // 0 .. P-1
-    BL_UNROLL
-    for (int b = P >> 1; b >= 1; b >>= 1) {  // stage b needs t[i + b] for i < NW + b (what the later stages still read)
-        if (sh & b) {
-            BL_UNROLL
-            for (int i = 0; i < NW + b; ++i) t[i] = t[i + b];
-        }
-    }
+    // stage b keeps t[0 .. NW + b) valid: exactly what the later stages still read
+    if (H > 8) shift_stage<NW + 8, 8>(t, sh);
+    if (H > 4) shift_stage<NW + 4, 4>(t, sh);
+    if (H > 2) shift_stage<NW + 2, 2>(t, sh);
+    if (H > 1) shift_stage<NW + 1, 1>(t, sh);
     BL_UNROLL
     for (int i = 0; i < NW; ++i) {  // the two ranges overlap when w < 2P: the same element on both sides gives d = 0
-        const uint32_t x = key[i], y = t[i + 1], d = (x ^ y) - 1u;
+        const uint32_t x = key[i], y = t[i + 1];
         a[i] = x < y ? x : y;
-        dmin = d < dmin ? d : dmin;
+        fold_min(dmin, (x ^ y) - 1u);
     }
     return dmin;
 }

@@ -29,7 +29,7 @@ struct TileShared {
     // (consecutive wave tiles overlap by their halo, so the halo of a wave is the next wave's data)
     uint32_t codes[NCHUNK];         // 2-bit codes, 16 bases per dword, first base most significant
     uint32_t flags[NCHUNK];         // [15:0] good-base bits, [31:16] sequence-start bits (bit b = base b)
-    uint64_t hash[W == 0 ? S : 1][W == 0 ? TPB : 1];  // runtime-w fallback only: hash[s][tid]
+    uint64_t hash[W <= 0 ? S : 1][W <= 0 ? TPB : 1];  // runtime-w kernels (W <= 0) only: hash[s][tid]
     alignas(4) uint16_t list_a[H];  // compacted records: (wave << 12) | wave-relative argmin position
                                     // (syncmer mode: the k-mer's own position)
     alignas(4) uint16_t list_j[MODE == MODE_SUPERKMER ? H : 2];  // compacted: first window of the occurrence
@@ -197,7 +197,7 @@ BL_DEV void phase_hash(const ScanParams& p, TileShared<MODE, W>& sh, int tid, Th
             st.h[s] = murmur64(v, p.seed);
         }
     }
-    if (W == 0) {  // runtime-w fallback keeps the hashes in LDS
+    if (W == 0 && MODE == MODE_SYNCMER) {  // runtime-w syncmers scan the hashes in LDS (minimizer modes: only on a tie)
         BL_UNROLL
         for (int s = 0; s < S; ++s) sh.hash[s][tid] = st.h[s];
     }
@@ -357,25 +357,81 @@ BL_DEV void window_argmin_lds(const TileShared<MODE, W>& sh, int tid, int w, int
     }
 }
 
-// Runtime window size, fast form (minimizer / super-k-mer scans of the W = 0 kernels): the lane's NW + w - 1 hashes are
-// in LDS already (phase_hash, W == 0), their high dwords become packed keys and window_argmin_doubling<P> finds the
-// argmins in registers; a prefix tie in an owning lane sends the wave through the exact LDS scan (window_argmin_lds).
-template <int MODE, int W, int NW, int P>
-BL_DEV void lane_window_argmin_generic(const TileShared<MODE, W>& sh, int tid, int w, bool owns, uint32_t* a)
+// the same scan with the window count as a template parameter: a[] is then indexed statically and can stay in the
+// registers the fast form left it in (a run-time loop over i turns it into an indexable array and costs ~150 VGPRs)
+template <int MODE, int W, bool LEFT, int NW>
+BL_DEV void window_argmin_lds_fixed(const TileShared<MODE, W>& sh, int tid, int w, uint32_t* a)
 {
-    constexpr int NE = NW + 2 * P - 1;
-    const int lane = tid & 63, wbase = tid & ~63;
-    const uint32_t* hash32 = reinterpret_cast<const uint32_t*>(&sh.hash[0][0]);
+    const int wbase = tid & ~63;
+    BL_UNROLL
+    for (int i = 0; i < NW; ++i) {
+        uint64_t best = 0;
+        int arg = 0;
+        for (int x = 0; x < w; ++x) {
+            int pos = 16 * (tid & 63) + i + x;
+            pos = pos < WH ? pos : WH - 1;
+            const uint64_t v = sh.hash[pos & 15][wbase + (pos >> 4)];
+            const bool take = x == 0 || (LEFT ? v < best : v <= best);
+            if (take) { best = v; arg = i + x; }
+        }
+        a[i] = (uint32_t)arg;
+    }
+}
+
+// Runtime window size, fast form (minimizer / super-k-mer scans of the W = 0 kernels): packed keys of the lane's own
+// 16 hashes and of the 2P that follow (DPP hops, as in the templated form; 7-bit tags) go through
+// window_argmin_doubling<P> in registers.  A prefix tie in an owning lane sends the wave through the exact scan: only
+// then are the wave's hashes written to LDS (wave-local region, no workgroup barrier) for window_argmin_lds.
+template <int MODE, int W, int NW, int P>
+BL_DEV void lane_window_argmin_generic(const ScanParams& p, TileShared<MODE, W>& sh, const ThreadState* all, int tid, ThreadState& st, int w, bool owns,
+                                       uint32_t* a)
+{
+    constexpr int NE = NW + 2 * P - 1, NH = NE - S;  // NH halo elements
     uint32_t key[NE];
     BL_UNROLL
-    for (int x = 0; x < NE; ++x) {
-        int pos = 16 * lane + x;        // wave-relative position
-        pos = pos < WH ? pos : WH - 1;  // beyond the wave tile: never part of an owned window
-        const uint32_t hi = hash32[2 * ((pos & 15) * (W == 0 ? TPB : 1) + wbase + (pos >> 4)) + 1];
-        key[x] = (x < NW + P || x < NW + w - 1) ? packed_key7(hi, x) : pad_key7(x);  // x < NW + P is always wanted (w > P)
+    for (int s = 0; s < S; ++s) key[s] = packed_key7((uint32_t)(st.h[s] >> 32), s);
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(BL_CPU_EMU)
+    (void)all;
+    {
+        uint32_t cur[S];
+        BL_UNROLL
+        for (int x = 0; x < S; ++x) cur[x] = key[x];
+        BL_UNROLL
+        for (int hop = 0; hop * S < NH; ++hop) {
+            BL_UNROLL
+            for (int x = 0; x < S; ++x) {
+                if (hop * S + x < NH || (hop + 1) * S + x < NH || (hop + 2) * S + x < NH || (hop + 3) * S + x < NH || (hop + 4) * S + x < NH)
+                    cur[x] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cur[x], 0x130, 0xf, 0xf, false) + 16u;
+                if (hop * S + x < NH) key[(hop + 1) * S + x] = cur[x];
+            }
+        }
     }
+#else
+    {
+        const int lane = tid & 63;
+        for (int x = 0; x < NH; ++x) {
+            const int nb = lane + 1 + (x >> 4);
+            const uint32_t hi = nb < 64 ? (uint32_t)(all[tid + 1 + (x >> 4)].h[x & 15] >> 32) : 0xDEADBEEFu;
+            key[S + x] = packed_key7(hi, S + x);
+        }
+    }
+#endif
+    BL_UNROLL
+    for (int x = NW + P; x < NE; ++x)  // beyond the last wanted element (runtime: w): pads that never win and never tie
+        if (x >= NW + w - 1) key[x] = pad_key7(x);
     const uint32_t dmin = window_argmin_doubling<NW, P>(key, w, a);
-    if (wave_any(owns && dmin < 128u)) window_argmin_lds<MODE, W, true>(sh, tid, w, NW, a);
+    if (wave_any(owns && dmin < 128u)) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(BL_CPU_EMU)
+        // the full hashes were dropped after packing (they would pin 32 registers through the fast path): redo them
+        phase_hash<MODE, W>(p, sh, tid, st);
+        BL_UNROLL
+        for (int s = 0; s < S; ++s) sh.hash[s][W <= 0 ? tid : 0] = st.h[s];  // same wave writes, same wave reads: LDS keeps program order
+#else
+        for (int t = tid & ~63; t < (tid & ~63) + 64; ++t)
+            for (int s = 0; s < S; ++s) sh.hash[s][W <= 0 ? t : 0] = all[t].h[s];
+#endif
+        window_argmin_lds_fixed<MODE, W, true, NW>(sh, tid, w, a);
+    }
 }
 
 // bit s: lane owns wave position 16*lane + s
@@ -389,11 +445,11 @@ BL_DEV uint32_t owned_mask(const ScanParams& p, int lane)
 // Phase 3 (minimizer / super-k-mer): window argmins, validity, start/end decisions.
 // Returns the packed per-thread counts: starts | ends << 16.
 template <int MODE, int W>
-BL_DEV uint32_t phase_window(const ScanParams& p, const TileShared<MODE, W>& sh, int tid, int64_t q0, ThreadState& st,
+BL_DEV uint32_t phase_window(const ScanParams& p, TileShared<MODE, W>& sh, int tid, int64_t q0, ThreadState& st,
                              const ThreadState* all)
 {
     const int wv = wave_index(tid), lane = tid & 63;
-    const int w = W ? W : p.w;
+    const int w = W > 0 ? W : p.w;
     uint32_t a[S + 1];
     uint32_t below = 0x1ffffu;  // w = 1 with a hash threshold (hash_sampler): bit s = hash of unit s is below it
     if (W > 1) {
@@ -411,14 +467,20 @@ BL_DEV uint32_t phase_window(const ScanParams& p, const TileShared<MODE, W>& sh,
             for (int s = 0; s <= S; ++s)
                 if (e[s] < p.hash_below) below |= 1u << s;
         }
-    } else if (w >= 2) {
+    } else if (w >= 2 && W < 0) {
+        // runtime w, grouped by kernel so that a small window does not pay for the registers of a large one:
+        // W = -8 : w <= 16, W = -16 : 17..32, W = -32 : 33..64 (launch_count_mode picks the kernel)
         const bool owns = owned_mask(p, tid & 63) != 0;
-        if (w <= 2) lane_window_argmin_generic<MODE, W, S + 1, 1>(sh, tid, w, owns, a);
-        else if (w <= 4) lane_window_argmin_generic<MODE, W, S + 1, 2>(sh, tid, w, owns, a);
-        else if (w <= 8) lane_window_argmin_generic<MODE, W, S + 1, 4>(sh, tid, w, owns, a);
-        else if (w <= 16) lane_window_argmin_generic<MODE, W, S + 1, 8>(sh, tid, w, owns, a);
-        else if (w <= 32) lane_window_argmin_generic<MODE, W, S + 1, 16>(sh, tid, w, owns, a);
-        else lane_window_argmin_generic<MODE, W, S + 1, 32>(sh, tid, w, owns, a);
+        if (W == -8) {
+            if (w <= 2) lane_window_argmin_generic<MODE, W, S + 1, 1>(p, sh, all, tid, st, w, owns, a);
+            else if (w <= 4) lane_window_argmin_generic<MODE, W, S + 1, 2>(p, sh, all, tid, st, w, owns, a);
+            else if (w <= 8) lane_window_argmin_generic<MODE, W, S + 1, 4>(p, sh, all, tid, st, w, owns, a);
+            else lane_window_argmin_generic<MODE, W, S + 1, 8>(p, sh, all, tid, st, w, owns, a);
+        } else if (W == -16) {
+            lane_window_argmin_generic<MODE, W, S + 1, 16>(p, sh, all, tid, st, w, owns, a);
+        } else {
+            lane_window_argmin_generic<MODE, W, S + 1, 32>(p, sh, all, tid, st, w, owns, a);
+        }
     } else {
         window_argmin_lds<MODE, W, true>(sh, tid, w, S + 1, a);
     }
@@ -490,7 +552,7 @@ BL_DEV uint32_t phase_sync_rev(const ScanParams& p, const TileShared<MODE, W>& s
                                const ThreadState* all, const uint32_t* af)
 {
     const int wv = wave_index(tid), lane = tid & 63;
-    const int w = W ? W : p.w;
+    const int w = W > 0 ? W : p.w;
     const int k = p.unit + w - 1;
     uint32_t ar[S + 1];
     if (p.canonical) {

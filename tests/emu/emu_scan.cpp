@@ -123,7 +123,12 @@ void run_mode(const ScanParams& p, unsigned long long* result)
         case 11: run_tiles<MODE, 11>(p, result); break;
         case 17: run_tiles<MODE, 17>(p, result); break;
         case 21: run_tiles<MODE, 21>(p, result); break;
-        default: run_tiles<MODE, 0>(p, result); break;
+        default:
+            if (MODE == MODE_SYNCMER) run_tiles<MODE, 0>(p, result);
+            else if (p.w <= 16) run_tiles<MODE, -8>(p, result);
+            else if (p.w <= 32) run_tiles<MODE, -16>(p, result);
+            else run_tiles<MODE, -32>(p, result);
+            break;
     }
 }
 
