@@ -443,14 +443,10 @@ static hipError_t launch_count_mode(const ScanParams& p, GroupRange g, hipStream
         case 17: hipLaunchKernelGGL((scan_count_kernel<MODE, 17, 0, -1>), grid, block, 0, stream, p, g); break;
         case 21: hipLaunchKernelGGL((scan_count_kernel<MODE, 21, 0, -1>), grid, block, 0, stream, p, g); break;
         default:
-            if (MODE == MODE_SYNCMER) {  // runtime-w syncmers: the LDS scan
-                hipLaunchKernelGGL((scan_count_kernel<MODE, 0, 0, -1>), grid, block, 0, stream, p, g);
-            } else {                     // runtime-w minimizers / super-k-mers: sparse-table argmin, one kernel per size group
-                constexpr int M2 = MODE == MODE_SYNCMER ? MODE_MINIMIZER : MODE;
-                if (p.w <= 16) hipLaunchKernelGGL((scan_count_kernel<M2, -8, 0, -1>), grid, block, 0, stream, p, g);
-                else if (p.w <= 32) hipLaunchKernelGGL((scan_count_kernel<M2, -16, 0, -1>), grid, block, 0, stream, p, g);
-                else hipLaunchKernelGGL((scan_count_kernel<M2, -32, 0, -1>), grid, block, 0, stream, p, g);
-            }
+            // runtime window size: sparse-table argmin in registers, one kernel per size group
+            if (p.w <= 16) hipLaunchKernelGGL((scan_count_kernel<MODE, -8, 0, -1>), grid, block, 0, stream, p, g);
+            else if (p.w <= 32) hipLaunchKernelGGL((scan_count_kernel<MODE, -16, 0, -1>), grid, block, 0, stream, p, g);
+            else hipLaunchKernelGGL((scan_count_kernel<MODE, -32, 0, -1>), grid, block, 0, stream, p, g);
             break;
     }
     return hipGetLastError();

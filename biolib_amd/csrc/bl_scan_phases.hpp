@@ -357,6 +357,13 @@ BL_DEV void window_argmin_lds(const TileShared<MODE, W>& sh, int tid, int w, int
     }
 }
 
+// bit s: lane owns wave position 16*lane + s
+BL_DEV uint32_t owned_mask(const ScanParams& p, int lane)
+{
+    const int own = p.stride / NWAVE - 16 * lane;
+    return own >= S ? 0xffffu : (own > 0 ? (1u << own) - 1 : 0u);
+}
+
 // the same scan with the window count as a template parameter: a[] is then indexed statically and can stay in the
 // registers the fast form left it in (a run-time loop over i turns it into an indexable array and costs ~150 VGPRs)
 template <int MODE, int W, bool LEFT, int NW>
@@ -382,14 +389,17 @@ BL_DEV void window_argmin_lds_fixed(const TileShared<MODE, W>& sh, int tid, int 
 // 16 hashes and of the 2P that follow (DPP hops, as in the templated form; 7-bit tags) go through
 // window_argmin_doubling<P> in registers.  A prefix tie in an owning lane sends the wave through the exact scan: only
 // then are the wave's hashes written to LDS (wave-local region, no workgroup barrier) for window_argmin_lds.
-template <int MODE, int W, int NW, int P>
+// LEFT = false (rightmost wins, tags 127 - x) and SECOND (st.h2) serve the reverse-strand pass of the syncmer scan, whose
+// ThreadState keeps both hash arrays alive anyway; the minimizer scans (REDO) drop st.h after packing and recompute it in
+// the rare exact branch.  a[] = argmin positions (plain indices) for the syncmer callers, raw keys for RAW.
+template <int MODE, int W, int NW, int P, bool LEFT, bool SECOND, bool RAW>
 BL_DEV void lane_window_argmin_generic(const ScanParams& p, TileShared<MODE, W>& sh, const ThreadState* all, int tid, ThreadState& st, int w, bool owns,
                                        uint32_t* a)
 {
     constexpr int NE = NW + 2 * P - 1, NH = NE - S;  // NH halo elements
     uint32_t key[NE];
     BL_UNROLL
-    for (int s = 0; s < S; ++s) key[s] = packed_key7((uint32_t)(st.h[s] >> 32), s);
+    for (int s = 0; s < S; ++s) key[s] = packed_key7((uint32_t)((SECOND ? st.h2[s] : st.h[s]) >> 32), LEFT ? s : 127 - s);
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(BL_CPU_EMU)
     (void)all;
     {
@@ -400,8 +410,10 @@ BL_DEV void lane_window_argmin_generic(const ScanParams& p, TileShared<MODE, W>&
         for (int hop = 0; hop * S < NH; ++hop) {
             BL_UNROLL
             for (int x = 0; x < S; ++x) {
-                if (hop * S + x < NH || (hop + 1) * S + x < NH || (hop + 2) * S + x < NH || (hop + 3) * S + x < NH || (hop + 4) * S + x < NH)
-                    cur[x] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cur[x], 0x130, 0xf, 0xf, false) + 16u;
+                if (hop * S + x < NH || (hop + 1) * S + x < NH || (hop + 2) * S + x < NH || (hop + 3) * S + x < NH || (hop + 4) * S + x < NH) {
+                    const uint32_t nb = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cur[x], 0x130, 0xf, 0xf, false);
+                    cur[x] = LEFT ? nb + 16u : nb - 16u;
+                }
                 if (hop * S + x < NH) key[(hop + 1) * S + x] = cur[x];
             }
         }
@@ -411,8 +423,8 @@ BL_DEV void lane_window_argmin_generic(const ScanParams& p, TileShared<MODE, W>&
         const int lane = tid & 63;
         for (int x = 0; x < NH; ++x) {
             const int nb = lane + 1 + (x >> 4);
-            const uint32_t hi = nb < 64 ? (uint32_t)(all[tid + 1 + (x >> 4)].h[x & 15] >> 32) : 0xDEADBEEFu;
-            key[S + x] = packed_key7(hi, S + x);
+            const uint64_t hv = nb < 64 ? (SECOND ? all[tid + 1 + (x >> 4)].h2[x & 15] : all[tid + 1 + (x >> 4)].h[x & 15]) : 0xDEADBEEFDEADBEEFull;
+            key[S + x] = packed_key7((uint32_t)(hv >> 32), LEFT ? S + x : 127 - (S + x));
         }
     }
 #endif
@@ -420,26 +432,41 @@ BL_DEV void lane_window_argmin_generic(const ScanParams& p, TileShared<MODE, W>&
     for (int x = NW + P; x < NE; ++x)  // beyond the last wanted element (runtime: w): pads that never win and never tie
         if (x >= NW + w - 1) key[x] = pad_key7(x);
     const uint32_t dmin = window_argmin_doubling<NW, P>(key, w, a);
+    if (!RAW) {
+        BL_UNROLL
+        for (int i = 0; i < NW; ++i) a[i] = LEFT ? (a[i] & 127u) : 127u - (a[i] & 127u);
+    }
     if (wave_any(owns && dmin < 128u)) {
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(BL_CPU_EMU)
-        // the full hashes were dropped after packing (they would pin 32 registers through the fast path): redo them
-        phase_hash<MODE, W>(p, sh, tid, st);
+        // minimizer scans dropped the full hashes after packing (they would pin 32 registers through the fast path)
+        if (MODE != MODE_SYNCMER) phase_hash<MODE, W>(p, sh, tid, st);
         BL_UNROLL
-        for (int s = 0; s < S; ++s) sh.hash[s][W <= 0 ? tid : 0] = st.h[s];  // same wave writes, same wave reads: LDS keeps program order
+        for (int s = 0; s < S; ++s) sh.hash[s][W <= 0 ? tid : 0] = SECOND ? st.h2[s] : st.h[s];  // same wave writes, same wave reads
 #else
         for (int t = tid & ~63; t < (tid & ~63) + 64; ++t)
-            for (int s = 0; s < S; ++s) sh.hash[s][W <= 0 ? t : 0] = all[t].h[s];
+            for (int s = 0; s < S; ++s) sh.hash[s][W <= 0 ? t : 0] = SECOND ? all[t].h2[s] : all[t].h[s];
 #endif
-        window_argmin_lds_fixed<MODE, W, true, NW>(sh, tid, w, a);
+        window_argmin_lds_fixed<MODE, W, LEFT, NW>(sh, tid, w, a);
     }
 }
 
-// bit s: lane owns wave position 16*lane + s
-BL_DEV uint32_t owned_mask(const ScanParams& p, int lane)
+// picks the doubling width for a run-time window size inside the size group of the kernel (W = -8 / -16 / -32)
+template <int MODE, int W, int NW, bool LEFT, bool SECOND, bool RAW>
+BL_DEV void window_argmin_runtime(const ScanParams& p, TileShared<MODE, W>& sh, const ThreadState* all, int tid, ThreadState& st, int w, uint32_t* a)
 {
-    const int own = p.stride / NWAVE - 16 * lane;
-    return own >= S ? 0xffffu : (own > 0 ? (1u << own) - 1 : 0u);
+    const bool owns = owned_mask(p, tid & 63) != 0;
+    if (W == -8) {
+        if (w <= 2) lane_window_argmin_generic<MODE, W, NW, 1, LEFT, SECOND, RAW>(p, sh, all, tid, st, w, owns, a);
+        else if (w <= 4) lane_window_argmin_generic<MODE, W, NW, 2, LEFT, SECOND, RAW>(p, sh, all, tid, st, w, owns, a);
+        else if (w <= 8) lane_window_argmin_generic<MODE, W, NW, 4, LEFT, SECOND, RAW>(p, sh, all, tid, st, w, owns, a);
+        else lane_window_argmin_generic<MODE, W, NW, 8, LEFT, SECOND, RAW>(p, sh, all, tid, st, w, owns, a);
+    } else if (W == -16) {
+        lane_window_argmin_generic<MODE, W, NW, 16, LEFT, SECOND, RAW>(p, sh, all, tid, st, w, owns, a);
+    } else {
+        lane_window_argmin_generic<MODE, W, NW, 32, LEFT, SECOND, RAW>(p, sh, all, tid, st, w, owns, a);
+    }
 }
+
 
 // ------------------------------------------------------------------------------------------------
 // Phase 3 (minimizer / super-k-mer): window argmins, validity, start/end decisions.
@@ -468,19 +495,8 @@ BL_DEV uint32_t phase_window(const ScanParams& p, TileShared<MODE, W>& sh, int t
                 if (e[s] < p.hash_below) below |= 1u << s;
         }
     } else if (w >= 2 && W < 0) {
-        // runtime w, grouped by kernel so that a small window does not pay for the registers of a large one:
-        // W = -8 : w <= 16, W = -16 : 17..32, W = -32 : 33..64 (launch_count_mode picks the kernel)
-        const bool owns = owned_mask(p, tid & 63) != 0;
-        if (W == -8) {
-            if (w <= 2) lane_window_argmin_generic<MODE, W, S + 1, 1>(p, sh, all, tid, st, w, owns, a);
-            else if (w <= 4) lane_window_argmin_generic<MODE, W, S + 1, 2>(p, sh, all, tid, st, w, owns, a);
-            else if (w <= 8) lane_window_argmin_generic<MODE, W, S + 1, 4>(p, sh, all, tid, st, w, owns, a);
-            else lane_window_argmin_generic<MODE, W, S + 1, 8>(p, sh, all, tid, st, w, owns, a);
-        } else if (W == -16) {
-            lane_window_argmin_generic<MODE, W, S + 1, 16>(p, sh, all, tid, st, w, owns, a);
-        } else {
-            lane_window_argmin_generic<MODE, W, S + 1, 32>(p, sh, all, tid, st, w, owns, a);
-        }
+        // runtime w: W = -8 : w <= 16, W = -16 : 17..32, W = -32 : 33..64 (launch_count_mode picks the kernel)
+        window_argmin_runtime<MODE, W, S + 1, true, false, true>(p, sh, all, tid, st, w, a);
     } else {
         window_argmin_lds<MODE, W, true>(sh, tid, w, S + 1, a);
     }
@@ -534,10 +550,12 @@ BL_DEV uint32_t phase_window(const ScanParams& p, TileShared<MODE, W>& sh, int t
 // Phase 3 (syncmer): leftmost minimum over the forward s-mer hashes, rightmost over the reverse ones.
 // `pass` is only used by the runtime-w fallback, which republishes the LDS hashes between the two.
 template <int MODE, int W>
-BL_DEV void phase_sync_fwd(const ScanParams& p, const TileShared<MODE, W>& sh, int tid, ThreadState& st, const ThreadState* all,
+BL_DEV void phase_sync_fwd(const ScanParams& p, TileShared<MODE, W>& sh, int tid, ThreadState& st, const ThreadState* all,
                            uint32_t* af)
 {
-    if (W > 1) {
+    if (W < 0 && p.w >= 2) {
+        window_argmin_runtime<MODE, W, S, true, false, false>(p, sh, all, tid, st, p.w, af);
+    } else if (W > 1) {
         lane_window_argmin<S, (W > 1 ? W : 2), true, false>(all, tid, st, owned_mask(p, tid & 63) != 0, af);
     } else if (W == 1) {
         BL_UNROLL
@@ -548,7 +566,7 @@ BL_DEV void phase_sync_fwd(const ScanParams& p, const TileShared<MODE, W>& sh, i
 }
 
 template <int MODE, int W>
-BL_DEV uint32_t phase_sync_rev(const ScanParams& p, const TileShared<MODE, W>& sh, int tid, int64_t q0, ThreadState& st,
+BL_DEV uint32_t phase_sync_rev(const ScanParams& p, TileShared<MODE, W>& sh, int tid, int64_t q0, ThreadState& st,
                                const ThreadState* all, const uint32_t* af)
 {
     const int wv = wave_index(tid), lane = tid & 63;
@@ -556,7 +574,9 @@ BL_DEV uint32_t phase_sync_rev(const ScanParams& p, const TileShared<MODE, W>& s
     const int k = p.unit + w - 1;
     uint32_t ar[S + 1];
     if (p.canonical) {
-        if (W > 1) {
+        if (W < 0 && w >= 2) {
+            window_argmin_runtime<MODE, W, S, false, true, false>(p, sh, all, tid, st, w, ar);
+        } else if (W > 1) {
             lane_window_argmin<S, (W > 1 ? W : 2), false, true>(all, tid, st, owned_mask(p, tid & 63) != 0, ar);
         } else if (W == 1) {
             BL_UNROLL

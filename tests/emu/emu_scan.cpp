@@ -117,15 +117,14 @@ void run_mode(const ScanParams& p, unsigned long long* result)
 {
     switch (p.w) {
         case 1: run_tiles<MODE, 1>(p, result); break;
-        case 5: if (MODE != MODE_SYNCMER) { run_tiles<MODE, 5>(p, result); break; } run_tiles<MODE, 0>(p, result); break;
-        case 10: if (MODE != MODE_SYNCMER) { run_tiles<MODE, 10>(p, result); break; } run_tiles<MODE, 0>(p, result); break;
-        case 19: if (MODE != MODE_SYNCMER) { run_tiles<MODE, 19>(p, result); break; } run_tiles<MODE, 0>(p, result); break;
+        case 5: if (MODE != MODE_SYNCMER) { run_tiles<MODE, 5>(p, result); break; } run_tiles<MODE, -8>(p, result); break;
+        case 10: if (MODE != MODE_SYNCMER) { run_tiles<MODE, 10>(p, result); break; } run_tiles<MODE, -8>(p, result); break;
+        case 19: if (MODE != MODE_SYNCMER) { run_tiles<MODE, 19>(p, result); break; } run_tiles<MODE, -16>(p, result); break;
         case 11: run_tiles<MODE, 11>(p, result); break;
         case 17: run_tiles<MODE, 17>(p, result); break;
         case 21: run_tiles<MODE, 21>(p, result); break;
         default:
-            if (MODE == MODE_SYNCMER) run_tiles<MODE, 0>(p, result);
-            else if (p.w <= 16) run_tiles<MODE, -8>(p, result);
+            if (p.w <= 16) run_tiles<MODE, -8>(p, result);
             else if (p.w <= 32) run_tiles<MODE, -16>(p, result);
             else run_tiles<MODE, -32>(p, result);
             break;
