@@ -115,17 +115,11 @@ __device__ __forceinline__ void count_tile(const ScanParams& p, TileShared<MODE,
 
     ThreadState st;
     phase_hash<MODE, W>(p, sh, tid, st);
-    if (W == 0 && MODE == MODE_SYNCMER) __syncthreads();  // runtime-w syncmers exchange hashes through LDS
 
     uint32_t packed;
     if (MODE == MODE_SYNCMER) {
         uint32_t af[S + 1];
         phase_sync_fwd<MODE, W>(p, sh, tid, st, nullptr, af);
-        if (W == 0 && p.canonical) {
-            __syncthreads();
-            phase_publish_h2<MODE, W>(sh, tid, st);
-            __syncthreads();
-        }
         packed = phase_sync_rev<MODE, W>(p, sh, tid, q0, st, nullptr, af);
     } else {
         packed = phase_window<MODE, W>(p, sh, tid, q0, st, nullptr);
@@ -192,7 +186,7 @@ __device__ __forceinline__ void emit_tile(const ScanParams& p, TileShared<MODE, 
 // parameter block is copied and the fields overwritten with constants, which the inlined phases fold
 // (constant shifts and masks in the roller, no strand selects).  U = 0 / C = -1: taken from the arguments.
 template <int MODE, int W, int U, int C>
-__global__ __launch_bounds__(TPB, (MODE == MODE_SYNCMER || W == 0 || (MODE == MODE_SUPERKMER && W < 0) ? 2 : (W < 0 ? 3 : (W <= 11 ? 5 : 4)))) void scan_count_kernel(const ScanParams pin, GroupRange g)
+__global__ __launch_bounds__(TPB, (MODE == MODE_SYNCMER || (MODE == MODE_SUPERKMER && W < 0) ? 2 : (W < 0 ? 3 : (W <= 11 ? 5 : 4)))) void scan_count_kernel(const ScanParams pin, GroupRange g)
 {
     __shared__ TileShared<MODE, W> sh;
     ScanParams p = pin;
@@ -428,7 +422,7 @@ static hipError_t launch_count_mode(const ScanParams& p, GroupRange g, hipStream
     }
     if (MODE != MODE_SYNCMER) {
         // more window sizes in registers for the minimizer / super-k-mer scans: the widths of minimap2's presets
-        // (k15 w10, k19 w19, k15/k19 w5); every other width runs the LDS-scan fallback (2-8x slower, W = 0)
+        // (k15 w10, k19 w19, k15/k19 w5); every other width runs the sparse-table kernels (W < 0, 1.2-2x slower)
         constexpr int M2 = MODE == MODE_SYNCMER ? MODE_MINIMIZER : MODE;  // never instantiated for syncmers
         switch (p.w) {
             case 5: hipLaunchKernelGGL((scan_count_kernel<M2, 5, 0, -1>), grid, block, 0, stream, p, g); return hipGetLastError();

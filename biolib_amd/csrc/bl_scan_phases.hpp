@@ -29,7 +29,7 @@ struct TileShared {
     // (consecutive wave tiles overlap by their halo, so the halo of a wave is the next wave's data)
     uint32_t codes[NCHUNK];         // 2-bit codes, 16 bases per dword, first base most significant
     uint32_t flags[NCHUNK];         // [15:0] good-base bits, [31:16] sequence-start bits (bit b = base b)
-    uint64_t hash[W <= 0 ? S : 1][W <= 0 ? TPB : 1];  // runtime-w kernels (W <= 0) only: hash[s][tid]
+    uint64_t hash[W < 0 ? S : 1][W < 0 ? TPB : 1];  // runtime-width kernels (W < 0) only, exact branch: hash[s][tid]
     alignas(4) uint16_t list_a[H];  // compacted records: (wave << 12) | wave-relative argmin position
                                     // (syncmer mode: the k-mer's own position)
     alignas(4) uint16_t list_j[MODE == MODE_SUPERKMER ? H : 2];  // compacted: first window of the occurrence
@@ -197,18 +197,7 @@ BL_DEV void phase_hash(const ScanParams& p, TileShared<MODE, W>& sh, int tid, Th
             st.h[s] = murmur64(v, p.seed);
         }
     }
-    if (W == 0 && MODE == MODE_SYNCMER) {  // runtime-w syncmers scan the hashes in LDS (minimizer modes: only on a tie)
-        BL_UNROLL
-        for (int s = 0; s < S; ++s) sh.hash[s][tid] = st.h[s];
-    }
-}
-
-// runtime-w fallback, syncmer mode: second pass over the same LDS array
-template <int MODE, int W>
-BL_DEV void phase_publish_h2(TileShared<MODE, W>& sh, int tid, const ThreadState& st)
-{
-    BL_UNROLL
-    for (int s = 0; s < S; ++s) sh.hash[s][tid] = st.h2[s];
+    (void)sh;  // the runtime-width kernels write hashes to LDS only in their exact branch (lane_window_argmin_generic)
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -338,25 +327,6 @@ BL_DEV uint32_t range_mask(int64_t lo, int64_t hi)
     return h > l ? (((1u << h) - 1) & ~((1u << l) - 1)) : 0u;
 }
 
-// runtime-w fallback: argmin by direct scan of the LDS hashes (slow path for unlisted window sizes)
-template <int MODE, int W, bool LEFT>
-BL_DEV void window_argmin_lds(const TileShared<MODE, W>& sh, int tid, int w, int nw, uint32_t* a)
-{
-    const int wbase = tid & ~63;  // first thread of this wave
-    for (int i = 0; i < nw; ++i) {
-        uint64_t best = 0;
-        int arg = 0;
-        for (int x = 0; x < w; ++x) {
-            int pos = 16 * (tid & 63) + i + x;  // wave-relative position
-            pos = pos < WH ? pos : WH - 1;      // beyond the wave tile: never owned
-            const uint64_t v = sh.hash[pos & 15][wbase + (pos >> 4)];
-            const bool take = x == 0 || (LEFT ? v < best : v <= best);
-            if (take) { best = v; arg = i + x; }
-        }
-        a[i] = (uint32_t)arg;
-    }
-}
-
 // bit s: lane owns wave position 16*lane + s
 BL_DEV uint32_t owned_mask(const ScanParams& p, int lane)
 {
@@ -385,10 +355,10 @@ BL_DEV void window_argmin_lds_fixed(const TileShared<MODE, W>& sh, int tid, int 
     }
 }
 
-// Runtime window size, fast form (minimizer / super-k-mer scans of the W = 0 kernels): packed keys of the lane's own
+// Runtime window size (kernels with W < 0): packed keys of the lane's own
 // 16 hashes and of the 2P that follow (DPP hops, as in the templated form; 7-bit tags) go through
 // window_argmin_doubling<P> in registers.  A prefix tie in an owning lane sends the wave through the exact scan: only
-// then are the wave's hashes written to LDS (wave-local region, no workgroup barrier) for window_argmin_lds.
+// then are the wave's hashes written to LDS (wave-local region, no workgroup barrier) for window_argmin_lds_fixed.
 // LEFT = false (rightmost wins, tags 127 - x) and SECOND (st.h2) serve the reverse-strand pass of the syncmer scan, whose
 // ThreadState keeps both hash arrays alive anyway; the minimizer scans (REDO) drop st.h after packing and recompute it in
 // the rare exact branch.  a[] = argmin positions (plain indices) for the syncmer callers, raw keys for RAW.
@@ -441,10 +411,10 @@ BL_DEV void lane_window_argmin_generic(const ScanParams& p, TileShared<MODE, W>&
         // minimizer scans dropped the full hashes after packing (they would pin 32 registers through the fast path)
         if (MODE != MODE_SYNCMER) phase_hash<MODE, W>(p, sh, tid, st);
         BL_UNROLL
-        for (int s = 0; s < S; ++s) sh.hash[s][W <= 0 ? tid : 0] = SECOND ? st.h2[s] : st.h[s];  // same wave writes, same wave reads
+        for (int s = 0; s < S; ++s) sh.hash[s][W < 0 ? tid : 0] = SECOND ? st.h2[s] : st.h[s];  // same wave writes, same wave reads
 #else
         for (int t = tid & ~63; t < (tid & ~63) + 64; ++t)
-            for (int s = 0; s < S; ++s) sh.hash[s][W <= 0 ? t : 0] = SECOND ? all[t].h2[s] : all[t].h[s];
+            for (int s = 0; s < S; ++s) sh.hash[s][W < 0 ? t : 0] = SECOND ? all[t].h2[s] : all[t].h[s];
 #endif
         window_argmin_lds_fixed<MODE, W, LEFT, NW>(sh, tid, w, a);
     }
@@ -497,8 +467,6 @@ BL_DEV uint32_t phase_window(const ScanParams& p, TileShared<MODE, W>& sh, int t
     } else if (w >= 2 && W < 0) {
         // runtime w: W = -8 : w <= 16, W = -16 : 17..32, W = -32 : 33..64 (launch_count_mode picks the kernel)
         window_argmin_runtime<MODE, W, S + 1, true, false, true>(p, sh, all, tid, st, w, a);
-    } else {
-        window_argmin_lds<MODE, W, true>(sh, tid, w, S + 1, a);
     }
     Bits128 good, start;
     gather_flags(sh.flags + wave_chunk0(p, wv), lane, good, start);
@@ -548,7 +516,6 @@ BL_DEV uint32_t phase_window(const ScanParams& p, TileShared<MODE, W>& sh, int t
 }
 
 // Phase 3 (syncmer): leftmost minimum over the forward s-mer hashes, rightmost over the reverse ones.
-// `pass` is only used by the runtime-w fallback, which republishes the LDS hashes between the two.
 template <int MODE, int W>
 BL_DEV void phase_sync_fwd(const ScanParams& p, TileShared<MODE, W>& sh, int tid, ThreadState& st, const ThreadState* all,
                            uint32_t* af)
@@ -560,8 +527,6 @@ BL_DEV void phase_sync_fwd(const ScanParams& p, TileShared<MODE, W>& sh, int tid
     } else if (W == 1) {
         BL_UNROLL
         for (int s = 0; s < S; ++s) af[s] = (uint32_t)s;
-    } else {
-        window_argmin_lds<MODE, W, true>(sh, tid, p.w, S, af);
     }
 }
 
@@ -581,8 +546,6 @@ BL_DEV uint32_t phase_sync_rev(const ScanParams& p, TileShared<MODE, W>& sh, int
         } else if (W == 1) {
             BL_UNROLL
             for (int s = 0; s < S; ++s) ar[s] = (uint32_t)s;
-        } else {
-            window_argmin_lds<MODE, W, false>(sh, tid, w, S, ar);
         }
     }
     Bits128 good, start;

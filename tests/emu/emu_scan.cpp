@@ -56,8 +56,6 @@ void run_tiles(ScanParams p, unsigned long long* result)
             for (int tid = 0; tid < TPB; ++tid) phase_hash<MODE, W>(p, *sh, tid, st[tid]);
             if (MODE == MODE_SYNCMER) {
                 for (int tid = 0; tid < TPB; ++tid) phase_sync_fwd<MODE, W>(p, *sh, tid, st[tid], st.data(), &af[tid * (S + 1)]);
-                if (W == 0 && p.canonical)
-                    for (int tid = 0; tid < TPB; ++tid) phase_publish_h2<MODE, W>(*sh, tid, st[tid]);
                 for (int tid = 0; tid < TPB; ++tid)
                     packed[tid] = phase_sync_rev<MODE, W>(p, *sh, tid, q0, st[tid], st.data(), &af[tid * (S + 1)]);
             } else {
