@@ -156,11 +156,17 @@ def main():
         achieved = bases_per_launch * 1.0 / avg_kernel_s / 1e9  # 1 algorithmic byte per base
         traffic = None
         valu = None
+        hbm_actual = None
         tp = os.path.join(ROOT, "profiles", "traffic.json")  # written from a separate rocprofv3 --pmc run, see DESIGN.md
         if os.path.exists(tp):
             try:
                 prof = json.load(open(tp))
                 traffic = int(prof["hbm_bytes_per_base"] * bases_per_launch)  # PMC bytes per base x this run's bases per launch
+                # what actually moves through HBM per range (both passes, PMC) over the time a range takes in this run
+                emit_bytes = prof.get("emit_kernel", {}).get("hbm_bytes_per_launch_measured", 0) / prof["measured_bases_per_launch"] * bases_per_launch
+                range_s = t_max / args.steps / len(ranges)
+                hbm_actual = {"bytes_per_range_both_passes": int(traffic + emit_bytes), "GBps": round((traffic + emit_bytes) / range_s / 1e9, 1),
+                              "frac_of_8TBps": round((traffic + emit_bytes) / range_s / 1e9 / HBM_PEAK_GBPS, 4)}
                 # second ceiling: VALU issue.  A wave64 instruction occupies a SIMD16 for 4 cycles, so the
                 # nominal peak is CUs x 4 SIMDs x clock / 4 wave-instructions per second (some simple ops retire faster,
                 # which is how the fraction can pass 1).
@@ -210,6 +216,8 @@ def main():
             out["rehearsal"] = "all ranks on cuda:0 over gloo: flow check only, NOT a measurement"
         if valu is not None:
             out["roofline"]["valu"] = valu
+        if hbm_actual is not None:
+            out["roofline"]["hbm_actual"] = hbm_actual
         if n_gpus == 1:
             try:
                 rd, cp = ctx.probe_hbm(8 << 30, 5)
