@@ -284,6 +284,11 @@ def test_async_scans_on_internal_lanes(lanes):
         b.minimizers_raw(31, 11, 42, B.FLAG_CANONICAL, first=a, n=m, values=v, positions=p, hashes=h, capacity=cap, result=r)
     sk = B.Result()
     b.syncmers_raw(31, 11, 0, 20, 0, B.FLAG_CANONICAL, first=0, n=n, result=sk)
+    # other kernels in flight on the same lanes: a runtime window size, super-k-mers, a runtime-width syncmer scan
+    gm, gs, gy = B.Result(), B.Result(), B.Result()
+    b.minimizers_raw(19, 13, 7, B.FLAG_CANONICAL, first=0, n=n, result=gm)
+    b.super_kmers_raw(27, 12, 5, B.FLAG_CANONICAL, first=0, n=n, result=gs)
+    b.syncmers_raw(25, 12, 0, 13, 0, B.FLAG_CANONICAL, first=0, n=n, result=gy)
     c.sync()
     whole = b.minimizers(31, 11, seed=42, canonical=True)
     assert sum(int(r.count) for r in res) == whole["count"] and all(r.status == 0 for r in res)
@@ -291,6 +296,13 @@ def test_async_scans_on_internal_lanes(lanes):
     hsh = np.concatenate([h[: int(r.count)].cpu().numpy().view(np.uint64) for (v, p, h), r in zip(outs, res)])
     assert np.array_equal(pos, whole["positions"]) and np.array_equal(hsh, whole["hashes"])
     assert int(sk.count) == b.syncmers(31, 11, 0, 20, canonical=True, positions=False)["count"]
+    seq = O.synth(5, n)
+    offs = O.fixed_offsets(n, 150)
+    d = O.minimizer_digest(seq, offs, 19, 13, 7, True, threads=8)
+    assert (int(gm.count), int(gm.xor_hash), int(gm.xor_pos)) == (d["count"], d["xor_hash"], d["xor_pos"])
+    assert int(gs.count) == len(O.super_kmers(seq[:3_000_000], offs[:20_001], 27, 12, 5, True)[0]) + b.super_kmers_raw(
+        27, 12, 5, B.FLAG_CANONICAL | B.FLAG_SYNC, first=3_000_000, n=n - 3_000_000).count
+    assert int(gy.count) == O.syncmers(seq, offs, 25, 12, 0, 13, True, positions=False, threads=8)[0]
     with pytest.raises(B.BiolibError):
         B.capi.check(c._lib.bl_ctx_set_lanes(c._h, 3))
     c.close()
