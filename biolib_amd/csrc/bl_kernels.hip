@@ -208,18 +208,15 @@ __global__ __launch_bounds__(TPB) void scan_emit_kernel(const ScanParams p, Grou
     Digest dg{0, 0, 0};
     emit_tile<MODE, 1>(p, sh, g.first + blockIdx.x, tid, dg);
 
-    // digest: wave reduce -> LDS -> one set of atomics per workgroup into a shard line
-    __syncthreads();
-    if (tid < 4) sh.dig[tid] = 0;
-    __syncthreads();
+    // digest: wave reduce, then one set of atomics per WAVE into a shard line (an LDS stage in between would add two
+    // barriers per tile to save 9 of 12 atomics that L2 absorbs anyway)
     const unsigned long long xv = wave_xor_to_last_u64(dg.xv), xh = wave_xor_to_last_u64(dg.xh), xp = wave_xor_to_last_u64(dg.xp);
-    if ((tid & 63) == 63) {
-        atomicXor(&sh.dig[1], xv);
-        atomicXor(&sh.dig[2], xh);
-        atomicXor(&sh.dig[3], xp);
+    if ((tid & 63) == 63 && (xv | xh | xp)) {
+        unsigned long long* shard = p.shards + 8 * ((blockIdx.x * NWAVE + (tid >> 6)) % NSHARD);
+        atomicXor(&shard[1], xv);
+        atomicXor(&shard[2], xh);
+        atomicXor(&shard[3], xp);
     }
-    __syncthreads();
-    if (tid >= 1 && tid < 4) atomicXor(&p.shards[8 * (blockIdx.x % NSHARD) + tid], sh.dig[tid]);
 }
 
 // ------------------------------------------------------------------------------------------------
