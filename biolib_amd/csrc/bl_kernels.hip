@@ -186,7 +186,7 @@ __device__ __forceinline__ void emit_tile(const ScanParams& p, TileShared<MODE, 
 // parameter block is copied and the fields overwritten with constants, which the inlined phases fold
 // (constant shifts and masks in the roller, no strand selects).  U = 0 / C = -1: taken from the arguments.
 template <int MODE, int W, int U, int C>
-__global__ __launch_bounds__(TPB, (MODE == MODE_SYNCMER || (MODE == MODE_SUPERKMER && W < 0) ? 2 : (W < 0 ? 3 : (W <= 11 ? 5 : 4)))) void scan_count_kernel(const ScanParams pin, GroupRange g)
+__global__ __launch_bounds__(TPB, (MODE == MODE_SYNCMER || (MODE == MODE_SUPERKMER && W == -32) ? 2 : (W == -32 || (W < 0 && MODE == MODE_SUPERKMER) ? 3 : (W == -16 ? 5 : (W < 0 ? 4 : (W <= 11 ? 5 : 4)))))) void scan_count_kernel(const ScanParams pin, GroupRange g)
 {
     __shared__ TileShared<MODE, W> sh;
     ScanParams p = pin;

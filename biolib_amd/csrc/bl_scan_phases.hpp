@@ -15,6 +15,8 @@
 //   windows i and i+1, whether window i+1 starts a new minimizer occurrence and whether window i
 //   ends one.
 #pragma once
+#include <type_traits>
+
 #include "bl_scan_core.hpp"
 
 namespace bl {
@@ -29,7 +31,11 @@ struct TileShared {
     // (consecutive wave tiles overlap by their halo, so the halo of a wave is the next wave's data)
     uint32_t codes[NCHUNK];         // 2-bit codes, 16 bases per dword, first base most significant
     uint32_t flags[NCHUNK];         // [15:0] good-base bits, [31:16] sequence-start bits (bit b = base b)
-    uint64_t hash[W < 0 ? S : 1][W < 0 ? TPB : 1];  // runtime-width kernels (W < 0) only, exact branch: hash[s][tid]
+    // runtime-width kernels (W < 0), exact branch only.  Minimizer / super-k-mer scans: one dword of hash[s][tid] at a time
+    // (high halves, then low halves: 16 KB, which lifts the LDS limit from 3 to 6 workgroups per CU).  The syncmer scan, whose
+    // registers hold it to 2 waves per SIMD anyway and whose small s-mers tie often, keeps whole hashes (one pass).
+    // The largest size group (W = -32) is register-bound at 3 waves per SIMD and keeps whole hashes too.
+    typename std::conditional<(MODE == MODE_SYNCMER || W == -32), uint64_t, uint32_t>::type half[W < 0 ? S : 1][W < 0 ? TPB : 1];
     alignas(4) uint16_t list_a[H];  // compacted records: (wave << 12) | wave-relative argmin position
                                     // (syncmer mode: the k-mer's own position)
     alignas(4) uint16_t list_j[MODE == MODE_SUPERKMER ? H : 2];  // compacted: first window of the occurrence
@@ -334,31 +340,83 @@ BL_DEV uint32_t owned_mask(const ScanParams& p, int lane)
     return own >= S ? 0xffffu : (own > 0 ? (1u << own) - 1 : 0u);
 }
 
-// the same scan with the window count as a template parameter: a[] is then indexed statically and can stay in the
-// registers the fast form left it in (a run-time loop over i turns it into an indexable array and costs ~150 VGPRs)
-template <int MODE, int W, bool LEFT, int NW>
-BL_DEV void window_argmin_lds_fixed(const TileShared<MODE, W>& sh, int tid, int w, uint32_t* a)
+// Exact argmins of the lane's NW windows of run-time size w from the wave's hashes, through LDS, one 32-bit half at a
+// time so that the buffer is 4 KB per wave: pass 1 publishes the high dwords and finds, per window, the minimum high
+// dword and the set of positions that attain it (a w-bit mask); pass 2 publishes the low dwords into the SAME buffer and
+// picks, among those positions, the minimum low dword — leftmost or rightmost on a full tie.  Wave-local: the lanes of a
+// wave run in lockstep, so every read of pass 1 precedes the writes of pass 2 (the emulation passes all[]).
+// The window count is a template parameter: a[] is indexed statically and stays in the registers the fast form left it in.
+template <int MODE, int W, bool LEFT, bool SECOND, int NW>
+BL_DEV void window_argmin_lds_exact(TileShared<MODE, W>& sh, const ThreadState* all, int tid, const ThreadState& st, int w, uint32_t* a)
 {
-    const int wbase = tid & ~63;
-    BL_UNROLL
-    for (int i = 0; i < NW; ++i) {
-        uint64_t best = 0;
-        int arg = 0;
-        for (int x = 0; x < w; ++x) {
-            int pos = 16 * (tid & 63) + i + x;
-            pos = pos < WH ? pos : WH - 1;
-            const uint64_t v = sh.hash[pos & 15][wbase + (pos >> 4)];
-            const bool take = x == 0 || (LEFT ? v < best : v <= best);
-            if (take) { best = v; arg = i + x; }
+    const int wbase = tid & ~63, lane = tid & 63;
+    if (MODE == MODE_SYNCMER || W == -32) {  // whole hashes in LDS: one pass
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(BL_CPU_EMU)
+        BL_UNROLL
+        for (int s = 0; s < S; ++s) sh.half[s][W < 0 ? tid : 0] = SECOND ? st.h2[s] : st.h[s];
+#else
+        for (int t = wbase; t < wbase + 64; ++t)
+            for (int s = 0; s < S; ++s) sh.half[s][W < 0 ? t : 0] = SECOND ? all[t].h2[s] : all[t].h[s];
+#endif
+        BL_UNROLL
+        for (int i = 0; i < NW; ++i) {
+            uint64_t best = 0;
+            int arg = 0;
+            for (int x = 0; x < w; ++x) {
+                int pos = 16 * lane + i + x;
+                pos = pos < WH ? pos : WH - 1;
+                const uint64_t v = sh.half[pos & 15][W < 0 ? wbase + (pos >> 4) : 0];
+                if (x == 0 || (LEFT ? v < best : v <= best)) { best = v; arg = i + x; }
+            }
+            a[i] = (uint32_t)arg;
         }
-        a[i] = (uint32_t)arg;
+        return;
+    }
+    using Mask = typename std::conditional<(W == -8 || W == -16), uint32_t, unsigned long long>::type;  // w <= 32 fits a dword
+    Mask cand[NW];
+    for (int half = 0; half < 2; ++half) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(BL_CPU_EMU)
+        (void)all;
+        BL_UNROLL
+        for (int s = 0; s < S; ++s) {
+            const uint64_t h = SECOND ? st.h2[s] : st.h[s];
+            sh.half[s][W < 0 ? tid : 0] = (uint32_t)(half == 0 ? h >> 32 : h);
+        }
+#else
+        (void)st;
+        for (int t = wbase; t < wbase + 64; ++t)
+            for (int s = 0; s < S; ++s) {
+                const uint64_t h = SECOND ? all[t].h2[s] : all[t].h[s];
+                sh.half[s][W < 0 ? t : 0] = (uint32_t)(half == 0 ? h >> 32 : h);
+            }
+#endif
+        BL_UNROLL
+        for (int i = 0; i < NW; ++i) {
+            uint32_t best = 0;
+            Mask mask = 0;
+            int arg = 0;
+            for (int x = 0; x < w; ++x) {
+                int pos = 16 * lane + i + x;
+                pos = pos < WH ? pos : WH - 1;  // beyond the wave tile: never part of an owned window
+                const uint32_t v = (uint32_t)sh.half[pos & 15][W < 0 ? wbase + (pos >> 4) : 0];
+                if (half == 0) {
+                    if (x == 0 || v < best) { best = v; mask = (Mask)1 << x; }
+                    else if (v == best) mask |= (Mask)1 << x;
+                } else if ((cand[i] >> x) & 1) {
+                    const bool first = ((cand[i] & (((Mask)1 << x) - 1)) == 0);
+                    if (first || (LEFT ? v < best : v <= best)) { best = v; arg = i + x; }
+                }
+            }
+            if (half == 0) cand[i] = mask;
+            else a[i] = (uint32_t)arg;
+        }
     }
 }
 
 // Runtime window size (kernels with W < 0): packed keys of the lane's own
 // 16 hashes and of the 2P that follow (DPP hops, as in the templated form; 7-bit tags) go through
 // window_argmin_doubling<P> in registers.  A prefix tie in an owning lane sends the wave through the exact scan: only
-// then are the wave's hashes written to LDS (wave-local region, no workgroup barrier) for window_argmin_lds_fixed.
+// then are the wave's hashes written to LDS (wave-local region, no workgroup barrier) for window_argmin_lds_exact (4 KB per wave, one hash half at a time).
 // LEFT = false (rightmost wins, tags 127 - x) and SECOND (st.h2) serve the reverse-strand pass of the syncmer scan, whose
 // ThreadState keeps both hash arrays alive anyway; the minimizer scans (REDO) drop st.h after packing and recompute it in
 // the rare exact branch.  a[] = argmin positions (plain indices) for the syncmer callers, raw keys for RAW.
@@ -410,13 +468,8 @@ BL_DEV void lane_window_argmin_generic(const ScanParams& p, TileShared<MODE, W>&
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(BL_CPU_EMU)
         // minimizer scans dropped the full hashes after packing (they would pin 32 registers through the fast path)
         if (MODE != MODE_SYNCMER) phase_hash<MODE, W>(p, sh, tid, st);
-        BL_UNROLL
-        for (int s = 0; s < S; ++s) sh.hash[s][W < 0 ? tid : 0] = SECOND ? st.h2[s] : st.h[s];  // same wave writes, same wave reads
-#else
-        for (int t = tid & ~63; t < (tid & ~63) + 64; ++t)
-            for (int s = 0; s < S; ++s) sh.hash[s][W < 0 ? t : 0] = SECOND ? all[t].h2[s] : all[t].h[s];
 #endif
-        window_argmin_lds_fixed<MODE, W, LEFT, NW>(sh, tid, w, a);
+        window_argmin_lds_exact<MODE, W, LEFT, SECOND, NW>(sh, all, tid, st, w, a);
     }
 }
 
