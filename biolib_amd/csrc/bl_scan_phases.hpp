@@ -465,6 +465,9 @@ BL_DEV void lane_window_argmin_generic(const ScanParams& p, TileShared<MODE, W>&
         for (int i = 0; i < NW; ++i) a[i] = LEFT ? (a[i] & 127u) : 127u - (a[i] & 127u);
     }
     if (wave_any(owns && dmin < 128u)) {
+#ifdef BL_EXPERIMENT_COUNT_FALLBACK
+        if ((tid & 63) == 0) atomicAdd(&bl_dbg_fallbacks, 1ull);
+#endif
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(BL_CPU_EMU)
         // minimizer scans dropped the full hashes after packing (they would pin 32 registers through the fast path)
         if (MODE != MODE_SYNCMER) phase_hash<MODE, W>(p, sh, tid, st);
