@@ -15,7 +15,7 @@ FLAG_CANONICAL, FLAG_DROP_LAST, FLAG_SYNC = 1, 2, 4
 
 # every symbol include/biolib_amd.h declares (tests check the library exports exactly these)
 SYMBOLS = [
-    "bl_last_error", "bl_version", "bl_device_count", "bl_ctx_create", "bl_ctx_destroy", "bl_ctx_set_stream", "bl_ctx_sync",
+    "bl_last_error", "bl_version", "bl_device_count", "bl_ctx_create", "bl_ctx_destroy", "bl_ctx_set_stream", "bl_ctx_use_own_streams", "bl_ctx_sync",
     "bl_batch_upload", "bl_batch_from_device", "bl_batch_synth", "bl_batch_destroy", "bl_batch_n_bases", "bl_batch_n_seqs",
     "bl_batch_device_bases", "bl_batch_download", "bl_scan_kmers", "bl_scan_minimizers", "bl_scan_hash_sample", "bl_scan_super_kmers", "bl_scan_syncmers", "bl_sort_unique_u64", "bl_jaccard_sorted_u64", "bl_partition_u64", "bl_sort_u64", "bl_count_sorted_u64", "bl_probe_hbm", "bl_ctx_set_lanes", "bl_pack_super_kmers", "bl_partition_records", "bl_expand_super_kmers",
     "bl_ctx_last_scan_ms", "bl_ctx_kernel_timing", "bl_ctx_kernel_time", "bl_reader_open", "bl_reader_close", "bl_reader_next_record",
@@ -63,6 +63,7 @@ def lib():
     L.bl_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
     L.bl_ctx_destroy.argtypes = [vp]
     L.bl_ctx_set_stream.argtypes = [vp, vp]
+    L.bl_ctx_use_own_streams.argtypes = [vp]
     L.bl_ctx_sync.argtypes = [vp]
     L.bl_batch_upload.argtypes = [vp, vp, u64, vp, u64, C.POINTER(vp)]
     L.bl_batch_from_device.argtypes = [vp, vp, u64, vp, u64, u64, C.POINTER(vp)]

@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <new>
 #include <string>
 #include <utility>
@@ -44,7 +45,7 @@ namespace {
     } while (0)
 
 constexpr int RESULT_WORDS = 16;   // device/pinned result record (u64 words)
-constexpr int RING = 64;           // pinned result slots
+constexpr int RING = 256;          // pinned result slots (recycled one by one behind their own events, never by draining the context)
 constexpr size_t HDR_BYTES = 256;  // ticket, error
 constexpr size_t SHARD_BYTES = (size_t)bl::NSHARD * 8 * sizeof(unsigned long long);
 
@@ -76,6 +77,7 @@ struct Lane {
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     hipEvent_t ev_count_done = nullptr;  // two-lane mode: recorded after this lane's pass-1 kernel
     bool count_recorded = false;
+    bool scan_recorded = false;          // ev_stop has been recorded at least once
 
     unsigned long long* shards() const { return reinterpret_cast<unsigned long long*>(ws + HDR_BYTES); }
     unsigned long long* result() const { return reinterpret_cast<unsigned long long*>(ws + HDR_BYTES + SHARD_BYTES); }
@@ -88,11 +90,13 @@ struct bl_ctx {
     int next_lane = 0;
     int n_lanes = 1;                   // 2: consecutive async scans alternate lanes, staggered (bl_ctx_set_lanes, env BL_LANES)
     uint32_t emit_lds_per_wg = 25600;  // two-lane mode: LDS footprint pass-2 workgroups are padded to (caps their residency per CU)
-    hipStream_t user_stream = nullptr; // borrowed (bl_ctx_set_stream)
+    hipStream_t user_stream = nullptr; // borrowed (bl_ctx_set_stream); NULL while borrowed = the legacy default stream
+    bool borrowed = false;             // scans run on user_stream instead of the lanes' own streams
     hipStream_t stream = nullptr;      // stream of `cur`
     unsigned long long* pinned = nullptr;  // RING * RESULT_WORDS
+    hipEvent_t slot_ev[RING] = {};         // recorded behind the copy into the slot
     int next_slot = 0;
-    std::vector<Pending> pending;
+    std::deque<Pending> pending;           // oldest first; at most RING entries
     bool timed = false;
     // optional per-launch timing of the main scan kernel alone (bl_ctx_kernel_timing)
     bool ktiming = false;
@@ -140,7 +144,7 @@ int ensure_workspace(bl_ctx* c)
 // pick the lane (and stream) of the next scan
 void select_lane(bl_ctx* c)
 {
-    if (c->user_stream) {
+    if (c->borrowed) {
         c->cur = &c->lanes[0];
         c->stream = c->user_stream;
     } else {
@@ -150,21 +154,24 @@ void select_lane(bl_ctx* c)
     }
 }
 
+void deliver(bl_ctx* c, const Pending& p)
+{
+    const unsigned long long* r = c->pinned + (size_t)p.slot * RESULT_WORDS;
+    bl_result out;
+    std::memset(&out, 0, sizeof(out));
+    out.count = r[0];
+    out.xor_value = r[1];
+    out.xor_hash = r[2];
+    out.xor_pos = r[3];
+    out.aux = r[4];
+    out.status = BL_OK;
+    if (p.has_capacity && r[0] > p.capacity) out.status = BL_ERR_CAPACITY;
+    if (p.user) *p.user = out;
+}
+
 int flush_pending(bl_ctx* c)
 {
-    for (const Pending& p : c->pending) {
-        const unsigned long long* r = c->pinned + (size_t)p.slot * RESULT_WORDS;
-        bl_result out;
-        std::memset(&out, 0, sizeof(out));
-        out.count = r[0];
-        out.xor_value = r[1];
-        out.xor_hash = r[2];
-        out.xor_pos = r[3];
-        out.aux = r[4];
-        out.status = BL_OK;
-        if (p.has_capacity && r[0] > p.capacity) out.status = BL_ERR_CAPACITY;
-        if (p.user) *p.user = out;
-    }
+    for (const Pending& p : c->pending) deliver(c, p);
     c->pending.clear();
     return BL_OK;
 }
@@ -186,7 +193,7 @@ int flush_kernel_events(bl_ctx* c)
 int sync_ctx(bl_ctx* c)
 {
     for (Lane& l : c->lanes) BL_HIP(hipStreamSynchronize(l.own));
-    if (c->user_stream) BL_HIP(hipStreamSynchronize(c->user_stream));
+    if (c->borrowed) BL_HIP(hipStreamSynchronize(c->user_stream));
     int rc = flush_kernel_events(c);
     if (rc != BL_OK) return rc;
     return flush_pending(c);
@@ -231,14 +238,20 @@ int end_scan(bl_ctx* c, uint32_t add_mask, bl_result* user, bool has_capacity, u
         if (e != hipSuccess) return fail(BL_ERR_HIP, std::string("reduce_shards: ") + hipGetErrorString(e));
     }
     if ((int)c->pending.size() >= RING) {
-        int rc = sync_ctx(c);
-        if (rc != BL_OK) return rc;
+        // the ring is full: hand over the OLDEST result alone (its scan was issued RING scans ago and has normally
+        // finished long since) — the streams keep running, nothing is drained
+        const Pending old = c->pending.front();
+        BL_HIP(hipEventSynchronize(c->slot_ev[old.slot]));
+        deliver(c, old);
+        c->pending.pop_front();
     }
     const int slot = c->next_slot;
     c->next_slot = (c->next_slot + 1) % RING;
     BL_HIP(hipMemcpyAsync(c->pinned + (size_t)slot * RESULT_WORDS, c->result(), RESULT_WORDS * sizeof(unsigned long long),
                           hipMemcpyDeviceToHost, c->stream));
+    BL_HIP(hipEventRecord(c->slot_ev[slot], c->stream));
     BL_HIP(hipEventRecord(c->cur->ev_stop, c->stream));
+    c->cur->scan_recorded = true;
     c->timed = true;
     c->pending.push_back(Pending{user, slot, capacity, has_capacity});
     if (flags & BL_FLAG_SYNC) {
@@ -261,8 +274,7 @@ int zero_result(bl_ctx* c, bl_result* user, uint32_t flags)
 int check_range(const bl_batch* b, uint64_t first, uint64_t n, uint64_t& end)
 {
     if (first > b->n_bases) return fail(BL_ERR_INVALID, "range starts beyond the batch");
-    end = n == 0 ? b->n_bases : first + n;
-    if (end > b->n_bases) end = b->n_bases;
+    end = (n == 0 || n > b->n_bases - first) ? b->n_bases : first + n;  // first + n cannot wrap here
     if (end - first > (1ull << 31)) return fail(BL_ERR_INVALID, "a scan range may hold at most 2^31 positions; split it");
     return BL_OK;
 }
@@ -283,11 +295,11 @@ int make_start_bits(bl_ctx* c, bl_batch* b, const uint64_t* offsets, uint64_t n_
         if (offsets[0] != 0 || offsets[n_seqs] != b->n_bases) return fail(BL_ERR_INVALID, "offsets must span [0, n_bases]");
         uint64_t* d_off = nullptr;
         BL_HIP(hipMalloc(&d_off, (n_seqs + 1) * sizeof(uint64_t)));
-        BL_HIP(hipMemcpyAsync(d_off, offsets, (n_seqs + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
-        hipError_t e = bl::launch_start_bits_offsets(b->start_bits, d_off, n_seqs, b->n_bases, c->stream);
+        hipError_t e = hipMemcpyAsync(d_off, offsets, (n_seqs + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = bl::launch_start_bits_offsets(b->start_bits, d_off, n_seqs, b->n_bases, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        (void)hipFree(d_off);
         if (e != hipSuccess) return fail(BL_ERR_HIP, std::string("start_bits_offsets: ") + hipGetErrorString(e));
-        BL_HIP(hipStreamSynchronize(c->stream));
-        BL_HIP(hipFree(d_off));
         b->n_seqs = n_seqs;
     } else {
         hipError_t e = bl::launch_start_bits_fixed(b->start_bits, n_words, b->n_bases, read_len, c->stream);
@@ -300,7 +312,16 @@ int make_start_bits(bl_ctx* c, bl_batch* b, const uint64_t* offsets, uint64_t n_
 
 }  // namespace
 
-hipStream_t bl_ctx_stream(bl_ctx* c) { return c->user_stream ? c->user_stream : c->lanes[0].own; }
+// The stream every NON-scan entry point (set operations, super-k-mer packing, the text parser ...) enqueues its work on:
+// the borrowed stream, or lane 0's.  With two lanes a scan may still be running on lane 1's stream, so lane 0's stream is
+// first made to wait for the end of the last scan issued on the other lane: callers may chain scan -> pack / sort / ...
+// without bl_ctx_sync, as the header promises.
+hipStream_t bl_ctx_stream(bl_ctx* c)
+{
+    if (c->borrowed) return c->user_stream;
+    if (c->n_lanes == 2 && c->lanes[1].scan_recorded) (void)hipStreamWaitEvent(c->lanes[0].own, c->lanes[1].ev_stop, 0);
+    return c->lanes[0].own;
+}
 int bl_batch_adopt_device(bl_ctx* ctx, void* d_bases, uint64_t n_bases, uint64_t* d_offsets, uint64_t n_seqs, bl_batch** out);
 int bl_ctx_device(bl_ctx* c) { return c->device; }
 
@@ -342,6 +363,7 @@ int bl_ctx_create(int device, bl_ctx** out)
         if (e == hipSuccess) e = hipEventCreate(&l.ev_stop);
     }
     if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&c->pinned), (size_t)RING * RESULT_WORDS * sizeof(unsigned long long), hipHostMallocDefault);
+    for (int i = 0; i < RING && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&c->slot_ev[i], hipEventDisableTiming);
     if (e != hipSuccess) {
         bl_ctx_destroy(c);
         return fail(BL_ERR_HIP, std::string("context setup: ") + hipGetErrorString(e));
@@ -378,7 +400,7 @@ int bl_ctx_destroy(bl_ctx* c)
     (void)hipSetDevice(c->device);
     for (Lane& l : c->lanes)
         if (l.own) (void)hipStreamSynchronize(l.own);
-    if (c->user_stream) (void)hipStreamSynchronize(c->user_stream);
+    if (c->borrowed) (void)hipStreamSynchronize(c->user_stream);
     while (!c->batches.empty()) bl_batch_destroy(c->batches.back());  // handles of leftover batches become invalid
     for (Lane& l : c->lanes) {
         if (l.ws) (void)hipFree(l.ws);
@@ -391,6 +413,8 @@ int bl_ctx_destroy(bl_ctx* c)
         if (l.own) (void)hipStreamDestroy(l.own);
     }
     if (c->pinned) (void)hipHostFree(c->pinned);
+    for (hipEvent_t ev : c->slot_ev)
+        if (ev) (void)hipEventDestroy(ev);
     for (auto& pr : c->ev_open) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     for (hipEvent_t ev : c->ev_pool) (void)hipEventDestroy(ev);
     delete c;
@@ -402,9 +426,22 @@ int bl_ctx_set_stream(bl_ctx* c, void* hip_stream)
     if (!c) return fail(BL_ERR_INVALID, "ctx is NULL");
     int rc = sync_ctx(c);
     if (rc != BL_OK) return rc;
-    c->user_stream = static_cast<hipStream_t>(hip_stream);
+    c->borrowed = true;
+    c->user_stream = static_cast<hipStream_t>(hip_stream);  // NULL is a stream too: the legacy default stream (torch's default)
     c->cur = &c->lanes[0];
-    c->stream = c->user_stream ? c->user_stream : c->lanes[0].own;
+    c->stream = c->user_stream;
+    return BL_OK;
+}
+
+int bl_ctx_use_own_streams(bl_ctx* c)
+{
+    if (!c) return fail(BL_ERR_INVALID, "ctx is NULL");
+    int rc = sync_ctx(c);
+    if (rc != BL_OK) return rc;
+    c->borrowed = false;
+    c->user_stream = nullptr;
+    c->cur = &c->lanes[0];
+    c->stream = c->lanes[0].own;
     return BL_OK;
 }
 
@@ -550,7 +587,7 @@ int bl_batch_destroy(bl_batch* b)
         (void)hipSetDevice(b->ctx->device);
         for (Lane& l : b->ctx->lanes)
             if (l.own) (void)hipStreamSynchronize(l.own);
-        if (b->ctx->user_stream) (void)hipStreamSynchronize(b->ctx->user_stream);
+        if (b->ctx->borrowed) (void)hipStreamSynchronize(b->ctx->user_stream);
         auto& v = b->ctx->batches;
         for (size_t i = 0; i < v.size(); ++i)
             if (v[i] == b) { v[i] = v.back(); v.pop_back(); break; }
@@ -568,7 +605,7 @@ const void* bl_batch_device_bases(const bl_batch* b) { return b ? b->bases : nul
 int bl_batch_download(bl_batch* b, uint64_t first, uint64_t n, char* out)
 {
     if (!b || (!out && n)) return fail(BL_ERR_INVALID, "NULL argument");
-    if (first + n > b->n_bases) return fail(BL_ERR_INVALID, "range beyond the batch");
+    if (first > b->n_bases || n > b->n_bases - first) return fail(BL_ERR_INVALID, "range beyond the batch");
     BL_HIP(hipSetDevice(b->ctx->device));
     int rc = sync_ctx(b->ctx);
     if (rc != BL_OK) return rc;
@@ -660,7 +697,7 @@ static int scan_windows(int mode, bl_ctx* c, const bl_batch* b, uint64_t first, 
     // groups with a running carry; one group is what is used)
     const bl::GroupRange all{0, (uint32_t)p.n_tiles};
     unsigned long long* carry = reinterpret_cast<unsigned long long*>(c->cur->ws);  // header word, zeroed by begin_scan
-    const bool staggered = c->n_lanes == 2 && !c->user_stream;
+    const bool staggered = c->n_lanes == 2 && !c->borrowed;
     if (staggered) {
         // two lanes: this scan's pass 1 starts when the other lane's pass 1 has finished, so that it runs beside the
         // other lane's pass 2 (HBM-write bound) instead of beside its pass 1 (both ALU bound: nothing to gain)
@@ -726,10 +763,10 @@ int bl_scan_super_kmers(bl_ctx* c, const bl_batch* b, uint64_t first, uint64_t n
     p.out_hash = d_hashes;
     const bool wants = d_minimizers || d_first_pos || d_mm_pos || d_sizes || d_hashes;
     if (d_sizes && capacity) {
-        Lane* ln = c->user_stream ? &c->lanes[0] : &c->lanes[c->next_lane];  // the lane begin_scan() will pick
+        Lane* ln = c->borrowed ? &c->lanes[0] : &c->lanes[c->next_lane];  // the lane begin_scan() will pick
         if (ln->last_cap < capacity) {
             BL_HIP(hipSetDevice(c->device));
-            BL_HIP(hipStreamSynchronize(c->user_stream ? c->user_stream : ln->own));
+            BL_HIP(hipStreamSynchronize(c->borrowed ? c->user_stream : ln->own));
             if (ln->last_buf) BL_HIP(hipFree(ln->last_buf));
             ln->last_buf = nullptr;
             ln->last_cap = 0;

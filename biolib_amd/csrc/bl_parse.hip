@@ -201,15 +201,21 @@ extern "C" int bl_batch_from_text(bl_ctx* ctx, const char* text, uint64_t n_byte
     unsigned int* d_err = nullptr;
     void* d_tmp = nullptr;
     uint8_t* d_bases = nullptr;
-    auto cleanup = [&]() {
+    bool handed_over = false;  // d_bases / d_offsets now belong to the batch
+    auto cleanup = [&]() {     // every exit path: the scratch always, the outputs unless the batch has adopted them
         (void)hipStreamSynchronize(s);
         for (void* p : {(void*)d_text, (void*)d_blk, (void*)d_line_end, (void*)d_len, (void*)d_hdr, (void*)d_rec, (void*)d_dst, (void*)d_err, d_tmp})
             if (p) (void)hipFree(p);
+        d_text = nullptr; d_blk = d_line_end = d_len = d_hdr = d_rec = d_dst = nullptr; d_err = nullptr; d_tmp = nullptr;
+        if (!handed_over) {
+            if (d_bases) (void)hipFree(d_bases);
+            if (d_offsets) (void)hipFree(d_offsets);
+            d_bases = nullptr;
+            d_offsets = nullptr;
+        }
     };
     auto fail_free = [&](int code, const char* msg) {
         cleanup();
-        if (d_bases) (void)hipFree(d_bases);
-        if (d_offsets) (void)hipFree(d_offsets);
         return bl_set_error(code, msg);
     };
 
@@ -295,6 +301,7 @@ extern "C" int bl_batch_from_text(bl_ctx* ctx, const char* text, uint64_t n_byte
     hipLaunchKernelGGL(record_offsets_kernel, dim3(lb), dim3(256), 0, s, d_hdr, d_rec, d_dst, n_lines, d_offsets, (uint64_t)n_records, (uint64_t)total);
     P_HIP(hipGetLastError());
     P_HIP(hipStreamSynchronize(s));
+    handed_over = true;
     cleanup();
     int rc = bl_batch_adopt_device(ctx, d_bases, total, reinterpret_cast<uint64_t*>(d_offsets), n_records, out);  // takes ownership of both
     if (rc != BL_OK) return rc;

@@ -58,9 +58,9 @@ int bl_sort_unique_u64(bl_ctx* ctx, uint64_t* d_keys, uint64_t n, uint64_t* n_un
     unsigned long long* d_count = nullptr;
     void* scratch = nullptr;
     size_t sort_bytes = 0, uniq_bytes = 0;
-    SET_HIP(hipMalloc(&tmp, n * sizeof(unsigned long long)));
-    SET_HIP(hipMalloc(&d_count, sizeof(unsigned long long)));
-    hipError_t e = rocprim::radix_sort_keys(nullptr, sort_bytes, keys, tmp, n, 0, 64, s);
+    hipError_t e = hipMalloc(&tmp, n * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMalloc(&d_count, sizeof(unsigned long long));
+    if (e == hipSuccess) e = rocprim::radix_sort_keys(nullptr, sort_bytes, keys, tmp, n, 0, 64, s);
     if (e == hipSuccess) e = rocprim::unique(nullptr, uniq_bytes, tmp, keys, d_count, n, rocprim::equal_to<unsigned long long>(), s);
     const size_t bytes = sort_bytes > uniq_bytes ? sort_bytes : uniq_bytes;
     if (e == hipSuccess) e = hipMalloc(&scratch, bytes ? bytes : 16);
@@ -69,8 +69,8 @@ int bl_sort_unique_u64(bl_ctx* ctx, uint64_t* d_keys, uint64_t n, uint64_t* n_un
     unsigned long long cnt = 0;
     if (e == hipSuccess) e = hipMemcpyAsync(&cnt, d_count, sizeof(cnt), hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
-    (void)hipFree(tmp);
-    (void)hipFree(d_count);
+    if (tmp) (void)hipFree(tmp);
+    if (d_count) (void)hipFree(d_count);
     if (scratch) (void)hipFree(scratch);
     if (e != hipSuccess) return bl_set_error(e == hipErrorOutOfMemory ? BL_ERR_OOM : BL_ERR_HIP, hipGetErrorString(e));
     *n_unique = cnt;

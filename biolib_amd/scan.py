@@ -37,14 +37,31 @@ class Context:
         self._h = h
         self._batches = weakref.WeakSet()
         self._pending = []  # Result structs of asynchronous scans: the library fills them at the next sync
+        self._borrowed = bool(torch_stream)
         if torch_stream:
-            # run on torch's current stream so torch.cuda.Event / torch allocations are ordered with the scans
-            with torch.cuda.device(self.device):
-                s = torch.cuda.current_stream(self.device).cuda_stream
-            check(self._lib.bl_ctx_set_stream(self._h, C.c_void_p(s)))
+            self.use_torch_stream()
         elif lanes != 1:
             # own streams only: consecutive asynchronous scans overlap (they must not share output arrays)
             check(self._lib.bl_ctx_set_lanes(self._h, int(lanes)))
+
+    def use_torch_stream(self):
+        """Run on torch's CURRENT stream (call again after switching torch streams): scans, set operations, torch kernels
+        and RCCL collectives are then ordered with each other.  torch's default stream is the legacy stream, handle 0,
+        which bl_ctx_set_stream honours as a stream (it does not mean "unset")."""
+        import torch
+
+        with torch.cuda.device(self.device):
+            s = torch.cuda.current_stream(self.device).cuda_stream
+        check(self._lib.bl_ctx_set_stream(self._h, C.c_void_p(s)))
+        self._borrowed = True
+
+    def _inputs_ready(self):
+        """A context on its own streams is not ordered with torch: tensors produced by pending torch work (kernels,
+        all-to-all payloads) must be complete before the library reads them."""
+        if not self._borrowed:
+            import torch
+
+            torch.cuda.current_stream(self.device).synchronize()
 
     def close(self):
         if getattr(self, "_h", None):
@@ -71,9 +88,13 @@ class Context:
     def kernel_timing(self, enable=True):
         check(self._lib.bl_ctx_kernel_timing(self._h, 1 if enable else 0))
 
-    def _trim_pending(self):
-        if len(self._pending) > 4096:
+    def _hold(self, result, flags):
+        """an asynchronous scan fills `result` at a later sync: keep it alive until then (bounded)"""
+        if flags & FLAG_SYNC:
+            return
+        if len(self._pending) >= 4096:
             self.sync()
+        self._pending.append(result)
 
     def kernel_time(self):
         """(total ms, launches) of the scan kernels alone since kernel_timing(True)."""
@@ -106,6 +127,7 @@ class Context:
 
     def from_tensor(self, t, offsets=None, read_len=0):
         """Wrap a uint8 CUDA tensor of ASCII bases (not copied; must stay alive)."""
+        self._inputs_ready()
         assert t.is_cuda and t.dtype.itemsize == 1 and t.is_contiguous()
         offs = None if offsets is None else np.ascontiguousarray(offsets, dtype=np.uint64)
         h = C.c_void_p()
@@ -120,12 +142,14 @@ class Context:
     def sort_unique(self, keys, n=None):
         """in-place sort + unique of keys[:n]; returns the number of distinct keys now at the front"""
         n = keys.numel() if n is None else int(n)
+        self._inputs_ready()
         out = C.c_uint64()
         check(self._lib.bl_sort_unique_u64(self._h, C.c_void_p(keys.data_ptr()), n, C.byref(out)))
         return int(out.value)
 
     def jaccard(self, a, na, b, nb):
         """(|A n B|, |A u B|) of two sorted duplicate-free key arrays"""
+        self._inputs_ready()
         i, u = C.c_uint64(), C.c_uint64()
         check(self._lib.bl_jaccard_sorted_u64(self._h, C.c_void_p(a.data_ptr()), int(na), C.c_void_p(b.data_ptr()), int(nb), C.byref(i), C.byref(u)))
         return int(i.value), int(u.value)
@@ -133,6 +157,7 @@ class Context:
     def partition(self, keys, parts, seed=0, n=None):
         """(bucketed copy of keys[:n], sizes[parts]): bucket b = keys with hash64(key, seed) % parts == b, contiguous, in bucket order"""
         n = keys.numel() if n is None else int(n)
+        self._inputs_ready()
         out = self.empty_u64(n)
         counts = (C.c_uint64 * int(parts))()
         check(self._lib.bl_partition_u64(self._h, C.c_void_p(keys.data_ptr()), n, int(parts), int(seed), C.c_void_p(out.data_ptr()), counts))
@@ -143,6 +168,7 @@ class Context:
         import torch
 
         n = keys.numel() if n is None else int(n)
+        self._inputs_ready()
         check(self._lib.bl_sort_u64(self._h, C.c_void_p(keys.data_ptr()), n))
         uniq = self.empty_u64(n)
         mult = torch.empty(max(n, 1), dtype=torch.int32, device=self.torch_device)
@@ -155,6 +181,7 @@ class Context:
         import torch
 
         n = records.shape[0] if n is None else int(n)
+        self._inputs_ready()
         out = torch.empty((max(n, 1), 2), dtype=torch.int64, device=self.torch_device)
         counts = (C.c_uint64 * int(parts))()
         check(self._lib.bl_partition_records(self._h, C.c_void_p(hashes.data_ptr()), C.c_void_p(records.data_ptr()), n, int(parts), C.c_void_p(out.data_ptr()), counts))
@@ -163,6 +190,7 @@ class Context:
     def expand_super_kmers(self, records, k, canonical=True, n=None):
         """the k-mers (device tensor) the packed super-k-mer records stand for, group after group"""
         n = records.shape[0] if n is None else int(n)
+        self._inputs_ready()
         need = C.c_uint64()
         flags = FLAG_CANONICAL if canonical else 0
         rc = self._lib.bl_expand_super_kmers(self._h, C.c_void_p(records.data_ptr()), n, int(k), flags, None, 0, C.byref(need))
@@ -238,20 +266,20 @@ class Batch:
     # ---- raw (asynchronous) entry points: device tensors in, Result filled after ctx.sync()
     def kmers_raw(self, k, seed, flags, first=0, n=0, values=None, hashes=None, valid=None, result=None):
         result = result if result is not None else Result()
-        self.ctx._pending.append(result)  # must outlive the call: filled asynchronously
+        self.ctx._hold(result, flags)
         check(self._lib.bl_scan_kmers(self.ctx._h, self._h, first, n, k, seed, flags, _ptr(values), _ptr(hashes), _ptr(valid), C.byref(result)))
         return result
 
     def minimizers_raw(self, unit, w, seed, flags, first=0, n=0, values=None, positions=None, hashes=None, capacity=0, result=None):
         result = result if result is not None else Result()
-        self.ctx._pending.append(result)  # must outlive the call: filled asynchronously
+        self.ctx._hold(result, flags)
         check(self._lib.bl_scan_minimizers(self.ctx._h, self._h, first, n, unit, w, seed, flags, _ptr(values), _ptr(positions), _ptr(hashes),
                                            capacity, C.byref(result)))
         return result
 
     def hash_sample_raw(self, k, seed, threshold, flags, first=0, n=0, values=None, positions=None, hashes=None, capacity=0, result=None):
         result = result if result is not None else Result()
-        self.ctx._pending.append(result)  # must outlive the call: filled asynchronously
+        self.ctx._hold(result, flags)
         check(self._lib.bl_scan_hash_sample(self.ctx._h, self._h, first, n, k, seed, threshold, flags, _ptr(values), _ptr(positions), _ptr(hashes),
                                             capacity, C.byref(result)))
         return result
@@ -259,14 +287,14 @@ class Batch:
     def super_kmers_raw(self, k, m, seed, flags, first=0, n=0, minimizers=None, first_pos=None, mm_pos=None, sizes=None, hashes=None,
                         capacity=0, result=None):
         result = result if result is not None else Result()
-        self.ctx._pending.append(result)  # must outlive the call: filled asynchronously
+        self.ctx._hold(result, flags)
         check(self._lib.bl_scan_super_kmers(self.ctx._h, self._h, first, n, k, m, seed, flags, _ptr(minimizers), _ptr(first_pos), _ptr(mm_pos),
                                             _ptr(sizes), _ptr(hashes), capacity, C.byref(result)))
         return result
 
     def syncmers_raw(self, k, s, soff, eoff, seed, flags, first=0, n=0, positions=None, capacity=0, result=None):
         result = result if result is not None else Result()
-        self.ctx._pending.append(result)  # must outlive the call: filled asynchronously
+        self.ctx._hold(result, flags)
         check(self._lib.bl_scan_syncmers(self.ctx._h, self._h, first, n, k, s, soff, eoff, seed, flags, _ptr(positions), capacity, C.byref(result)))
         return result
 

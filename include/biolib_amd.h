@@ -48,7 +48,7 @@ enum {
     BL_ERR_OOM = -3,         /* device or pinned-host allocation failed */
     BL_ERR_CAPACITY = -4,    /* output arrays too small: result.count says how many records exist */
     BL_ERR_NO_DEVICE = -5,   /* no gfx950 device visible */
-    BL_ERR_INTERNAL = -6     /* inter-tile protocol timed out (never expected; results invalid) */
+    BL_ERR_INTERNAL = -6     /* an internal consistency check failed (never expected; results invalid) */
 };
 
 enum {
@@ -68,7 +68,7 @@ typedef struct bl_result {
     uint64_t xor_hash;   /* XOR of their 64-bit hashes */
     uint64_t xor_pos;    /* XOR of their global positions (k-mer scan: wrapping SUM of hashes instead) */
     uint64_t aux;        /* super-k-mers: number of group ends seen (== count when consistent) */
-    int32_t status;      /* BL_OK, BL_ERR_CAPACITY or BL_ERR_INTERNAL */
+    int32_t status;      /* BL_OK or BL_ERR_CAPACITY */
     int32_t reserved;
 } bl_result;
 
@@ -81,9 +81,13 @@ int bl_ctx_create(int device, bl_ctx** out);
 /* Destroying a context also destroys the batches created on it that are still alive (their handles
  * become invalid). */
 int bl_ctx_destroy(bl_ctx* ctx);
-/* Borrow the caller's HIP stream (e.g. torch.cuda.current_stream().cuda_stream).  NULL = back to the
- * context's own stream. */
+/* Borrow the caller's HIP stream (e.g. torch.cuda.current_stream().cuda_stream): every call of this context is then
+ * enqueued on it, in order with the caller's own work.  NULL is a stream like any other here — the legacy default
+ * stream, which is what torch's default stream is — so a NULL handle is honoured, not read as "unset".
+ * bl_ctx_use_own_streams returns to the context's own (non-blocking) streams, which are NOT ordered with any other
+ * stream: device buffers handed to the library must then be complete (synchronise the producing stream first). */
 int bl_ctx_set_stream(bl_ctx* ctx, void* hip_stream);
+int bl_ctx_use_own_streams(bl_ctx* ctx);
 int bl_ctx_sync(bl_ctx* ctx);
 /* Execution lanes of a context that runs on its own streams: with n = 2 consecutive asynchronous scans alternate between two
  * streams, staggered so that the record pass of one scan runs beside the hashing pass of the next (+12 % on MI355X).  Scans in
