@@ -115,9 +115,10 @@ struct bl_batch {
     bl_ctx* ctx = nullptr;
     uint8_t* bases = nullptr;
     bool owns_bases = false;
-    uint32_t* start_bits = nullptr;  // nullptr: single sequence
+    uint32_t* start_bits = nullptr;  // nullptr: single sequence, or fixed-length reads whose vector has not been needed yet
     uint64_t n_bases = 0;
     uint64_t n_seqs = 0;
+    uint64_t read_len = 0;           // != 0: every sequence has this length (the last one may be shorter)
 };
 
 namespace {
@@ -308,6 +309,17 @@ int make_start_bits(bl_ctx* c, bl_batch* b, const uint64_t* offsets, uint64_t n_
         BL_HIP(hipStreamSynchronize(c->stream));  // the batch may be scanned from either lane
     }
     return BL_OK;
+}
+
+// Fixed-length reads: where a read starts is arithmetic, and the read-tiled scans (bl_scan_frl.hpp) never look at the
+// 1-bit-per-base vector (6.25 GB for a 50-Gbp batch).  It is only built when a position-tiled scan first needs it.
+int ensure_start_bits(bl_ctx* c, const bl_batch* cb)
+{
+    bl_batch* b = const_cast<bl_batch*>(cb);  // the handle is the library's own object
+    if (b->start_bits || b->read_len == 0 || b->read_len >= b->n_bases) return BL_OK;
+    int rc = sync_ctx(c);  // no scan of this batch is in flight while its description changes
+    if (rc != BL_OK) return rc;
+    return make_start_bits(c, b, nullptr, 0, b->read_len);
 }
 
 }  // namespace
@@ -508,7 +520,19 @@ int bl_batch_upload(bl_ctx* c, const char* bases, uint64_t n_bases, const uint64
     e = hipMemsetAsync(b->bases + (n_bases & ~15ull), 0, 64 + (n_bases & 15ull), c->stream);
     if (e == hipSuccess && n_bases) e = hipMemcpyAsync(b->bases, bases, n_bases, hipMemcpyHostToDevice, c->stream);
     if (e != hipSuccess) { bl_batch_destroy(b); return fail(BL_ERR_HIP, std::string("upload: ") + hipGetErrorString(e)); }
-    rc = make_start_bits(c, b, offsets, n_seqs, 0);
+    uint64_t fixed = 0;  // offsets that describe equal-length reads (the usual short-read batch) need no start-bit vector
+    if (offsets && n_seqs > 1 && offsets[0] == 0 && offsets[n_seqs] == n_bases && offsets[1] > 0 && offsets[1] < n_bases) {
+        fixed = offsets[1];
+        for (uint64_t q = 1; q < n_seqs && fixed; ++q)
+            if (offsets[q] != q * fixed) fixed = 0;
+        if (fixed && (n_bases - offsets[n_seqs - 1] > fixed || n_bases == offsets[n_seqs - 1])) fixed = 0;
+    }
+    if (fixed) {
+        b->read_len = fixed;
+        b->n_seqs = n_seqs;
+    } else {
+        rc = make_start_bits(c, b, offsets, n_seqs, 0);
+    }
     if (rc == BL_OK) {
         e = hipStreamSynchronize(c->stream);  // the host buffer may go away after we return
         if (e != hipSuccess) rc = fail(BL_ERR_HIP, std::string("upload sync: ") + hipGetErrorString(e));
@@ -530,8 +554,13 @@ int bl_batch_from_device(bl_ctx* c, const void* d_bases, uint64_t n_bases, const
     }
     b->bases = const_cast<uint8_t*>(static_cast<const uint8_t*>(d_bases));
     b->owns_bases = false;
-    rc = make_start_bits(c, b, offsets, n_seqs, read_len);
-    if (rc != BL_OK) { bl_batch_destroy(b); return rc; }
+    if (!offsets && read_len > 0 && read_len < n_bases) {  // fixed-length reads: the start-bit vector is built on demand
+        b->read_len = read_len;
+        b->n_seqs = (n_bases + read_len - 1) / read_len;
+    } else {
+        rc = make_start_bits(c, b, offsets, n_seqs, read_len);
+        if (rc != BL_OK) { bl_batch_destroy(b); return rc; }
+    }
     *out = b;
     return BL_OK;
 }
@@ -547,7 +576,12 @@ int bl_batch_synth(bl_ctx* c, uint64_t seed, uint64_t n_bases, uint64_t read_len
     e = hipMemsetAsync(b->bases + (n_bases & ~15ull), 0, 64 + (n_bases & 15ull), c->stream);
     if (e == hipSuccess) e = bl::launch_synth(b->bases, 0, n_bases, seed, c->stream);
     if (e != hipSuccess) { bl_batch_destroy(b); return fail(BL_ERR_HIP, std::string("synth: ") + hipGetErrorString(e)); }
-    rc = make_start_bits(c, b, nullptr, 0, read_len);
+    if (read_len > 0 && read_len < n_bases) {
+        b->read_len = read_len;
+        b->n_seqs = (n_bases + read_len - 1) / read_len;
+    } else {
+        rc = make_start_bits(c, b, nullptr, 0, read_len);
+    }
     if (rc == BL_OK && hipStreamSynchronize(c->stream) != hipSuccess) rc = fail(BL_ERR_HIP, "synth sync failed");
     if (rc != BL_OK) { bl_batch_destroy(b); return rc; }
     *out = b;
@@ -624,6 +658,8 @@ int bl_scan_kmers(bl_ctx* c, const bl_batch* b, uint64_t first, uint64_t n, uint
     int rc = check_range(b, first, n, end);
     if (rc != BL_OK) return rc;
     if (end <= first) return zero_result(c, result, flags);
+    rc = ensure_start_bits(c, b);
+    if (rc != BL_OK) return rc;
     bl::KmerParams p{};
     p.bases = b->bases;
     p.n_bases = (int64_t)b->n_bases;
@@ -664,8 +700,19 @@ static int scan_windows(int mode, bl_ctx* c, const bl_batch* b, uint64_t first, 
     if (end <= first) return zero_result(c, result, flags);
     p.bases = b->bases;
     p.n_bases = (int64_t)b->n_bases;
-    p.start_bits = b->start_bits;
     bl::plan_scan(mode, (int64_t)first, (int64_t)end, (int)w, p);
+    // fixed-length short reads, range aligned to reads: the read-tiled layout (no start bits, no hashing of positions
+    // that cannot start a unit) when it pays; BL_NO_FRL=1 keeps the position-tiled kernels (A/B measurements)
+    static const bool no_frl = std::getenv("BL_NO_FRL") != nullptr;
+    if (b->read_len && !no_frl && !p.use_threshold && bl::frl_width_built(mode, (int)w)) {
+        const bool tuned = mode == bl::MODE_MINIMIZER && w == 11 && unit == 31 && (flags & BL_FLAG_CANONICAL) && b->read_len == 150;
+        bl::plan_scan_frl((int64_t)first, (int64_t)end, (int64_t)b->n_bases, (int64_t)b->read_len, (int)unit, (int)w, tuned ? 0 : bl::S, p);
+    }
+    if (!p.frl) {
+        rc = ensure_start_bits(c, b);
+        if (rc != BL_OK) return rc;
+    }
+    p.start_bits = b->start_bits;
     p.unit = (int32_t)unit;
     p.w = (int32_t)w;
     p.seed = (uint32_t)seed;
@@ -681,7 +728,7 @@ static int scan_windows(int mode, bl_ctx* c, const bl_batch* b, uint64_t first, 
     const size_t n_lists = mode == bl::MODE_SUPERKMER ? 3 : 1;
     const size_t slot_entries = nt * (size_t)p.stride;
     const size_t list_bytes = n_lists * slot_entries * sizeof(uint16_t);  // multiple of 32 bytes (stride % 16 == 0)
-    rc = grow(c, reinterpret_cast<void**>(&c->cur->slot_buf), &c->cur->slot_buf_bytes, list_bytes + nt * bl::NCHUNK * sizeof(uint32_t));
+    rc = grow(c, reinterpret_cast<void**>(&c->cur->slot_buf), &c->cur->slot_buf_bytes, list_bytes + nt * (size_t)p.slot_chunks * sizeof(uint32_t));
     if (rc != BL_OK) return rc;
     unsigned long long* tb = reinterpret_cast<unsigned long long*>(c->cur->tile_buf);
     p.tile_counts = tb;

@@ -2,7 +2,7 @@
 // Written for CDNA4 only (wave64, 256-thread workgroups, LDS-staged tiles); no portability layer.
 #include <hip/hip_runtime.h>
 #include <cstdlib>
-#include "bl_scan_phases.hpp"
+#include "bl_scan_frl.hpp"
 #include "bl_launch.hpp"
 
 namespace bl {
@@ -107,7 +107,7 @@ __device__ __forceinline__ void count_tile(const ScanParams& p, TileShared<MODE,
     phase_load<MODE, W>(p, sh, tid, q0);
     {   // hand the packed codes to pass 2 (0.26 B/base instead of re-reading and re-encoding 1 B/base there)
         const int needed = staged_chunks(p);
-        uint32_t* sc = p.slots_c + (size_t)tile * NCHUNK;
+        uint32_t* sc = p.slots_c + (size_t)tile * p.slot_chunks;
         if (tid < needed) sc[tid] = sh.codes[tid];  // own LDS entries: no barrier needed
         if (TPB + tid < needed) sc[TPB + tid] = sh.codes[TPB + tid];
     }
@@ -143,18 +143,49 @@ __device__ __forceinline__ void count_tile(const ScanParams& p, TileShared<MODE,
     }
 }
 
+// Pass 1 of one tile in the read-tiled layout (fixed-length short reads, bl_scan_frl.hpp): same outputs as count_tile.
+template <int MODE, int W, int NS>
+__device__ __forceinline__ void count_tile_frl(const ScanParams& p, TileShared<MODE, W>& sh, uint32_t tile, int tid)
+{
+    const int64_t q0 = tile_q0(p, tile);
+    phase_load_frl<MODE, W>(p, sh, tid, q0);
+    {   // hand the packed codes to pass 2
+        uint32_t* sc = p.slots_c + (size_t)tile * p.slot_chunks;
+        for (int c = tid; c < p.slot_chunks; c += TPB) sc[c] = sh.codes[c];  // own LDS entries: no barrier needed
+    }
+    __syncthreads();
+
+    ThreadState st;
+    phase_hash_frl<MODE, W, NS>(p, sh, tid, q0, tile, st);
+    phase_window_frl_a<MODE, W, NS>(p, sh, tid, st, nullptr);
+    const uint32_t packed = phase_window_frl_b<MODE, W, NS>(p, tid, st, nullptr);
+
+    uint32_t total;
+    const uint32_t excl = block_excl_scan(packed, sh.wave_tot, tid, total);
+    const uint32_t n_s = total & 0xffffu, n_e = total >> 16;
+    phase_list_frl<MODE, W>(sh, st, excl & 0xffffu, excl >> 16);
+    if (tid == 0) p.tile_counts[tile] = (unsigned long long)n_s | ((unsigned long long)n_e << 32);
+    __syncthreads();  // lists complete
+    const size_t slot = (size_t)tile * p.stride;  // stride is a multiple of 4 entries: dword aligned
+    spill_list(p.slots_a + slot, sh.list_a, n_s, tid);
+    if (MODE == MODE_SUPERKMER) {
+        spill_list(p.slots_j + slot, sh.list_j, n_s, tid);
+        spill_list(p.slots_e + slot, sh.list_e, n_e, tid);
+    }
+}
+
 // Pass 2 of one tile: reload the tile's 2-bit codes (spilled by pass 1), rebuild each record from its u16 list entry
 // (unit value, hash, position) and store it at the tile's global offset with coalesced stores.
 template <int MODE, int W>
 __device__ __forceinline__ void emit_tile(const ScanParams& p, TileShared<MODE, W>& sh, uint32_t tile, int tid, Digest& dg)
 {
     // one memory round trip: every load of the tile is issued before the first one is consumed
-    const int64_t q0 = p.origin + (int64_t)tile * p.stride;
+    const int64_t q0 = tile_q0(p, tile);
     const size_t slot = (size_t)tile * p.stride;
     const unsigned long long cnt = p.tile_counts[tile];
     const unsigned long long base = p.tile_base[tile] + p.block_base[tile / SCAN_BLK];
     const int needed = staged_chunks(p);
-    const uint32_t* sc = p.slots_c + (size_t)tile * NCHUNK;
+    const uint32_t* sc = p.slots_c + (size_t)tile * p.slot_chunks;
     const uint32_t c0 = tid < needed ? sc[tid] : 0;
     const uint32_t c1 = TPB + tid < needed ? sc[TPB + tid] : 0;
     // the first 2*TPB list entries speculatively (a tile of 150-bp reads holds ~545)
@@ -197,6 +228,30 @@ __global__ __launch_bounds__(TPB, (MODE == MODE_SYNCMER || (MODE == MODE_SUPERKM
     }
     if (C >= 0) p.canonical = C;
     if (blockIdx.x < g.count) count_tile<MODE, W>(p, sh, g.first + blockIdx.x, threadIdx.x);
+}
+
+// Read-tiled pass 1.  L (read length) and U, C specialise the headline configuration as in scan_count_kernel; L fixes
+// the whole lane -> (read, unit) map at compile time (lanes per read, reads per wave, windows per read).
+template <int MODE, int W, int NS, int U, int L, int C>
+__global__ __launch_bounds__(TPB, (W <= 11 ? 5 : 4)) void scan_count_frl_kernel(const ScanParams pin, GroupRange g)
+{
+    __shared__ TileShared<MODE, W> sh;
+    ScanParams p = pin;
+    p.w = W;
+    p.ns = NS;
+    if (U != 0) p.unit = U;
+    if (C >= 0) p.canonical = C;
+    if (L != 0) {  // plan_scan_frl's values for (L, U, W, NS), as constants
+        constexpr int nu = L - U + 1, lpr = (nu + S - 1) / S, rpw = 64 / (lpr > 0 ? lpr : 1);
+        p.read_len = L;
+        p.lpr = lpr;
+        p.rpw = rpw;
+        p.nwin = nu - W + 1;
+        p.lpr_inv = (65536u + lpr - 1) / lpr;
+        p.stride = NWAVE * rpw * L;
+        p.slot_chunks = (15 + NWAVE * rpw * L + 15) / 16 + 3;
+    }
+    if (blockIdx.x < g.count) count_tile_frl<MODE, W, NS>(p, sh, g.first + blockIdx.x, threadIdx.x);
 }
 
 template <int MODE>
@@ -292,8 +347,8 @@ __global__ void tile_scan_top_kernel(const unsigned long long* block_tot, unsign
 // ------------------------------------------------------------------------------------------------
 // Dense k-mer scan kernel (C2): no windows, no compaction.
 struct KmerShared {
-    uint32_t codes[NCHUNK];
-    uint32_t flags[NCHUNK];
+    uint32_t codes[NCHUNK_POS];
+    uint32_t flags[NCHUNK_POS];
     unsigned long long dig[4];
 };
 
@@ -311,7 +366,7 @@ __global__ __launch_bounds__(TPB) void kmer_kernel(const KmerParams p)
         const int64_t q0 = p.origin + (int64_t)tile * H;
         __syncthreads();
         stage_chunk(lp, sh.codes, sh.flags, tid, q0);
-        if (tid < NCHUNK - TPB) stage_chunk(lp, sh.codes, sh.flags, TPB + tid, q0);
+        if (tid < NCHUNK_POS - TPB) stage_chunk(lp, sh.codes, sh.flags, TPB + tid, q0);
         __syncthreads();
         kmer_thread(p, sh.codes, sh.flags, tid, q0, acc);
     }
@@ -415,6 +470,30 @@ __global__ void start_bits_offsets_kernel(uint32_t* bits, const uint64_t* offset
 // ------------------------------------------------------------------------------------------------
 // launchers
 
+static hipError_t launch_count_frl(int mode, const ScanParams& p, GroupRange g, hipStream_t stream)
+{
+    const dim3 grid(g.count), block(TPB);
+    if (mode == MODE_MINIMIZER && p.w == 11 && p.unit == 31 && p.canonical && p.read_len == 150 && p.ns == 15 && p.rpw == 8) {
+        hipLaunchKernelGGL((scan_count_frl_kernel<MODE_MINIMIZER, 11, 15, 31, 150, 1>), grid, block, 0, stream, p, g);  // BASELINE C3
+        return hipGetLastError();
+    }
+    if (p.ns != S) return hipErrorInvalidValue;  // the general kernels give every lane S unit starts
+    if (mode == MODE_MINIMIZER) {
+        switch (p.w) {
+            case 5: hipLaunchKernelGGL((scan_count_frl_kernel<MODE_MINIMIZER, 5, S, 0, 0, -1>), grid, block, 0, stream, p, g); break;
+            case 10: hipLaunchKernelGGL((scan_count_frl_kernel<MODE_MINIMIZER, 10, S, 0, 0, -1>), grid, block, 0, stream, p, g); break;
+            case 11: hipLaunchKernelGGL((scan_count_frl_kernel<MODE_MINIMIZER, 11, S, 0, 0, -1>), grid, block, 0, stream, p, g); break;
+            case 19: hipLaunchKernelGGL((scan_count_frl_kernel<MODE_MINIMIZER, 19, S, 0, 0, -1>), grid, block, 0, stream, p, g); break;
+            default: return hipErrorInvalidValue;
+        }
+    } else if (mode == MODE_SUPERKMER && p.w == 17) {
+        hipLaunchKernelGGL((scan_count_frl_kernel<MODE_SUPERKMER, 17, S, 0, 0, -1>), grid, block, 0, stream, p, g);
+    } else {
+        return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
 template <int MODE>
 static hipError_t launch_count_mode(const ScanParams& p, GroupRange g, hipStream_t stream)
 {
@@ -462,6 +541,7 @@ static hipError_t launch_count_mode(const ScanParams& p, GroupRange g, hipStream
 hipError_t launch_scan_count(int mode, const ScanParams& p, GroupRange g, hipStream_t stream)
 {
     if (g.count == 0) return hipSuccess;
+    if (p.frl) return launch_count_frl(mode, p, g, stream);
     switch (mode) {
         case MODE_MINIMIZER: return launch_count_mode<MODE_MINIMIZER>(p, g, stream);
         case MODE_SUPERKMER: return launch_count_mode<MODE_SUPERKMER>(p, g, stream);

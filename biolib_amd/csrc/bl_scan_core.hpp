@@ -28,11 +28,13 @@ namespace bl {
 constexpr int TPB = 256;            // threads per workgroup (4 wave64)
 constexpr int S = 16;               // window/unit start positions owned by one thread (= one 16-byte load)
 constexpr int H = TPB * S;          // positions hashed per tile
-constexpr int NCHUNK = H / 16 + 8;  // 16-base chunks staged per tile (halo of up to 128 bases)
+constexpr int NCHUNK = 512;         // 16-base chunks a tile may stage (position-tiled scans use H / 16 + 8 of them, read-tiled ones more)
+constexpr int NCHUNK_POS = H / 16 + 8;  // position-tiled scans: one chunk per thread plus a halo of up to 128 bases
 constexpr int MAX_UNIT = 32;        // KmerType = uint64_t only
 constexpr int MAX_W = 64;
 constexpr int NSHARD = 256;         // digest accumulator shards (one 64-byte line each)
 constexpr int SCAN_BLK = 2048;      // tiles per block of the tile-count prefix scan
+constexpr int NWAVE_CORE = TPB / 64;
 
 enum ScanMode { MODE_MINIMIZER = 0, MODE_SUPERKMER = 1, MODE_SYNCMER = 2 };
 
@@ -69,9 +71,65 @@ struct ScanParams {
     uint16_t* slots_a;                // [n_tiles][stride] list_a of every tile (first `starts` entries valid)
     uint16_t* slots_j;                // super-k-mer: list_j
     uint16_t* slots_e;                // super-k-mer: list_e (first `ends` entries valid)
-    uint32_t* slots_c;                // [n_tiles][NCHUNK] the tile's 2-bit codes (pass 2 rebuilds unit values from them)
+    uint32_t* slots_c;                // [n_tiles][slot_chunks] the tile's 2-bit codes (pass 2 rebuilds unit values from them)
+    int32_t slot_chunks;              // chunks a tile stages and hands to pass 2 (<= NCHUNK)
     unsigned long long* shards;       // [NSHARD][8] digest accumulators
+    // Read-tiled layout (bl_scan_frl.hpp): batches of FIXED-LENGTH short reads, range aligned to reads.  A wave takes
+    // rpw whole reads, lpr lanes per read, ns consecutive unit starts per lane: the unit-1 tail positions of a read,
+    // which cannot start a unit, are never rolled or hashed, sequence starts are arithmetic (no start_bits), and there
+    // is no halo between wave tiles.  origin = first base of the range, stride = NWAVE * rpw * read_len bases per tile.
+    int32_t frl;                      // 0: position-tiled layout
+    int32_t read_len;
+    int32_t lpr, rpw, ns;
+    int32_t nwin;                     // windows per read = read_len - unit - w + 2
+    uint32_t lpr_inv;                 // ceil(65536 / lpr): lane / lpr == (lane * lpr_inv) >> 16 for lane < 64
+    int64_t n_reads;                  // reads in the range
 };
+
+// widths the read-tiled kernels are built for (bl_kernels.hip: launch_count_frl; the emulation harness instantiates the same set)
+BL_DEV bool frl_width_built(int mode, int w)
+{
+    return (mode == MODE_MINIMIZER && (w == 11 || w == 5 || w == 10 || w == 19)) || (mode == MODE_SUPERKMER && w == 17);
+}
+
+// Read-tiled plan for a range of fixed-length reads.  ns_fixed: units per lane the kernel was compiled for (0: choose).
+// Returns false when the layout does not apply (long reads, windows that do not fit, LDS bound) or would hash MORE
+// positions per useful window than the position-tiled layout.
+BL_DEV bool plan_scan_frl(int64_t first, int64_t end, int64_t n_bases, int64_t read_len, int unit, int w, int ns_fixed, ScanParams& p)
+{
+    if (read_len <= 0 || read_len > 4096 || first % read_len != 0) return false;
+    if (end % read_len != 0 || end > n_bases || end <= first) return false;
+    const int L = (int)read_len;
+    const int nu = L - unit + 1, nwin = nu - w + 1;
+    if (nwin < 1 || w < 2) return false;
+    const int lpr = (nu + S - 1) / S;
+    if (lpr > 64) return false;
+    const int ns = ns_fixed ? ns_fixed : (nu + lpr - 1) / lpr;
+    if (ns * lpr < nu || ns > S || w - 1 > 3 * ns) return false;     // halo of at most three lanes
+    int rpw = 64 / lpr;
+    const int cap = (NCHUNK * 16 - 64 - 32) / NWAVE_CORE / L;        // every staged chunk of a tile must fit NCHUNK
+    if (rpw > cap) rpw = cap;
+    if (rpw < 1) return false;
+    // useful windows per hashed lane-slot, both layouts (64 lanes x 16 slots per wave tile)
+    const double frl_eff = (double)(rpw * nwin) / (64.0 * ns);
+    const double pos_eff = (double)nwin / L * (double)(64 * S - 16 * ((w + 15) / 16)) / (64.0 * S);
+    if (frl_eff <= pos_eff) return false;
+    p.frl = 1;
+    p.read_len = L;
+    p.lpr = lpr;
+    p.rpw = rpw;
+    p.ns = ns;
+    p.nwin = nwin;
+    p.lpr_inv = (65536u + (uint32_t)lpr - 1) / (uint32_t)lpr;
+    p.n_reads = (end - first) / L;
+    p.win_first = first;
+    p.win_end = end;
+    p.origin = first;
+    p.stride = NWAVE_CORE * rpw * L;
+    p.n_tiles = (int32_t)((p.n_reads + NWAVE_CORE * rpw - 1) / (NWAVE_CORE * rpw));
+    p.slot_chunks = (15 + p.stride + 15) / 16 + 3;
+    return true;
+}
 
 // a contiguous group of tiles handled by one stage of the software pipeline
 struct GroupRange {
@@ -90,6 +148,8 @@ BL_DEV void plan_scan(int mode, int64_t first, int64_t end, int w, ScanParams& p
     // minimizer modes: the owner of position i decides window i+1, so tile 0 starts one position early
     p.origin = align_down16(mode == MODE_SYNCMER ? first : first - 1);
     p.n_tiles = end > first ? (int32_t)((end - 1 - p.origin) / p.stride + 1) : 0;
+    p.frl = 0;
+    p.slot_chunks = NCHUNK_POS;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -1,0 +1,292 @@
+// bl_scan_frl.hpp — the READ-TILED layout of the minimizer / super-k-mer scan for batches of fixed-length short reads
+// (plan_scan_frl in bl_scan_core.hpp decides when it applies; 150-bp reads with k = 31, w = 11 is the headline case).
+//
+// The position-tiled layout (bl_scan_phases.hpp) gives every lane 16 consecutive POSITIONS; on 150-bp reads 30 of every
+// 150 positions cannot start a 31-mer, yet they are rolled, hashed and thrown away, and sequence starts are read from a
+// 1-bit-per-base vector.  Here a wave takes rpw whole reads, lpr lanes per read, and a lane takes NS consecutive UNIT
+// STARTS of its read (150 bp, k = 31: 8 reads per wave, 8 lanes per read, 15 units per lane = all 120 units of a read):
+//   * the unit-1 tail positions of a read are never hashed (1.27 x fewer hashes per useful window at C3),
+//   * reads do not share windows, so a wave needs no halo from the next wave tile,
+//   * where a read starts and which windows exist is arithmetic on (lane, slot): no start_bits, no flag gathering,
+//   * bases that are not ACGTUacgtu are the only thing left to look up, and only in tiles that hold one.
+// Semantics are those of the position-tiled scan (reference minimizer_view.hpp:229-245: the window is cleared at a break
+// and at a sequence end; leftmost minimum wins, :283,374) and the record order is the same, so both layouts produce
+// identical arrays; tests/emu runs these phases thread by thread against the oracle under ASan.
+#pragma once
+#include "bl_scan_phases.hpp"
+
+namespace bl {
+
+// global position the tile's staged chunk 0 starts at (both layouts)
+BL_DEV int64_t tile_q0(const ScanParams& p, uint32_t tile)
+{
+    const int64_t g = p.origin + (int64_t)tile * p.stride;
+    return p.frl ? (g & ~15LL) : g;  // read-tiled: origin >= 0, tiles start at a read, not at a 16-byte boundary
+}
+
+// ------------------------------------------------------------------------------------------------
+// Phase 1: coalesced 16-byte loads -> 2-bit codes + good-base bits; true if the chunk holds a break
+BL_DEV bool stage_chunk_frl(const ScanParams& p, uint32_t* codes, uint32_t* flags, int c, int64_t q0)
+{
+    const int64_t g = q0 + 16 * (int64_t)c;  // >= 0
+    uint32_t d[4] = {0, 0, 0, 0};
+    if (g + 16 <= p.n_bases) {
+        const Vec16 v = *reinterpret_cast<const Vec16*>(p.bases + g);
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    } else if (g < p.n_bases) {  // ragged end of the batch: byte-wise, zeros (= breaks) outside
+        for (int b = 0; b < 16; ++b) {
+            const int64_t q = g + b;
+            if (q < p.n_bases) d[b >> 2] |= (uint32_t)p.bases[q] << (8 * (b & 3));
+        }
+    }
+    uint32_t code, bad;
+    encode16(d, code, bad);
+    codes[c] = code;
+    flags[c] = ~bad & 0xffffu;
+    return bad != 0;
+}
+
+template <int MODE, int W>
+BL_DEV void phase_load_frl(const ScanParams& p, TileShared<MODE, W>& sh, int tid, int64_t q0)
+{
+    bool bad = false;
+    for (int c = tid; c < p.slot_chunks; c += TPB) bad |= stage_chunk_frl(p, sh.codes, sh.flags, c, q0);  // 2 rounds at most; the 2nd is a few lanes of wave 0
+    const int wv = wave_index(tid);
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(BL_CPU_EMU)
+    const bool any = wave_any(bad);
+    if ((tid & 63) == 0) sh.wave_bad[wv] = any ? 1u : 0u;
+#else
+    if ((tid & 63) == 0) sh.wave_bad[wv] = 0;  // threads of a wave are emulated in order
+    if (bad) sh.wave_bad[wv] = 1;
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------
+// Phase 2: which read and which units this lane owns; roll and hash them.
+template <int MODE, int W, int NS>
+BL_DEV void phase_hash_frl(const ScanParams& p, TileShared<MODE, W>& sh, int tid, int64_t q0, uint32_t tile, ThreadState& st)
+{
+    const int wv = wave_index(tid), lane = tid & 63;
+    const int r = (int)(((uint32_t)lane * p.lpr_inv) >> 16);  // read of this wave the lane works on
+    const int j = lane - r * p.lpr;                           // lane inside that read
+    const int64_t read_idx = ((int64_t)tile * NWAVE + wv) * p.rpw + r;
+    const bool active = r < p.rpw && read_idx < p.n_reads;
+    const int off0 = (int)(p.origin + (int64_t)tile * p.stride - q0);  // 0..15
+    const int base = active ? off0 + (wv * p.rpw + r) * p.read_len + j * NS : off0;
+    st.lane_base = base;
+    st.jlane = active ? j : -1;
+    // the lane's 48 bases from `base` on: four staged dwords funnel-shifted to the lane's own alignment
+    const uint32_t* cp = sh.codes + (base >> 4);
+    const uint32_t c0 = cp[0], c1 = cp[1], c2 = cp[2], c3 = cp[3];
+    const int sh2 = 2 * (base & 15);
+    const uint32_t a0 = (uint32_t)(((((uint64_t)c0 << 32) | c1) << sh2) >> 32);
+    const uint32_t a1 = (uint32_t)(((((uint64_t)c1 << 32) | c2) << sh2) >> 32);
+    const uint32_t a2 = (uint32_t)(((((uint64_t)c2 << 32) | c3) << sh2) >> 32);
+    Roller rr;
+    roller_start(rr, a0, a1, a2, p.unit);
+    BL_UNROLL
+    for (int s = 0; s < NS; ++s) {
+        roller_step(rr, s);
+        const uint64_t fw = roller_fwd(rr), rv = roller_rc(rr);
+        const uint64_t v = (p.canonical && rv < fw) ? rv : fw;  // minimizer_view.hpp:236-238
+        st.h[s] = murmur64(v, p.seed);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Neighbouring lanes: values of lane - 1 / lane + 1 (DPP wave shifts on the GPU, lane 0 / 63 get their own value back,
+// which no owned window ever uses; the emulation reads the neighbour's state).
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(BL_CPU_EMU)
+BL_DEV uint32_t dpp_next32(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, false); }  // wave_shl:1
+// the same with a chosen value for lane 63, which has no lane to read from
+BL_DEV uint32_t dpp_next32_or(uint32_t v, uint32_t last) { return (uint32_t)__builtin_amdgcn_update_dpp((int)last, (int)v, 0x130, 0xf, 0xf, false); }
+BL_DEV uint32_t dpp_prev32(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, false); }  // wave_shr:1
+#endif
+
+// Window argmins of a lane that owns NS elements: the W - 1 halo elements come from the following lanes, NS per hop.
+// a[i] = raw packed key (element index in its low 6 bits) or, after the exact branch, the plain element index.
+template <int NS, int W>
+BL_DEV void lane_window_argmin_frl(const ThreadState* all, int tid, const ThreadState& st, bool owns, uint32_t* a)
+{
+    constexpr int NE = W - 1, NK = NS + NE;  // NK <= 64: 6-bit tags
+    uint32_t key[NK];
+    BL_UNROLL
+    for (int s = 0; s < NS; ++s) key[s] = packed_key((uint32_t)(st.h[s] >> 32), s, true);
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(BL_CPU_EMU)
+    (void)all;
+    (void)tid;
+    {
+        uint32_t cur[NS];
+        BL_UNROLL
+        for (int x = 0; x < NS; ++x) cur[x] = key[x];
+        BL_UNROLL
+        for (int hop = 0; hop * NS < NE; ++hop) {
+            BL_UNROLL
+            for (int x = 0; x < NS; ++x) {
+                // lane 63 owns windows too (64 = rpw * lpr lanes at work) but has no lane to take a halo from: it gets pad
+                // keys with pairwise different prefixes, so that its (non-existent) halo windows never look like a hash tie
+                if (hop * NS + x < NE || (hop + 1) * NS + x < NE || (hop + 2) * NS + x < NE)
+                    cur[x] = dpp_next32_or(cur[x], (0x03fffff0u - (uint32_t)(4 * x + hop)) << 6) + (uint32_t)NS;
+                if (hop * NS + x < NE) key[(hop + 1) * NS + x] = cur[x];
+            }
+        }
+    }
+#else
+    {
+        const int lane = tid & 63;
+        for (int x = 0; x < NE; ++x) {
+            const int nb = lane + 1 + x / NS;
+            const uint32_t hi = nb < 64 ? (uint32_t)(all[tid + 1 + x / NS].h[x % NS] >> 32) : 0xDEADBEEFu;
+            key[NS + x] = packed_key(hi, NS + x, true);
+        }
+    }
+#endif
+    const uint32_t dmin = window_argmin_packed<NS, W, true, true>(key, a);
+    if (wave_any(owns && dmin < 64u)) {  // a prefix tie somewhere in the wave: the exact 64-bit form
+        uint64_t e[NK];
+        BL_UNROLL
+        for (int s = 0; s < NS; ++s) e[s] = st.h[s];
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(BL_CPU_EMU)
+        uint64_t cur[NS];
+        BL_UNROLL
+        for (int x = 0; x < NS; ++x) cur[x] = st.h[x];
+        BL_UNROLL
+        for (int hop = 0; hop * NS < NE; ++hop) {
+            BL_UNROLL
+            for (int x = 0; x < NS; ++x) {
+                if (hop * NS + x < NE || (hop + 1) * NS + x < NE || (hop + 2) * NS + x < NE) cur[x] = lane_next(cur[x]);
+                if (hop * NS + x < NE) e[(hop + 1) * NS + x] = cur[x];
+            }
+        }
+#else
+        const int lane = tid & 63;
+        for (int x = 0; x < NE; ++x) {
+            const int nb = lane + 1 + x / NS;
+            e[NS + x] = nb < 64 ? all[tid + 1 + x / NS].h[x % NS] : 0xDEADBEEFDEADBEEFull;
+        }
+#endif
+        window_argmin<NS, W, true>(e, a);
+    }
+}
+
+// bit s: every base of the window that starts at staged position base + s, span bases long, is one of ACGTUacgtu
+// (only run for tiles that hold a break)
+template <int NS>
+BL_DEV uint32_t frl_good_mask(const ScanParams& p, const uint32_t* flags, int base, int span)
+{
+    const int ch = base >> 4, off = base & 15;
+    uint64_t g[3] = {0, 0, 0};
+    for (int c = 0; c < 9; ++c) {  // 144 staged bits cover off + 15 + 95 positions
+        int idx = ch + c;
+        idx = idx < p.slot_chunks ? idx : p.slot_chunks - 1;  // beyond the staged tile: only windows that do not exist look there
+        g[c >> 2] |= (uint64_t)(flags[idx] & 0xffffu) << (16 * (c & 3));
+    }
+    Bits128 good;
+    good.lo = off ? (g[0] >> off) | (g[1] << (64 - off)) : g[0];
+    good.hi = off ? (g[1] >> off) | (g[2] << (64 - off)) : g[1];
+    return (uint32_t)and_run(good, span).lo & ((1u << NS) - 1);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Phase 3a: window argmins of the lane's NS windows and which of them exist.
+template <int MODE, int W, int NS>
+BL_DEV void phase_window_frl_a(const ScanParams& p, TileShared<MODE, W>& sh, int tid, ThreadState& st, const ThreadState* all)
+{
+    uint32_t a[S];
+    lane_window_argmin_frl<NS, (W > 1 ? W : 2)>(all, tid, st, st.jlane >= 0, a);
+    BL_UNROLL
+    for (int s = NS; s < S; ++s) a[s] = 0;
+    uint32_t apk[4];
+    BL_UNROLL
+    for (int q = 0; q < 4; ++q) {  // byte s of apk = element index of the argmin of window s
+        const uint32_t lo2 = byte_perm(a[4 * q + 1], a[4 * q], 0x0c0c0400u);
+        const uint32_t hi2 = byte_perm(a[4 * q + 3], a[4 * q + 2], 0x04000c0cu);
+        apk[q] = (lo2 | hi2) & 0x3f3f3f3fu;
+    }
+    st.apk0 = ((uint64_t)apk[1] << 32) | apk[0];
+    st.apk1 = ((uint64_t)apk[3] << 32) | apk[2];
+    st.a_first = a[0] & 63u;
+    st.a_last = a[NS - 1] & 63u;
+    // windows of the read: window index j * NS + s must be below nwin; breaks only where the tile holds one
+    uint32_t vmask = 0;
+    if (st.jlane >= 0) {
+        int lim = p.nwin - st.jlane * NS;
+        lim = lim < 0 ? 0 : (lim > NS ? NS : lim);
+        vmask = (1u << lim) - 1u;
+    }
+    const uint32_t tile_bad = sh.wave_bad[0] | sh.wave_bad[1] | sh.wave_bad[2] | sh.wave_bad[3];
+    if (tile_bad) vmask &= frl_good_mask<NS>(p, sh.flags, st.lane_base, p.unit + (W > 0 ? W : p.w) - 1);
+    st.vmask = vmask;
+}
+
+// Phase 3b: start / end decisions.  Returns starts | ends << 16.
+template <int MODE, int W, int NS>
+BL_DEV uint32_t phase_window_frl_b(const ScanParams& p, int tid, ThreadState& st, const ThreadState* all)
+{
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(BL_CPU_EMU)
+    (void)all;
+    (void)tid;
+    const uint32_t prev_last = dpp_prev32(st.a_last), prev_vm = dpp_prev32(st.vmask);
+    const uint32_t next_first = dpp_next32(st.a_first), next_vm = dpp_next32(st.vmask);
+#else
+    const int lane = tid & 63;
+    const uint32_t prev_last = lane > 0 ? all[tid - 1].a_last : 0xAAu, prev_vm = lane > 0 ? all[tid - 1].vmask : 0xAAAAu;
+    const uint32_t next_first = lane < 63 ? all[tid + 1].a_first : 0x55u, next_vm = lane < 63 ? all[tid + 1].vmask : 0x5555u;
+#endif
+    const int j = st.jlane;
+    const uint32_t apk[4] = {(uint32_t)st.apk0, (uint32_t)(st.apk0 >> 32), (uint32_t)st.apk1, (uint32_t)(st.apk1 >> 32)};
+    // differ bit s: the argmin of window s is another occurrence than that of window s - 1 (the previous lane's last
+    // window for s = 0: its element index moves by NS into this lane's frame; an index below NS there wraps to >= 112)
+    const uint32_t p0 = (prev_last - (uint32_t)NS) & 0x7fu;
+    uint32_t differ = 0;
+    BL_UNROLL
+    for (int q = 0; q < 4; ++q) {
+        const uint32_t prv = q ? funnel_shr(apk[q], apk[q - 1], 24) : ((apk[0] << 8) | p0);
+        const uint32_t x = apk[q] ^ prv;                             // bytes < 128
+        const uint32_t nz = ((x + 0x7f7f7f7fu) >> 7) & 0x01010101u;  // 1 in every non-zero byte
+        differ |= ((nz * 0x01020408u) >> 24) << (4 * q);             // byte b -> bit b
+    }
+    const uint32_t vm = st.vmask;
+    const uint32_t pv = (j > 0) ? ((prev_vm >> (NS - 1)) & 1u) : 0u;  // the window before this lane's first, same read
+    const uint32_t vprev = (vm << 1) | pv;
+    st.emit = vm & (~vprev | differ);  // window s starts an occurrence
+    st.endm = 0;
+    if (MODE == MODE_SUPERKMER) {
+        const uint32_t nv = (j >= 0 && j < p.lpr - 1) ? (next_vm & 1u) : 0u;  // the window after this lane's last, same read
+        const uint32_t dn = ((next_first + (uint32_t)NS) != st.a_last) ? 1u : 0u;
+        const uint32_t vnext = (vm >> 1) | (nv << (NS - 1));
+        const uint32_t dnext = (differ >> 1) | (dn << (NS - 1));
+        st.endm = vm & (~vnext | dnext);  // window s ends one
+    }
+    return (uint32_t)__builtin_popcount(st.emit) | ((uint32_t)__builtin_popcount(st.endm) << 16);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Phase 4: tile-local compaction.  List entries are FLAT positions relative to the tile's first staged chunk
+// (< 16 * NCHUNK), not (wave, wave-relative position) pairs: pass 2 tells the two apart by p.frl.
+template <int MODE, int W>
+BL_DEV void phase_list_frl(TileShared<MODE, W>& sh, const ThreadState& st, uint32_t excl_s, uint32_t excl_e)
+{
+    uint32_t m = st.emit;
+    uint32_t r = excl_s;
+    while (m) {
+        const int s = __builtin_ctz(m);
+        m &= m - 1;
+        const uint32_t arel = (uint32_t)((s < 8 ? st.apk0 : st.apk1) >> (8 * (s & 7))) & 0xffu;
+        sh.list_a[r] = (uint16_t)((uint32_t)st.lane_base + arel);
+        if (MODE == MODE_SUPERKMER) sh.list_j[r] = (uint16_t)(st.lane_base + s);
+        ++r;
+    }
+    if (MODE == MODE_SUPERKMER) {
+        m = st.endm;
+        r = excl_e;
+        while (m) {
+            const int s = __builtin_ctz(m);
+            m &= m - 1;
+            sh.list_e[r] = (uint16_t)(st.lane_base + s);
+            ++r;
+        }
+    }
+}
+
+}  // namespace bl

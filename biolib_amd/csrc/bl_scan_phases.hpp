@@ -41,9 +41,8 @@ struct TileShared {
     alignas(4) uint16_t list_j[MODE == MODE_SUPERKMER ? H : 2];  // compacted: first window of the occurrence
     alignas(4) uint16_t list_e[MODE == MODE_SUPERKMER ? H : 2];  // compacted: last window of the occurrence
     uint32_t wave_tot[NWAVE];
+    uint32_t wave_bad[NWAVE];       // read-tiled scans: wave wv staged at least one base that is not ACGTUacgtu
     unsigned long long dig[4];
-    uint32_t tile;
-    uint32_t base_s, base_e;        // global record offsets of this tile (from the look-back)
 };
 
 struct ThreadState {
@@ -53,6 +52,11 @@ struct ThreadState {
     uint32_t endm;    // bit s: an occurrence ends at window s (super-k-mer mode)
     uint32_t strand;  // syncmer: bit s set <=> reverse strand is canonical for the k-mer at s
     uint64_t apk0, apk1;  // minimizer modes: argmin (lane-relative element index) of window s+1 in byte s (8 per word)
+    // read-tiled scans (bl_scan_frl.hpp): byte s of apk = argmin of window s itself
+    int32_t lane_base;    // tile-relative base (from the tile's first staged chunk) of the lane's first unit
+    int32_t jlane;        // index of the lane inside its read, -1: the lane has no read
+    uint32_t a_first, a_last;  // argmin index of the lane's first / last window
+    uint32_t vmask;       // bit s: window s exists and is valid
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -141,6 +145,7 @@ BL_DEV int wave_chunk0(const ScanParams& p, int wv) { return wv * (p.stride / NW
 // contents; only lanes that own nothing look at them.
 BL_DEV int staged_chunks(const ScanParams& p)
 {
+    if (p.frl) return p.slot_chunks;  // read-tiled: every chunk of the tile's reads (bl_scan_frl.hpp)
     const int wchunks = p.stride / NWAVE / 16;
     int per_wave = (wchunks - 1) + (S + p.unit + p.w) / 16 + 1;
     per_wave = per_wave < 66 ? 66 : (per_wave > WCHUNK ? WCHUNK : per_wave);
@@ -685,18 +690,19 @@ template <int MODE, int W>
 BL_DEV Record emit_prepare(const ScanParams& p, const TileShared<MODE, W>& sh, int64_t q0, uint32_t r, Digest& dg)
 {
     Record rec{0, 0, 0, 0, 0};
+    // list entries: (wave << 12) | wave-relative position, or — read-tiled scans — a flat tile-relative position
     const uint32_t ent = sh.list_a[r];
-    const int wv = ent >> 12, ap = ent & 0xfff;
-    const int64_t wq0 = wave_origin(p, q0, wv);
+    const int wv = p.frl ? 0 : ent >> 12, ap = p.frl ? ent : ent & 0xfff;
+    const int64_t wq0 = p.frl ? q0 : wave_origin(p, q0, wv);
     rec.pos = (uint64_t)(wq0 + ap);
     dg.xp ^= rec.pos;
     if (MODE != MODE_SYNCMER) {
-        rec.v = extract_unit(sh.codes + wave_chunk0(p, wv), ap, p.unit, p.canonical);
+        rec.v = extract_unit(p.frl ? sh.codes : sh.codes + wave_chunk0(p, wv), ap, p.unit, p.canonical);
         rec.h = murmur64(rec.v, p.seed);
         dg.xv ^= rec.v;
         dg.xh ^= rec.h;
         if (MODE == MODE_SUPERKMER) {
-            const int j = sh.list_j[r] & 0xfff;
+            const int j = p.frl ? sh.list_j[r] : sh.list_j[r] & 0xfff;
             rec.first = (uint64_t)(wq0 + j);
             rec.mmpos = (uint32_t)(ap - j);  // super_kmer_view.hpp:132
         }
@@ -741,7 +747,8 @@ BL_DEV void emit_ends(const ScanParams& p, const TileShared<MODE, W>& sh, int ti
         for (uint32_t r = tid; r < n_e; r += TPB) {
             const uint64_t g = base_e + r;
             const uint32_t ent = sh.list_e[r];
-            if (p.out_last && g < p.capacity) p.out_last[g] = (uint64_t)(wave_origin(p, q0, ent >> 12) + (ent & 0xfff));
+            const int64_t pos = p.frl ? q0 + ent : wave_origin(p, q0, ent >> 12) + (ent & 0xfff);
+            if (p.out_last && g < p.capacity) p.out_last[g] = (uint64_t)pos;
         }
     }
 }

@@ -12,7 +12,7 @@
 #include <cstring>
 #include <vector>
 
-#include "../../biolib_amd/csrc/bl_scan_phases.hpp"
+#include "../../biolib_amd/csrc/bl_scan_frl.hpp"
 
 using namespace bl;
 
@@ -41,7 +41,7 @@ void run_tiles(ScanParams p, unsigned long long* result)
     const size_t nt = (size_t)p.n_tiles;
     std::vector<unsigned long long> counts(nt), base(nt);
     std::vector<uint16_t> sa(nt * p.stride), sj(MODE == MODE_SUPERKMER ? nt * p.stride : 1), se(MODE == MODE_SUPERKMER ? nt * p.stride : 1);
-    std::vector<uint32_t> sc(nt * NCHUNK);
+    std::vector<uint32_t> sc(nt * p.slot_chunks);
     {
         auto* sh = new TileShared<MODE, W>();
         std::vector<ThreadState> st(TPB);
@@ -52,7 +52,7 @@ void run_tiles(ScanParams p, unsigned long long* result)
             std::memset(st.data(), 0x5A, st.size() * sizeof(ThreadState));
             const int64_t q0 = p.origin + (int64_t)tile * p.stride;
             for (int tid = 0; tid < TPB; ++tid) phase_load<MODE, W>(p, *sh, tid, q0);
-            for (int c = 0; c < staged_chunks(p); ++c) sc[tile * NCHUNK + c] = sh->codes[c];  // codes spill
+            for (int c = 0; c < staged_chunks(p); ++c) sc[tile * p.slot_chunks + c] = sh->codes[c];  // codes spill
             for (int tid = 0; tid < TPB; ++tid) phase_hash<MODE, W>(p, *sh, tid, st[tid]);
             if (MODE == MODE_SYNCMER) {
                 for (int tid = 0; tid < TPB; ++tid) phase_sync_fwd<MODE, W>(p, *sh, tid, st[tid], st.data(), &af[tid * (S + 1)]);
@@ -91,7 +91,7 @@ void run_tiles(ScanParams p, unsigned long long* result)
             if (n_s == 0 && n_e == 0) continue;
             std::memset(sh, 0xA5, sizeof(*sh));
             const int64_t q0 = p.origin + (int64_t)tile * p.stride;
-            for (int c = 0; c < staged_chunks(p); ++c) sh->codes[c] = sc[tile * NCHUNK + c];  // pass 2 reloads the codes
+            for (int c = 0; c < staged_chunks(p); ++c) sh->codes[c] = sc[tile * p.slot_chunks + c];  // pass 2 reloads the codes
             for (uint32_t r = 0; r < n_s; ++r) {
                 sh->list_a[r] = sa[tile * p.stride + r];
                 if (MODE == MODE_SUPERKMER) sh->list_j[r] = sj[tile * p.stride + r];
@@ -110,9 +110,97 @@ void run_tiles(ScanParams p, unsigned long long* result)
     result[4] = run >> 32;
 }
 
+// the read-tiled pass 1 (scan_count_frl_kernel), then the common prefix scan and pass 2
+template <int MODE, int W, int NS>
+void run_tiles_frl(ScanParams p, unsigned long long* result)
+{
+    const size_t nt = (size_t)p.n_tiles;
+    std::vector<unsigned long long> counts(nt), base(nt);
+    std::vector<uint16_t> sa(nt * p.stride), sj(MODE == MODE_SUPERKMER ? nt * p.stride : 1), se(MODE == MODE_SUPERKMER ? nt * p.stride : 1);
+    std::vector<uint32_t> sc(nt * p.slot_chunks);
+    {
+        auto* sh = new TileShared<MODE, W>();
+        std::vector<ThreadState> st(TPB);
+        std::vector<uint32_t> packed(TPB), excl(TPB);
+        for (size_t tile = 0; tile < nt; ++tile) {
+            std::memset(sh, 0xA5, sizeof(*sh));
+            std::memset(st.data(), 0x5A, st.size() * sizeof(ThreadState));
+            const int64_t q0 = tile_q0(p, (uint32_t)tile);
+            for (int tid = 0; tid < TPB; ++tid) phase_load_frl<MODE, W>(p, *sh, tid, q0);
+            for (int c = 0; c < p.slot_chunks; ++c) sc[tile * p.slot_chunks + c] = sh->codes[c];
+            for (int tid = 0; tid < TPB; ++tid) phase_hash_frl<MODE, W, NS>(p, *sh, tid, q0, (uint32_t)tile, st[tid]);
+            for (int tid = 0; tid < TPB; ++tid) phase_window_frl_a<MODE, W, NS>(p, *sh, tid, st[tid], st.data());
+            for (int tid = 0; tid < TPB; ++tid) packed[tid] = phase_window_frl_b<MODE, W, NS>(p, tid, st[tid], st.data());
+            uint32_t run = 0;
+            for (int tid = 0; tid < TPB; ++tid) {
+                excl[tid] = run;
+                run += packed[tid];
+            }
+            const uint32_t n_s = run & 0xffffu, n_e = run >> 16;
+            for (int tid = 0; tid < TPB; ++tid) phase_list_frl<MODE, W>(*sh, st[tid], excl[tid] & 0xffffu, excl[tid] >> 16);
+            counts[tile] = (unsigned long long)n_s | ((unsigned long long)n_e << 32);
+            for (uint32_t r = 0; r < n_s; ++r) {
+                sa[tile * p.stride + r] = sh->list_a[r];
+                if (MODE == MODE_SUPERKMER) sj[tile * p.stride + r] = sh->list_j[r];
+            }
+            if (MODE == MODE_SUPERKMER)
+                for (uint32_t r = 0; r < n_e; ++r) se[tile * p.stride + r] = sh->list_e[r];
+        }
+        delete sh;
+    }
+    unsigned long long run = 0;
+    for (size_t tile = 0; tile < nt; ++tile) {
+        base[tile] = run;
+        run += counts[tile];
+    }
+    Digest dg{0, 0, 0};
+    {
+        auto* sh = new TileShared<MODE, 1>();
+        for (size_t tile = 0; tile < nt; ++tile) {
+            const uint32_t n_s = (uint32_t)counts[tile], n_e = (uint32_t)(counts[tile] >> 32);
+            if (n_s == 0 && n_e == 0) continue;
+            std::memset(sh, 0xA5, sizeof(*sh));
+            const int64_t q0 = tile_q0(p, (uint32_t)tile);
+            for (int c = 0; c < p.slot_chunks; ++c) sh->codes[c] = sc[tile * p.slot_chunks + c];
+            for (uint32_t r = 0; r < n_s; ++r) {
+                sh->list_a[r] = sa[tile * p.stride + r];
+                if (MODE == MODE_SUPERKMER) sh->list_j[r] = sj[tile * p.stride + r];
+            }
+            if (MODE == MODE_SUPERKMER)
+                for (uint32_t r = 0; r < n_e; ++r) sh->list_e[r] = se[tile * p.stride + r];
+            for (int tid = 0; tid < TPB; ++tid)
+                phase_emit<MODE, 1>(p, *sh, tid, q0, n_s, n_e, base[tile] & 0xffffffffull, base[tile] >> 32, dg);
+        }
+        delete sh;
+    }
+    result[0] = run & 0xffffffffull;
+    result[1] = dg.xv;
+    result[2] = dg.xh;
+    result[3] = dg.xp;
+    result[4] = run >> 32;
+}
+
+// the instantiations launch_count_frl (bl_kernels.hip) makes
+template <int MODE>
+void run_mode_frl(const ScanParams& p, unsigned long long* result)
+{
+    if (MODE == MODE_MINIMIZER && p.ns == 15) { run_tiles_frl<MODE_MINIMIZER, 11, 15>(p, result); return; }
+    if (MODE == MODE_MINIMIZER) {
+        switch (p.w) {
+            case 5: run_tiles_frl<MODE_MINIMIZER, 5, S>(p, result); return;
+            case 10: run_tiles_frl<MODE_MINIMIZER, 10, S>(p, result); return;
+            case 11: run_tiles_frl<MODE_MINIMIZER, 11, S>(p, result); return;
+            case 19: run_tiles_frl<MODE_MINIMIZER, 19, S>(p, result); return;
+        }
+    }
+    if (MODE == MODE_SUPERKMER && p.w == 17) { run_tiles_frl<MODE_SUPERKMER, 17, S>(p, result); return; }
+    std::abort();
+}
+
 template <int MODE>
 void run_mode(const ScanParams& p, unsigned long long* result)
 {
+    if (p.frl) { run_mode_frl<MODE == MODE_SYNCMER ? MODE_MINIMIZER : MODE>(p, result); return; }
     switch (p.w) {
         case 1: run_tiles<MODE, 1>(p, result); break;
         case 5: if (MODE != MODE_SYNCMER) { run_tiles<MODE, 5>(p, result); break; } run_tiles<MODE, -8>(p, result); break;
@@ -129,8 +217,10 @@ void run_mode(const ScanParams& p, unsigned long long* result)
     }
 }
 
+int g_frl_scans = 0;  // how many scans took the read-tiled path (the selftest checks that it is exercised at all)
+
 void fill_common(ScanParams& p, const uint8_t* bases, uint64_t n_bases, const uint32_t* bits, int mode, uint64_t first, uint64_t n,
-                 unsigned unit, unsigned w, uint64_t seed, unsigned flags)
+                 unsigned unit, unsigned w, uint64_t seed, unsigned flags, uint64_t read_len = 0)
 {
     uint64_t end = n == 0 ? n_bases : first + n;
     if (end > n_bases) end = n_bases;
@@ -138,6 +228,10 @@ void fill_common(ScanParams& p, const uint8_t* bases, uint64_t n_bases, const ui
     p.n_bases = (int64_t)n_bases;
     p.start_bits = bits;
     plan_scan(mode, (int64_t)first, (int64_t)end, (int)w, p);
+    if (read_len && !p.use_threshold && frl_width_built(mode, (int)w)) {  // the decision of bl_capi.hip: scan_windows
+        const bool tuned = mode == MODE_MINIMIZER && w == 11 && unit == 31 && (flags & 1) && read_len == 150;
+        if (plan_scan_frl((int64_t)first, (int64_t)end, (int64_t)n_bases, (int64_t)read_len, (int)unit, (int)w, tuned ? 0 : S, p)) ++g_frl_scans;
+    }
     p.unit = (int)unit;
     p.w = (int)w;
     p.seed = (uint32_t)seed;
@@ -157,6 +251,7 @@ struct EmuBatch {
     uint64_t n_bases;
     std::vector<uint32_t> bits;
     bool single;
+    uint64_t read_len;  // != 0: fixed-length reads (the read-tiled layout may apply)
 };
 
 EmuBatch* emu_batch(const uint8_t* bases, uint64_t n_bases, const uint64_t* offsets, uint64_t n_seqs, uint64_t read_len)
@@ -168,6 +263,7 @@ EmuBatch* emu_batch(const uint8_t* bases, uint64_t n_bases, const uint64_t* offs
     if (n_bases) std::memcpy(b->bases, bases, n_bases);
     b->n_bases = n_bases;
     b->single = !offsets && (read_len == 0 || read_len >= n_bases);
+    b->read_len = (!offsets && !b->single) ? read_len : 0;
     if (!b->single) b->bits = make_start_bits(n_bases, offsets, n_seqs, read_len);
     return b;
 }
@@ -182,7 +278,7 @@ void emu_minimizers(const EmuBatch* b, uint64_t first, uint64_t n, unsigned unit
                     uint64_t* out_value, uint64_t* out_pos, uint64_t* out_hash, uint64_t capacity, unsigned long long* result)
 {
     ScanParams p{};
-    fill_common(p, b->bases, b->n_bases, b->single ? nullptr : b->bits.data(), MODE_MINIMIZER, first, n, unit, w, seed, flags);
+    fill_common(p, b->bases, b->n_bases, b->single ? nullptr : b->bits.data(), MODE_MINIMIZER, first, n, unit, w, seed, flags, b->read_len);
     p.out_value = out_value;
     p.out_pos = out_pos;
     p.out_hash = out_hash;
@@ -190,6 +286,8 @@ void emu_minimizers(const EmuBatch* b, uint64_t first, uint64_t n, unsigned unit
     std::memset(result, 0, 8 * sizeof(unsigned long long));
     run_mode<MODE_MINIMIZER>(p, result);
 }
+
+int emu_frl_scans() { return g_frl_scans; }
 
 void emu_hash_sample(const EmuBatch* b, uint64_t first, uint64_t n, unsigned k, uint64_t seed, uint64_t threshold, unsigned flags,
                      uint64_t* out_value, uint64_t* out_pos, uint64_t* out_hash, uint64_t capacity, unsigned long long* result)
@@ -211,7 +309,7 @@ void emu_super_kmers(const EmuBatch* b, uint64_t first, uint64_t n, unsigned k, 
                      unsigned long long* result)
 {
     ScanParams p{};
-    fill_common(p, b->bases, b->n_bases, b->single ? nullptr : b->bits.data(), MODE_SUPERKMER, first, n, m, k - m + 1, seed, flags);
+    fill_common(p, b->bases, b->n_bases, b->single ? nullptr : b->bits.data(), MODE_SUPERKMER, first, n, m, k - m + 1, seed, flags, b->read_len);
     std::vector<uint64_t> last(capacity ? capacity : 1);
     p.out_value = out_min;
     p.out_first = out_first;
@@ -263,10 +361,10 @@ void emu_kmers(const EmuBatch* b, uint64_t first, uint64_t n, unsigned k, uint64
     lp.n_bases = p.n_bases;
     lp.start_bits = p.start_bits;
     KmerAcc acc{0, 0, 0, 0};
-    std::vector<uint32_t> codes(NCHUNK), flg(NCHUNK);
+    std::vector<uint32_t> codes(NCHUNK_POS), flg(NCHUNK_POS);
     for (int tile = 0; tile < p.n_tiles; ++tile) {
         const int64_t q0 = p.origin + (int64_t)tile * H;
-        for (int c = 0; c < NCHUNK; ++c) stage_chunk(lp, codes.data(), flg.data(), c, q0);
+        for (int c = 0; c < NCHUNK_POS; ++c) stage_chunk(lp, codes.data(), flg.data(), c, q0);
         for (int tid = 0; tid < TPB; ++tid) kmer_thread(p, codes.data(), flg.data(), tid, q0, acc);
     }
     result[0] = acc.cnt;

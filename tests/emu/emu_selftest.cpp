@@ -28,6 +28,7 @@ void emu_kmers(const EmuBatch* b, uint64_t first, uint64_t n, unsigned k, uint64
 void emu_hash_sample(const EmuBatch* b, uint64_t first, uint64_t n, unsigned k, uint64_t seed, uint64_t threshold, unsigned flags,
                      uint64_t* out_value, uint64_t* out_pos, uint64_t* out_hash, uint64_t capacity, unsigned long long* result);
 uint64_t emu_hash64(uint64_t v, uint64_t seed);
+int emu_frl_scans();
 }
 
 static int g_fail = 0;
@@ -233,6 +234,57 @@ int main(int argc, char** argv)
             }
         }
     }
+    // batches of whole fixed-length reads: the read-tiled layout (bl_scan_frl.hpp) — clean, with breaks, tie-heavy,
+    // read counts that fill tiles exactly / leave partial waves, sub-ranges cut at read boundaries (check_case cuts anywhere:
+    // cuts inside a read take the position-tiled path, which must agree)
+    for (int round = 0; round < rounds; ++round) {
+        const uint64_t lens[] = {150, 150, 100, 250, 64, 76, 41, 151, 33, 300, 1000};
+        for (uint64_t L : lens) {
+            const uint64_t read_counts[] = {1, 7, 8, 31, 32, 33, 64, 65, 200};
+            for (uint64_t nr : read_counts) {
+                for (int flavour = 0; flavour < 3; ++flavour) {
+                    if (L * nr > 40000) continue;
+                    Case c;
+                    const uint64_t n = L * nr;
+                    c.seq.resize(n);
+                    c.single = false;
+                    if (flavour == 2) {
+                        const char* motifs[] = {"A", "AC", "ACG", "AAAT", "ACGTT", "GATTACA"};
+                        const std::string mo = motifs[rng() % 6];
+                        for (uint64_t i = 0; i < n; ++i) c.seq[i] = (uint8_t)mo[i % mo.size()];
+                        for (uint64_t i = 0; i + 1 < n; i += 97 + rng() % 300) c.seq[i] = "ACGT"[rng() % 4];
+                    } else {
+                        blo_synth(777 * round + n + flavour, 0, n, reinterpret_cast<char*>(c.seq.data()));
+                    }
+                    if (flavour == 1)
+                        for (uint64_t q = 0, nb = 1 + n / 400; q < nb; ++q) c.seq[rng() % n] = (uint8_t)alphabet_breaks[rng() % (sizeof(alphabet_breaks) - 1)];
+                    c.offsets = fixed_offsets(n, L);
+                    c.read_len = L;
+                    if (nr == 1) { c.single = true; c.read_len = 0; c.offsets = {0, n}; }
+                    c.name = "frl" + std::to_string(L) + "x" + std::to_string(nr) + "/f" + std::to_string(flavour) + "/r" + std::to_string(round);
+                    check_case(c, rng);
+                    // cuts at read boundaries keep both halves read-tiled
+                    if (nr >= 2) {
+                        EmuBatch* b = emu_batch(c.seq.data(), n, nullptr, 0, L);
+                        const uint64_t cut = L * (1 + rng() % (nr - 1)), cap = n + 2;
+                        std::vector<uint64_t> ov(cap), op(cap), oh(cap), ev(cap), ep(cap), eh(cap);
+                        unsigned long long r1[8], r2[8];
+                        const size_t cnt = blo_minimizers(reinterpret_cast<const char*>(c.seq.data()), c.offsets.data(), c.offsets.size() - 1, 31, 11, 42, 1, 1,
+                                                          ov.data(), op.data(), oh.data(), cap);
+                        emu_minimizers(b, 0, cut, 31, 11, 42, 1, ev.data(), ep.data(), eh.data(), cap, r1);
+                        emu_minimizers(b, cut, 0, 31, 11, 42, 1, ev.data() + r1[0], ep.data() + r1[0], eh.data() + r1[0], cap - r1[0], r2);
+                        CHECK(r1[0] + r2[0] == cnt, "%s read-aligned split at %llu: %llu + %llu vs %zu", c.name.c_str(), (unsigned long long)cut, r1[0], r2[0], cnt);
+                        if (r1[0] + r2[0] == cnt)
+                            for (size_t i = 0; i < cnt; ++i)
+                                CHECK(ev[i] == ov[i] && ep[i] == op[i] && eh[i] == oh[i], "%s read-aligned split record %zu", c.name.c_str(), i);
+                        emu_batch_free(b);
+                    }
+                }
+            }
+        }
+    }
+    CHECK(emu_frl_scans() > 100, "the read-tiled path was hardly exercised: %d scans", emu_frl_scans());
+    std::printf("read-tiled scans run: %d\n", emu_frl_scans());
     if (g_fail) {
         std::printf("emu_selftest: %d mismatches\n", g_fail);
         return 1;
