@@ -10,10 +10,15 @@ materialised into HBM output arrays.  Shards are independent (weak scaling, no d
 the only collective is the optional count reduction, done after the timed region over RCCL.
 
 Prints ONE JSON line on rank 0, including
-  roofline     achieved HBM-read GB/s of the scan kernel (1 byte/base x bases per launch / mean
-               kernel time from HIP events on the launch stream) against the 8 TB/s peak
-  cpu_baseline the CPU oracle (port of the reference algorithm) timed on this box's host cores on a
-               bounded sample of the same reads, plus a bit-exact check of the GPU result on it
+  roofline       achieved HBM-read GB/s of the dominant kernel (1 byte/base x bases per launch / mean kernel time from
+                 HIP events on the launch stream) against the 8 TB/s peak; `valu` = the second ceiling: the instructions
+                 the kernels execute (ISA census x PMC count) priced at the issue cycles tools/ubench_valu.hip measured,
+                 over the SIMD cycles available at the shader clock measured DURING the timed region
+  other_configs  (1 GPU) one pass each over the other BASELINE.json configurations at their stated sizes:
+                 C2 canonical 31-mer + hash64 over 10 Gbp, C4 super-k-mers k=31 m=15 over 50 Gbp of 10-kbp reads,
+                 C5 syncmers k=31 s=11 over 50 Gbp of 10-kbp reads — Gbp/s, kernel ms, roofline fraction
+  cpu_baseline   the CPU oracle (port of the reference algorithm) timed on this box's host cores on a bounded sample
+                 of the same reads, a bit-exact check of the GPU result on it, and the reference itself on C2's path
 """
 import argparse
 import json
@@ -25,9 +30,35 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 UNIT, W, SEED, READ_LEN = 31, 11, 42, 150
-N_CU = 256
-CLOCK_HZ = 2.4e9
+N_SIMD = 256 * 4
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+MODEL_PATH = os.path.join(ROOT, "profiles", "valu_model.json")   # tools/valu_model.py
+TRAFFIC_PATH = os.path.join(ROOT, "profiles", "traffic.json")    # tools/summarise_profiles.py
+
+
+def load_json_or_none(path):
+    """A missing profile file is reported as such in the JSON line; a broken one is an error, not a silent null."""
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        return json.load(f)
+
+
+def valu_ceiling(model, kernels, bases, seconds, ghz):
+    """Second ceiling: SIMD cycles the named kernels need per `bases` at the measured issue cost of their
+    instructions, over the SIMD cycles `seconds` hold at the measured shader clock.  <= 1 by construction: the issue
+    costs are the best sustained rates of tools/ubench_valu.hip (8 waves per SIMD, nothing else running)."""
+    if model is None:
+        return {"error": "profiles/valu_model.json missing: run tools/collect_profiles.sh on the GPU box and tools/valu_model.py"}
+    need, parts = 0.0, {}
+    for k in kernels:
+        km = model["kernels"][k]
+        need += km["cycles_per_base"] * bases
+        parts[k] = {"valu_lane_instr_per_base": round(km["valu_per_base"] * 64, 1), "simd_cycles_per_base": round(km["cycles_per_base"], 4),
+                    "avg_issue_cycles": round(km["cycles_per_base"] / km["valu_per_base"], 3)}
+    avail = N_SIMD * ghz * 1e9 * seconds
+    return {"frac": round(need / avail, 4), "simd_cycles_needed": int(need), "simd_cycles_available": int(avail), "shader_clock_GHz": round(ghz, 3),
+            "kernels": parts, "issue_cycles": model["issue_cycles"], "source": model["provenance"]}
 
 
 def main():
@@ -40,6 +71,8 @@ def main():
     ap.add_argument("--lanes", type=int, default=2, choices=(1, 2),
                     help="execution lanes of the context: 2 = the record pass of one range runs beside the hashing pass of the next")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true")
+    ap.add_argument("--other-gbp", type=float, default=0.0, help="size of the other configs (0 = as BASELINE.json states them: 10 / 50 / 50 Gbp)")
     args = ap.parse_args()
 
     import numpy as np
@@ -96,15 +129,21 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    step_est = None
+    for _ in range(max(args.warmup, 0)):
         res = []
+        tw = time.perf_counter()
         one_step(res)
         ctx.sync()
+        step_est = time.perf_counter() - tw
         for r in res:
             assert r.status == 0, f"scan failed with status {r.status} (count {r.count}, capacity {cap})"
 
     ctx.kernel_timing(True)
     barrier()
+    # shader clock over (most of) the timed region: one sleeping wave on its own stream, started with the region
+    probe_ms = int(min(4000, max(20, 0.8 * args.steps * (step_est if step_est else 0.12) * 1e3)))
+    probe = ctx.clock_probe_start(probe_ms)
     t0 = time.perf_counter()
     all_res = []
     for _ in range(args.steps):
@@ -112,6 +151,7 @@ def main():
     ctx.sync()
     barrier()
     elapsed = time.perf_counter() - t0
+    clock_ghz = ctx.clock_probe_finish(probe)
     kernel_ms, launches = ctx.kernel_time()
     ctx.kernel_timing(False)
     for r in all_res:
@@ -149,39 +189,21 @@ def main():
 
     out = None
     if rank == 0:
+        model = load_json_or_none(MODEL_PATH)
+        prof = load_json_or_none(TRAFFIC_PATH)
         total_bases = float(n_bases) * n_gpus * args.steps
         value = total_bases / t_max / 1e9
         bases_per_launch = sum(n for _, n in ranges) / len(ranges)
         avg_kernel_s = kernel_ms / 1e3 / max(launches, 1)
         achieved = bases_per_launch * 1.0 / avg_kernel_s / 1e9  # 1 algorithmic byte per base
-        traffic = None
-        valu = None
-        hbm_actual = None
-        tp = os.path.join(ROOT, "profiles", "traffic.json")  # written from a separate rocprofv3 --pmc run, see DESIGN.md
-        if os.path.exists(tp):
-            try:
-                prof = json.load(open(tp))
-                traffic = int(prof["hbm_bytes_per_base"] * bases_per_launch)  # PMC bytes per base x this run's bases per launch
-                # what actually moves through HBM per range (both passes, PMC) over the time a range takes in this run
-                emit_bytes = prof.get("emit_kernel", {}).get("hbm_bytes_per_launch_measured", 0) / prof["measured_bases_per_launch"] * bases_per_launch
-                range_s = t_max / args.steps / len(ranges)
-                hbm_actual = {"bytes_per_range_both_passes": int(traffic + emit_bytes), "GBps": round((traffic + emit_bytes) / range_s / 1e9, 1),
-                              "frac_of_8TBps": round((traffic + emit_bytes) / range_s / 1e9 / HBM_PEAK_GBPS, 4)}
-                # second ceiling: VALU issue.  A wave64 instruction occupies a SIMD16 for 4 cycles, so the
-                # nominal peak is CUs x 4 SIMDs x clock / 4 wave-instructions per second (some simple ops retire faster,
-                # which is how the fraction can pass 1).
-                per_base = prof["valu_wave_instr_per_base"]
-                if args.lanes == 2:  # the record pass of the previous range shares the SIMDs with this kernel: count its instructions too
-                    per_base += prof.get("emit_valu_wave_instr_per_base", 0.0)
-                winstr = per_base * bases_per_launch
-                peak_winstr = N_CU * 4 * CLOCK_HZ / 4.0
-                valu = {"wave_instr_per_launch": int(winstr), "achieved_Ginstr_s": round(winstr / avg_kernel_s / 1e9, 1),
-                        "peak_Ginstr_s": round(peak_winstr / 1e9, 1), "frac": round(winstr / avg_kernel_s / peak_winstr, 3),
-                        "lane_instr_per_base": round(per_base * 64, 1),
-                        "kernels": "scan_count + co-running scan_emit" if args.lanes == 2 else "scan_count",
-                        "source": "SQ_INSTS_VALU, profiles/r01_pmc_summary.txt; 256 CUs x 4 SIMD16 at 2.4 GHz"}
-            except Exception:
-                traffic = None
+        range_s = t_max / args.steps / len(ranges)
+        traffic, hbm_actual, traffic_note = None, None, "profiles/traffic.json missing: no PMC traffic figure"
+        if prof is not None:
+            c3 = prof["c3"]
+            traffic = int(c3["count_kernel"]["hbm_bytes_per_base"] * bases_per_launch)  # PMC bytes per base x this run's bases per launch
+            both = (c3["count_kernel"]["hbm_bytes_per_base"] + c3["emit_kernel"]["hbm_bytes_per_base"]) * bases_per_launch
+            hbm_actual = {"bytes_per_range_both_passes": int(both), "GBps": round(both / range_s / 1e9, 1), "frac_of_8TBps": round(both / range_s / 1e9 / HBM_PEAK_GBPS, 4)}
+            traffic_note = prof["provenance"]
         out = {
             "metric": "Gbp/s minimizer-scanned (k=31,w=11)",
             "value": round(value, 3),
@@ -205,17 +227,18 @@ def main():
             "xor_hash": xor_hash,
             "roofline": {
                 "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5),
-                "traffic": traffic, "kernel": "bl::scan_count_kernel<MODE_MINIMIZER,W=11,U=31,C=1> (pass 1 of 2)", "avg_kernel_ms": round(avg_kernel_s * 1e3, 4),
+                "traffic": traffic, "traffic_source": traffic_note,
+                "kernel": "bl::scan_count_frl_kernel<MODE_MINIMIZER,W=11,NS=15,U=31,L=150,C=1> (pass 1 of 2, read-tiled)", "avg_kernel_ms": round(avg_kernel_s * 1e3, 4),
                 "launches_timed": launches, "algorithmic_bytes_per_launch": int(bases_per_launch),
-                "note": "integer-ALU bound before HBM: 6 x 64-bit multiplies per base (MurmurHash3_x64_128), see DESIGN.md"
-                        + ("; with 2 lanes this kernel's duration includes sharing the SIMDs with the previous range's scan_emit_kernel "
-                           "(alone: --lanes 1, profiles/r01_bench_1gpu_lanes1.json)" if args.lanes == 2 else ""),
+                "note": "VALU-issue bound before HBM: 6 x 64-bit multiplies per 31-mer (MurmurHash3_x64_128), see roofline.valu and DESIGN.md"
+                        + ("; with 2 lanes this kernel's duration includes sharing the SIMDs with the previous range's scan_emit_kernel (alone: --lanes 1)"
+                           if args.lanes == 2 else ""),
             },
         }
         if rehearse:
             out["rehearsal"] = "all ranks on cuda:0 over gloo: flow check only, NOT a measurement"
-        if valu is not None:
-            out["roofline"]["valu"] = valu
+        # VALU ceiling over the whole timed region: both passes' instructions against the SIMD cycles a range's share of it holds
+        out["roofline"]["valu"] = valu_ceiling(model, ["c3_count", "c3_emit"], bases_per_launch, range_s, clock_ghz)
         if hbm_actual is not None:
             out["roofline"]["hbm_actual"] = hbm_actual
         if n_gpus == 1:
@@ -229,11 +252,97 @@ def main():
             out["count_allreduce_ms"] = round(allreduce_ms, 3)
         if n_gpus == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(np, ctx, batch, n_bases)
+    if n_gpus == 1 and not args.no_other_configs:
+        batch.close()
+        del outs
+        torch.cuda.empty_cache()
+        out["other_configs"] = other_configs(ctx, args, load_json_or_none(MODEL_PATH))
+    if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     return out
+
+
+def other_configs(ctx, args, model):
+    """One pass each (after an untimed one) over the other BASELINE.json configurations on this GPU, at the sizes they are
+    stated at: parity-test cases with a driver-timed rate.  Same protocol as the headline: inputs resident, ranges of
+    <= 1.5 Gbp, records materialised where the configuration has records, HIP-event time of the dominant kernel."""
+    import biolib_amd as B
+
+    CH = 1_500_000_000
+    res = {}
+
+    def timed(issue, n_bases, kernels, kernel_name, steps=2):
+        issue()
+        ctx.sync()
+        ctx.kernel_timing(True)
+        probe = ctx.clock_probe_start(max(20, int(0.8 * steps * n_bases / 250e9 * 1e3)))
+        t0 = time.perf_counter()
+        n_ranges = 0
+        for _ in range(steps):
+            n_ranges += issue()
+        ctx.sync()
+        dt = time.perf_counter() - t0
+        ghz = ctx.clock_probe_finish(probe)
+        kms, launches = ctx.kernel_time()
+        ctx.kernel_timing(False)
+        per_launch = n_bases * steps / max(launches, 1)
+        k_s = kms / 1e3 / max(launches, 1)
+        achieved = per_launch / k_s / 1e9
+        return {"value": round(n_bases * steps / dt / 1e9, 2), "unit": "Gbp/s", "bases": n_bases, "steps": steps, "ms_per_step": round(dt / steps * 1e3, 3),
+                "kernel": kernel_name, "avg_kernel_ms": round(k_s * 1e3, 4), "launches_timed": launches,
+                "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5),
+                             "valu": valu_ceiling(model, kernels, per_launch, dt / max(n_ranges, 1), ghz)}}
+
+    # C2: canonical 31-mer 2-bit encode + hash64 digest over 10 Gbp, one sequence (digest only: 80 GB of hashes are not materialised)
+    n = int((args.other_gbp or 10.0) * 1e9)
+    b = ctx.synth(SEED, n)
+
+    def c2():
+        k = 0
+        for a in range(0, n, CH):
+            b.kmers_raw(31, 0, B.FLAG_CANONICAL, first=a, n=min(CH, n - a))
+            k += 1
+        return k
+
+    res["C2_kmer_hash_10Gbp"] = timed(c2, n, ["c2_kmer"], "bl::kmer_kernel")
+    b.close()
+
+    # C4 / C5: 50 Gbp of 10-kbp reads
+    L = 10_000
+    n = int((args.other_gbp or 50.0) * 1e9) // L * L
+    b = ctx.synth(SEED, n, L)
+    chunk = CH // L * L
+    cap4 = int(chunk * 2.3 / 18) + 65536
+    bufs = [(ctx.empty_u64(cap4), ctx.empty_u64(cap4), ctx.empty_u8(cap4), ctx.empty_u8(cap4), ctx.empty_u64(cap4)) for _ in range(2)]
+
+    def c4():
+        k = 0
+        for i, a in enumerate(range(0, n, chunk)):
+            mn, fp, mp, sz, hs = bufs[i & 1]
+            b.super_kmers_raw(31, 15, SEED, B.FLAG_CANONICAL, first=a, n=min(chunk, n - a), minimizers=mn, first_pos=fp, mm_pos=mp, sizes=sz, hashes=hs, capacity=cap4)
+            k += 1
+        return k
+
+    res["C4_super_kmers_50Gbp_10kbp_reads"] = timed(c4, n, ["c4_count", "c4_emit"], "bl::scan_count_kernel<MODE_SUPERKMER,W=17,U=15,C=1>")
+    del bufs
+    cap5 = int(chunk * 2.6 / 21) + 65536
+    pbuf = [ctx.empty_u64(cap5) for _ in range(2)]
+
+    def c5():
+        k = 0
+        for i, a in enumerate(range(0, n, chunk)):
+            b.syncmers_raw(31, 11, 0, 20, 0, B.FLAG_CANONICAL, first=a, n=min(chunk, n - a), positions=pbuf[i & 1], capacity=cap5)
+            k += 1
+        return k
+
+    res["C5_syncmers_50Gbp_shard_10kbp_reads"] = timed(c5, n, ["c5_count", "c5_emit"], "bl::scan_count_kernel<MODE_SYNCMER,W=21,U=11,C=1>")
+    b.close()
+    res["note"] = ("parity of these configurations at these sizes: tests/test_gpu_edges.py (two cuttings agree, 256 Mbp against the oracle); "
+                   "C5's 8-GPU RCCL leg needs hardware a 1-GPU box does not have (world-1 nccl reduce is tested)")
+    return res
 
 
 def usable_cores():
@@ -256,12 +365,12 @@ def cpu_baseline(np, ctx, batch, n_bases):
     import oracle_lib as O
 
     cores = usable_cores()
-    n1 = min(n_bases, 2_000_000 * READ_LEN)       # 300 Mbp single-thread (~8 s)
+    n1 = min(n_bases, 2_000_000 * READ_LEN)       # 300 Mbp single-thread (~4 s)
     nall = min(n_bases, 20_000_000 * READ_LEN)    # 3 Gbp on all cores
     seq = batch.download(0, nall)
     offs = np.arange(0, nall + 1, READ_LEN, dtype=np.uint64)
     t = time.perf_counter()
-    d1 = O.minimizer_digest(seq[:n1], offs[: n1 // READ_LEN + 1], UNIT, W, SEED, True, threads=1)
+    O.minimizer_digest(seq[:n1], offs[: n1 // READ_LEN + 1], UNIT, W, SEED, True, threads=1)
     t1 = time.perf_counter() - t
     t = time.perf_counter()
     dall = O.minimizer_digest(seq, offs, UNIT, W, SEED, True, threads=cores)
@@ -274,7 +383,7 @@ def cpu_baseline(np, ctx, batch, n_bases):
         g = batch.minimizers_raw(UNIT, W, SEED, FLAG_CANONICAL | FLAG_SYNC, first=a, n=min(step, nall - a))
         gc += int(g.count); gv ^= int(g.xor_value); gh ^= int(g.xor_hash); gp ^= int(g.xor_pos)
     same = (gc, gv, gh, gp) == (dall["count"], dall["xor_value"], dall["xor_hash"], dall["xor_pos"])
-    return {
+    out = {
         "value": round(nall / tall / 1e9, 4), "unit": "Gbp/s", "cores": cores, "kind": "port",
         "sample": f"first {nall // READ_LEN} reads ({nall / 1e9:.2f} Gbp) of rank 0's shard, OpenMP over reads, {cores} threads; "
                   f"single thread on the first {n1 / 1e9:.2f} Gbp",
@@ -282,6 +391,21 @@ def cpu_baseline(np, ctx, batch, n_bases):
         "gpu_result_bit_identical_on_sample": bool(same),
         "sample_records": dall["count"],
     }
+    # anchor: the REFERENCE itself (oracle/_ref, compiled from its unmodified sources) on the part of this path it can run — kmer_view
+    # canonical k=31 + hash64 per k-mer (BASELINE C2) — beside the port on the same bases, one thread each (within ~2x)
+    if O.have_ref():
+        nr = min(n_bases, 100_000_000)
+        s = O.as_bytes(seq[:nr])
+        t = time.perf_counter()
+        rx = int(O.ref().ref_scan_kmer_hash_xor(O._ptr(s), nr, 31, 1, 0))
+        tr = time.perf_counter() - t
+        t = time.perf_counter()
+        px = O.kmer_digest(s, np.array([0, nr], np.uint64), 31, True, 0, drop_last=True, threads=1)
+        tp = time.perf_counter() - t
+        out["reference_c2_anchor"] = {"kind": "reference", "path": "kmer_view<uint64_t> canonical k=31 + hash64 per k-mer, `it != cend()` idiom", "cores": 1,
+                                      "sample_Mbp": nr // 1_000_000, "reference_Gbps": round(nr / tr / 1e9, 4), "port_Gbps": round(nr / tp / 1e9, 4),
+                                      "xor_of_hashes_equal": bool(rx == px["xor_hash"])}
+    return out
 
 
 if __name__ == "__main__":

@@ -23,6 +23,15 @@
 #define BL_UNROLL
 #endif
 
+// Branches that synthetic / clean data never take (hash-prefix ties, breaks, ragged batch ends).  tools/valu_model.py builds
+// the kernels with BL_CENSUS_HOT, which compiles them out, to count the instructions of the hot path alone; no product build
+// defines it.
+#ifdef BL_CENSUS_HOT
+#define BL_COLD(c) (false)
+#else
+#define BL_COLD(c) (c)
+#endif
+
 namespace bl {
 
 constexpr int TPB = 256;            // threads per workgroup (4 wave64)
@@ -256,7 +265,7 @@ BL_DEV void encode16(const uint32_t d[4], uint32_t& code, uint32_t& bad)
     code = (c0 << 24) | (c1 << 16) | (c2 << 8) | c3;
     bad = 0;
     // breaks are rare in sequencing data: the per-base bit gather runs only for waves that hold one
-    if (wave_any((f0 | f1 | f2 | f3) != 0)) bad = bad_bits4(f0) | (bad_bits4(f1) << 4) | (bad_bits4(f2) << 8) | (bad_bits4(f3) << 12);
+    if (BL_COLD(wave_any((f0 | f1 | f2 | f3) != 0))) bad = bad_bits4(f0) | (bad_bits4(f1) << 4) | (bad_bits4(f2) << 8) | (bad_bits4(f3) << 12);
 }
 
 // reverse the order of the 32 two-bit pairs of x

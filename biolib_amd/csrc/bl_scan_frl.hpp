@@ -33,7 +33,7 @@ BL_DEV bool stage_chunk_frl(const ScanParams& p, uint32_t* codes, uint32_t* flag
     if (g + 16 <= p.n_bases) {
         const Vec16 v = *reinterpret_cast<const Vec16*>(p.bases + g);
         d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-    } else if (g < p.n_bases) {  // ragged end of the batch: byte-wise, zeros (= breaks) outside
+    } else if (BL_COLD(g < p.n_bases)) {  // ragged end of the batch: byte-wise, zeros (= breaks) outside
         for (int b = 0; b < 16; ++b) {
             const int64_t q = g + b;
             if (q < p.n_bases) d[b >> 2] |= (uint32_t)p.bases[q] << (8 * (b & 3));
@@ -142,7 +142,7 @@ BL_DEV void lane_window_argmin_frl(const ThreadState* all, int tid, const Thread
     }
 #endif
     const uint32_t dmin = window_argmin_packed<NS, W, true, true>(key, a);
-    if (wave_any(owns && dmin < 64u)) {  // a prefix tie somewhere in the wave: the exact 64-bit form
+    if (BL_COLD(wave_any(owns && dmin < 64u))) {  // a prefix tie somewhere in the wave: the exact 64-bit form
         uint64_t e[NK];
         BL_UNROLL
         for (int s = 0; s < NS; ++s) e[s] = st.h[s];
@@ -215,7 +215,7 @@ BL_DEV void phase_window_frl_a(const ScanParams& p, TileShared<MODE, W>& sh, int
         vmask = (1u << lim) - 1u;
     }
     const uint32_t tile_bad = sh.wave_bad[0] | sh.wave_bad[1] | sh.wave_bad[2] | sh.wave_bad[3];
-    if (tile_bad) vmask &= frl_good_mask<NS>(p, sh.flags, st.lane_base, p.unit + (W > 0 ? W : p.w) - 1);
+    if (BL_COLD(tile_bad)) vmask &= frl_good_mask<NS>(p, sh.flags, st.lane_base, p.unit + (W > 0 ? W : p.w) - 1);
     st.vmask = vmask;
 }
 

@@ -72,7 +72,7 @@ BL_DEV void stage_chunk(const ScanParams& p, uint32_t* codes, uint32_t* flags, i
     if (g >= 0 && g + 16 <= p.n_bases) {
         const Vec16 v = *reinterpret_cast<const Vec16*>(p.bases + g);  // one global_load_dwordx4 (a non-temporal load measured no faster)
         d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-    } else if (g + 16 > 0 && g < p.n_bases) {  // ragged edge: byte-wise, zeros (= breaks) outside
+    } else if (BL_COLD(g + 16 > 0 && g < p.n_bases)) {  // ragged edge: byte-wise, zeros (= breaks) outside
         for (int b = 0; b < 16; ++b) {
             const int64_t q = g + b;
             if (q >= 0 && q < p.n_bases) d[b >> 2] |= (uint32_t)p.bases[q] << (8 * (b & 3));
@@ -318,7 +318,7 @@ BL_DEV void lane_window_argmin(const ThreadState* all, int tid, const ThreadStat
     }
 #endif
     const uint32_t dmin = window_argmin_packed<NW, W, LEFT, RAW && LEFT>(key, a);
-    if (wave_any(owns && dmin < 64u)) {
+    if (BL_COLD(wave_any(owns && dmin < 64u))) {
 #ifdef BL_EXPERIMENT_COUNT_FALLBACK
         if ((tid & 63) == 0) atomicAdd(&bl_dbg_fallbacks, 1ull);
 #endif
@@ -469,7 +469,7 @@ BL_DEV void lane_window_argmin_generic(const ScanParams& p, TileShared<MODE, W>&
         BL_UNROLL
         for (int i = 0; i < NW; ++i) a[i] = LEFT ? (a[i] & 127u) : 127u - (a[i] & 127u);
     }
-    if (wave_any(owns && dmin < 128u)) {
+    if (BL_COLD(wave_any(owns && dmin < 128u))) {
 #ifdef BL_EXPERIMENT_COUNT_FALLBACK
         if ((tid & 63) == 0) atomicAdd(&bl_dbg_fallbacks, 1ull);
 #endif
@@ -758,7 +758,7 @@ template <int MODE, int W>
 BL_DEV void phase_emit(const ScanParams& p, const TileShared<MODE, W>& sh, int tid, int64_t q0, uint32_t n_s, uint32_t n_e,
                        uint64_t base_s, uint64_t base_e, Digest& dg)
 {
-    if (base_s + n_s <= p.capacity) {  // the usual case, uniform for the workgroup: no per-record capacity test
+    if (!BL_COLD(base_s + n_s > p.capacity)) {  // the usual case, uniform for the workgroup: no per-record capacity test
         for (uint32_t r = tid; r < n_s; r += TPB) {
             const Record rec = emit_prepare<MODE, W>(p, sh, q0, r, dg);
             emit_store<MODE, false>(p, rec, base_s + r);

@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstring>
+#include <new>
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_select.hpp>
 
@@ -262,5 +263,73 @@ extern "C" int bl_probe_hbm(bl_ctx* ctx, uint64_t n_bytes, int iters, double* re
     if (e != hipSuccess) return bl_set_error(e == hipErrorOutOfMemory ? BL_ERR_OOM : BL_ERR_HIP, hipGetErrorString(e));
     *read_gbps = (double)n_bytes * iters / (ms_read * 1e-3) / 1e9;
     *copy_gbps = 2.0 * (double)n_bytes * iters / (ms_copy * 1e-3) / 1e9;  // read + write
+    return BL_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Shader clock held by the chip WHILE other kernels run (MI355X_MICROARCH.md, DVFS item 6): one wave on its own stream
+// sleeps for duration_ms and stamps s_memtime (shader cycles) and s_memrealtime (100 MHz) at both ends.  bench.py starts
+// it at the head of the timed region, so the VALU ceiling is priced at the clock of the run, not at the nominal 2.4 GHz.
+namespace {
+
+__global__ __launch_bounds__(64) void clock_probe_kernel(unsigned long long* out, unsigned long long ticks)
+{
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime();
+    unsigned long long t = t0;
+    while (t - t0 < ticks) {  // wall-clock bound: the loop ends after `ticks` x 10 ns whatever else happens
+        __builtin_amdgcn_s_sleep(127);
+        t = __builtin_amdgcn_s_memrealtime();
+    }
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime();
+    if (threadIdx.x == 0) {
+        out[0] = c1 - c0;
+        out[1] = t - t0;
+    }
+}
+
+}  // namespace
+
+struct bl_clock_probe {
+    int device;
+    hipStream_t stream;
+    unsigned long long* pinned;  // [2]
+};
+
+extern "C" int bl_clock_probe_start(bl_ctx* ctx, uint32_t duration_ms, bl_clock_probe** out)
+{
+    if (!ctx || !out || duration_ms == 0 || duration_ms > 5000) return bl_set_error(BL_ERR_INVALID, "clock probe: need a context and 1..5000 ms");
+    *out = nullptr;
+    SET_HIP(hipSetDevice(bl_ctx_device(ctx)));
+    bl_clock_probe* p = new (std::nothrow) bl_clock_probe{bl_ctx_device(ctx), nullptr, nullptr};
+    if (!p) return bl_set_error(BL_ERR_OOM, "host allocation failed");
+    hipError_t e = hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&p->pinned), 2 * sizeof(unsigned long long), hipHostMallocDefault);
+    if (e == hipSuccess) {
+        p->pinned[0] = p->pinned[1] = 0;
+        hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, p->stream, p->pinned, (unsigned long long)duration_ms * 100000ull);
+        e = hipGetLastError();
+    }
+    if (e != hipSuccess) {
+        if (p->pinned) (void)hipHostFree(p->pinned);
+        if (p->stream) (void)hipStreamDestroy(p->stream);
+        delete p;
+        return bl_set_error(BL_ERR_HIP, hipGetErrorString(e));
+    }
+    *out = p;
+    return BL_OK;
+}
+
+extern "C" int bl_clock_probe_finish(bl_clock_probe* p, double* shader_ghz)
+{
+    if (!p) return bl_set_error(BL_ERR_INVALID, "probe is NULL");
+    (void)hipSetDevice(p->device);
+    hipError_t e = hipStreamSynchronize(p->stream);
+    const double cycles = (double)p->pinned[0], ticks = (double)p->pinned[1];
+    (void)hipHostFree(p->pinned);
+    (void)hipStreamDestroy(p->stream);
+    delete p;
+    if (e != hipSuccess) return bl_set_error(BL_ERR_HIP, hipGetErrorString(e));
+    if (shader_ghz) *shader_ghz = ticks > 0 ? cycles / ticks * 0.1 : 0.0;
     return BL_OK;
 }

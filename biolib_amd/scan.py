@@ -207,6 +207,17 @@ class Context:
         check(self._lib.bl_probe_hbm(self._h, int(n_bytes), int(iters), C.byref(r), C.byref(c)))
         return r.value, c.value
 
+    def clock_probe_start(self, duration_ms):
+        """start measuring the shader clock the chip holds over the next duration_ms (beside whatever else runs)"""
+        h = C.c_void_p()
+        check(self._lib.bl_clock_probe_start(self._h, int(duration_ms), C.byref(h)))
+        return h
+
+    def clock_probe_finish(self, probe):
+        ghz = C.c_double()
+        check(self._lib.bl_clock_probe_finish(probe, C.byref(ghz)))
+        return float(ghz.value)
+
     # ---- device arrays (torch plumbing)
     def empty_u64(self, n):
         import torch

@@ -105,7 +105,7 @@ def exchange(bucketed, counts, group=None):
     return inbox.to(bucketed.device) if staged else inbox
 
 
-def count_kmers_via_super_kmers(ctx, batch, k, m, seed=0, canonical=True, group=None):
+def count_kmers_via_super_kmers(ctx, batch, k, m, seed=0, canonical=True, group=None, force_exchange=False):
     """Distributed exact k-mer counting the way super-k-mers are meant to be used:
 
       scan  -> super-k-mers of this rank's reads (bl_scan_super_kmers)
@@ -115,11 +115,12 @@ def count_kmers_via_super_kmers(ctx, batch, k, m, seed=0, canonical=True, group=
 
     All occurrences of a canonical k-mer share their minimizer value, so they meet on one rank and its local count is
     the global one.  ~1.8 bytes per input base cross the links instead of 8 bytes per k-mer.  Works without a process
-    group (single GPU).  Returns (distinct k-mers, multiplicities) owned by this rank, as device tensors."""
+    group (single GPU); force_exchange runs the all-to-all even at world size 1 (tests).  Returns (distinct k-mers,
+    multiplicities) owned by this rank, as device tensors."""
     import torch.distributed as dist
 
     recs, hashes = batch.super_kmer_records(k, m, seed=seed, canonical=canonical)
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or force_exchange):
         bucketed, counts = ctx.partition_records(hashes, recs, dist.get_world_size(group))
         recs = exchange(bucketed, counts, group)
     kmers = ctx.expand_super_kmers(recs, k, canonical=canonical)

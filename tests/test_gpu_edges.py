@@ -1,5 +1,6 @@
 """GPU edge-case and property tests: limits of the C ABI, alternative batch constructors, extremes of k / w,
 super-k-mer and syncmer range unions, multi-context use from threads, size-independent properties at 1 Gbp."""
+import os
 import threading
 
 import numpy as np
@@ -234,4 +235,138 @@ def test_bench_two_rank_flow_on_one_gpu():
         xh ^= int(r.xor_hash)
         b.close()
     assert d["records_per_step"] == cnt and d["xor_hash"] == xh
+    c.close()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# The other BASELINE.json configurations at the sizes they are stated at (one GPU).  Parity at that size comes from
+# size-independent properties — two different cuttings of the shard must give the same count and digests — plus the
+# CPU oracle on a 256-Mbp prefix.
+
+def _cores():
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
+def _fold(results):
+    cnt, xv, xh, xp, aux = 0, 0, 0, 0, 0
+    for r in results:
+        assert r.status == 0
+        cnt += int(r.count); xv ^= int(r.xor_value); xh ^= int(r.xor_hash); xp ^= int(r.xor_pos); aux += int(r.aux)
+    return cnt, xv, xh, xp, aux
+
+
+def test_full_baseline_size_c2_kmers_10gbp():
+    """BASELINE C2 as stated: canonical 31-mer 2-bit encode + hash64 over 10 Gbp of synthetic DNA on one GPU (one sequence).
+    Two cuttings agree on count / XOR of values / XOR of hashes / wrapping sum of hashes; the count has its closed form;
+    the first 256 Mbp match the CPU oracle's digest."""
+    import biolib_amd as B
+
+    c = B.Context(0, torch_stream=False, lanes=2)
+    n = 10_000_000_000
+    b = c.synth(42, n)
+
+    def scan(step):
+        res = [b.kmers_raw(31, 0, B.FLAG_CANONICAL, first=a, n=min(step, n - a)) for a in range(0, n, step)]
+        c.sync()
+        cnt, xv, xh = 0, 0, 0
+        sm = 0
+        for r in res:
+            assert r.status == 0
+            cnt += int(r.count); xv ^= int(r.xor_value); xh ^= int(r.xor_hash); sm = (sm + int(r.xor_pos)) & (2**64 - 1)
+        return cnt, xv, xh, sm
+
+    a = scan(1_500_000_000)
+    d = scan(2_147_483_648)  # the largest range the ABI takes
+    assert a == d and a[0] == n - 30
+    s = 256_000_000
+    o = O.kmer_digest(b.download(0, s + 30), np.array([0, s + 30], np.uint64), 31, True, 0, threads=_cores())
+    r = b.kmers_raw(31, 0, B.FLAG_CANONICAL | B.FLAG_SYNC, first=0, n=s)
+    assert (int(r.count), int(r.xor_value), int(r.xor_hash)) == (o["count"], o["xor_value"], o["xor_hash"])
+    c.close()
+
+
+def test_full_baseline_size_c4_super_kmers_50gbp():
+    """BASELINE C4 as stated: super_kmer_view k=31 m=15 over 50 Gbp of 10-kbp reads on one GPU, records materialised.
+    Two cuttings agree; every group start has its end; group sizes sum to the k-mer total; 256 Mbp against the oracle."""
+    import biolib_amd as B
+
+    c = B.Context(0, torch_stream=False, lanes=2)
+    L, n_reads = 10_000, 5_000_000
+    n = L * n_reads
+    b = c.synth(42, n, L)
+    cap = int(2_147_480_000 * 2.3 / 18) + 65536
+    bufs = [(c.empty_u64(cap), c.empty_u64(cap), c.empty_u8(cap), c.empty_u8(cap), c.empty_u64(cap)) for _ in range(2)]
+
+    def scan(reads_per_range):
+        res = []
+        for i, a in enumerate(range(0, n_reads, reads_per_range)):
+            m = min(reads_per_range, n_reads - a)
+            mn, fp, mp, sz, hs = bufs[i & 1]
+            res.append(b.super_kmers_raw(31, 15, 42, B.FLAG_CANONICAL, first=a * L, n=m * L, minimizers=mn, first_pos=fp, mm_pos=mp, sizes=sz,
+                                         hashes=hs, capacity=cap))
+        c.sync()
+        return _fold(res)
+
+    a = scan(150_000)
+    d = scan(214_748)  # 2,147,480,000 positions per range: just under the 2^31 limit
+    assert a == d and a[0] == a[4]                      # every start has its end
+    windows = n_reads * (L - 31 + 1)
+    assert abs(a[0] / windows - 2 / 18) < 0.005         # random minimizers: 2/(w+1) groups per k-mer, w = 17
+    s = 25_600 * L
+    g = b.super_kmers(31, 15, seed=42, canonical=True, first=0, n=s)
+    assert int(g["sizes"].sum(dtype=np.uint64)) == 25_600 * (L - 30)
+    seq = b.download(0, s)
+    mn, fp, mp, sz, hs = O.super_kmers(seq, O.fixed_offsets(s, L), 31, 15, 42, True)
+    assert g["count"] == len(mn) and np.array_equal(g["first_pos"], fp) and np.array_equal(g["sizes"], sz)
+    assert np.array_equal(g["minimizers"], mn) and np.array_equal(g["mm_pos"], mp) and np.array_equal(g["hashes"], hs)
+    c.close()
+
+
+def test_full_baseline_size_c5_syncmers_with_rccl_count_reduce():
+    """BASELINE C5, one GPU's share as stated: syncmer_sampler k=31 s=11 offsets {0, 20} over a 50-Gbp shard of 10-kbp reads,
+    then the count reduction over RCCL (backend nccl, world 1 — the 8-GPU leg needs hardware this box does not have).
+    Two cuttings of the shard agree on count and position digest; 256 Mbp match the oracle's count."""
+    import torch
+    import torch.distributed as dist
+
+    import biolib_amd as B
+    from biolib_amd.shard import reduce_digests
+
+    c = B.Context(0, torch_stream=False, lanes=2)
+    L, n_reads = 10_000, 5_000_000
+    n = L * n_reads
+    b = c.synth(42, n, L)
+
+    def scan(reads_per_range):
+        res = [b.syncmers_raw(31, 11, 0, 20, 0, B.FLAG_CANONICAL, first=a * L, n=min(reads_per_range, n_reads - a) * L)
+               for a in range(0, n_reads, reads_per_range)]
+        c.sync()
+        return _fold(res)
+
+    a = scan(150_000)
+    d = scan(214_748)
+    assert a == d
+    kmers = n_reads * (L - 30)
+    assert abs(a[0] / kmers - 2 / 21) < 0.003           # open syncmers at two offsets of 21: 2/(k-s+1) of the k-mers
+    s = 25_600 * L
+    cnt, _ = O.syncmers(b.download(0, s), O.fixed_offsets(s, L), 31, 11, 0, 20, True, threads=_cores(), positions=False)
+    assert int(b.syncmers_raw(31, 11, 0, 20, 0, B.FLAG_CANONICAL | B.FLAG_SYNC, first=0, n=s).count) == cnt
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29561")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        tot = reduce_digests(dict(count=a[0], xor_pos=a[3]), device="cuda")  # all-reduce (sum) + all-gather (xor fold) on the device
+        assert tot == dict(count=a[0], xor_pos=a[3])
+    finally:
+        if created:
+            dist.destroy_process_group()
     c.close()

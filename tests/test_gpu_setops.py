@@ -261,6 +261,35 @@ def test_count_kmers_via_super_kmers_single_gpu(ctx):
             dist.destroy_process_group()
 
 
+def test_exchange_large_payload_rccl_own_streams():
+    """A context on its OWN (non-blocking) streams chained behind a large RCCL all-to-all: the library must not read the
+    inbox before the collective has delivered it (the wrapper synchronises torch's stream first).  60 Mbp -> ~100 MB of
+    16-byte records through all_to_all_single, then expand + sort + count, against the borrowed-stream context's result."""
+    import torch
+    import torch.distributed as dist
+
+    import biolib_amd as B
+    from biolib_amd.shard import count_kmers_via_super_kmers
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29536")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        n, L = 60_000_000, 150
+        own = B.Context(0, torch_stream=False, lanes=2)
+        ref = B.Context(0)
+        u1, c1 = count_kmers_via_super_kmers(own, own.synth(9, n, L), 31, 15, seed=42, canonical=True, group=dist.group.WORLD, force_exchange=True)
+        u2, c2 = count_kmers_via_super_kmers(ref, ref.synth(9, n, L), 31, 15, seed=42, canonical=True)
+        assert u1.numel() > 40_000_000 and torch.equal(u1, u2) and torch.equal(c1, c2)
+        own.close()
+        ref.close()
+    finally:
+        if created:
+            dist.destroy_process_group()
+
+
 TWO_RANK_COUNTER = r"""
 import os, sys
 sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))

@@ -1,18 +1,39 @@
 #!/usr/bin/env python3
-"""Turn gpurun_out/prof/ (tools/collect_profiles.sh) into the files under profiles/ that bench.py and DESIGN.md cite:
-r01_kernel_stats.csv (+ _lanes1), r01_pmc_summary.txt, traffic.json."""
-import collections, csv, glob, json, os, shutil, sys
+"""Turn gpurun_out/prof/ (tools/collect_profiles.sh, run on the GPU box) into the files under profiles/ that bench.py and
+DESIGN.md cite: rNN_kernel_stats.csv (+ _lanes1), rNN_pmc_summary.txt, rNN_pmc.json, rNN_ubench_valu.{txt,json},
+traffic.json — each stamped with where and from which commit it was measured.  Usage: summarise_profiles.py [rNN]"""
+import collections, csv, json, os, shutil, subprocess, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+RND = sys.argv[1] if len(sys.argv) > 1 else "r02"
 src = os.path.join(ROOT, "gpurun_out", "prof")
 dst = os.path.join(ROOT, "profiles")
-shutil.copy(os.path.join(src, "stats_lanes2", "s_kernel_stats.csv"), os.path.join(dst, "r01_kernel_stats.csv"))
-shutil.copy(os.path.join(src, "stats_lanes1", "s_kernel_stats.csv"), os.path.join(dst, "r01_kernel_stats_lanes1.csv"))
+BASES = 1_500_000_000  # every launch of the PMC command covers 1.5e9 bases (collect_profiles.sh)
 
-BASES = 1_500_000_000  # --gbp 6 -> 4 launches of 1.5e9 bases
-kernels = {"scan_count": "bl::scan_count_kernel<0, 11, 31, 1>", "scan_emit": "bl::scan_emit_kernel<0>"}
+git = lambda *a: subprocess.run(["git", "-C", ROOT, *a], capture_output=True, text=True).stdout.strip()
+box = open(os.path.join(src, "box.txt")).read().split("\n")
+prov = {"commit": git("rev-parse", "--short", "HEAD") + ("+dirty" if git("status", "--porcelain", "--untracked-files=no") else ""),
+        "box": box[0], "collected_utc": box[1] if len(box) > 1 else "", "command": open(os.path.join(src, "pmc_command.txt")).read().strip(),
+        "tools": "tools/collect_profiles.sh + tools/summarise_profiles.py"}
+
+shutil.copy(os.path.join(src, "stats_lanes2", "s_kernel_stats.csv"), os.path.join(dst, f"{RND}_kernel_stats.csv"))
+shutil.copy(os.path.join(src, "stats_lanes1", "s_kernel_stats.csv"), os.path.join(dst, f"{RND}_kernel_stats_lanes1.csv"))
+shutil.copy(os.path.join(src, "ubench_valu.txt"), os.path.join(dst, f"{RND}_ubench_valu.txt"))
+shutil.copy(os.path.join(src, "ubench_valu.json"), os.path.join(dst, f"{RND}_ubench_valu.json"))
+for lanes in ("lanes2", "lanes1"):
+    line = [x for x in open(os.path.join(src, f"stats_{lanes}.log")).read().splitlines() if x.startswith("{")]
+    if line:
+        open(os.path.join(dst, f"{RND}_bench_1gpu{'' if lanes == 'lanes2' else '_lanes1'}_under_rocprof.json"), "w").write(line[-1] + "\n")
+
+# kernel key -> substring of the kernel name rocprofv3 reports
+kernels = {
+    "c3_count": "scan_count_frl_kernel<0, 11, 15, 31, 150, 1>", "c3_emit": "scan_emit_kernel<0>",
+    "c2_kmer": "kmer_kernel",
+    "c4_count": "scan_count_kernel<1, 17, 15, 1>", "c4_emit": "scan_emit_kernel<1>",
+    "c5_count": "scan_count_kernel<2, 21, 11, 1>", "c5_emit": "scan_emit_kernel<2>",
+}
 means = {k: {} for k in kernels}
-for d in ("pmc_fetch", "pmc_write", "pmc_sq1", "pmc_sq2"):
+for d in ("pmc_fetch", "pmc_write", "pmc_sq1", "pmc_sq2", "pmc_sq3"):
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for row in csv.DictReader(open(os.path.join(src, d, "p_counter_collection.csv"))):
         for k, name in kernels.items():
@@ -21,30 +42,27 @@ for d in ("pmc_fetch", "pmc_write", "pmc_sq1", "pmc_sq2"):
     for k in acc:
         for c, v in acc[k].items():
             means[k][c] = (sum(v) / len(v), len(v))
-with open(os.path.join(dst, "r01_pmc_summary.txt"), "w") as f:
+with open(os.path.join(dst, f"{RND}_pmc_summary.txt"), "w") as f:
+    f.write(f"# {json.dumps(prov)}\n# mean per launch of {BASES:.3g} bases; FETCH_SIZE / WRITE_SIZE in KiB; FETCH_SIZE to be doubled on gfx950 (MI355X_MICROARCH.md, HBM)\n")
     for k in kernels:
-        f.write(f"== {k} (mean per launch of 1.5e9 bases over the dispatches of `bench.py --gbp 6 --steps 1 --warmup 0 --lanes 1`; "
-                "FETCH_SIZE/WRITE_SIZE in KiB; FETCH_SIZE to be doubled on gfx950, MI355X_MICROARCH.md)\n")
+        f.write(f"== {k}: {kernels[k]}\n")
         for c, (m, n) in sorted(means[k].items()):
             f.write(f"{c:28s} n={n:3d} mean={m:.6g}\n")
-cnt, emi = means["scan_count"], means["scan_emit"]
-hbm = lambda m: int((2 * m["FETCH_SIZE"][0] + m["WRITE_SIZE"][0]) * 1024)
-traffic = {
-    "kernel": kernels["scan_count"],
-    "measured_bases_per_launch": BASES,
-    "FETCH_SIZE_KiB": cnt["FETCH_SIZE"][0], "WRITE_SIZE_KiB": cnt["WRITE_SIZE"][0],
-    "hbm_bytes_per_launch_measured": hbm(cnt), "hbm_bytes_per_base": hbm(cnt) / BASES,
-    "valu_wave_instr_per_base": cnt["SQ_INSTS_VALU"][0] / BASES,
-    "emit_valu_wave_instr_per_base": emi["SQ_INSTS_VALU"][0] / BASES,
-    "method": "separate rocprofv3 --pmc passes (FETCH_SIZE; WRITE_SIZE; SQ counters; --kernel-trace only) over `python3 bench.py --gbp 6 --steps 1 "
-              "--warmup 0 --lanes 1 --no-cpu-baseline` (4 launches of 1.5e9 bases, one lane so that every counter belongs to one kernel); FETCH_SIZE "
-              "doubled: gfx950 reports 1/2 of a wide coalesced read stream (MI355X_MICROARCH.md, HBM); mean over the dispatches; bench.py scales by its "
-              "own bases per launch.  tools/collect_profiles.sh + tools/summarise_profiles.py",
-    "breakdown": "reads: 1 B/base ASCII + 1/8 B/base sequence-start bits (+3 % halo); writes: 2-byte record-list entries, 8-byte tile counts, "
-                 "0.26 B/base packed 2-bit codes handed to the emit pass",
-    "valu_note": "SQ_INSTS_VALU: wave-level VALU instructions per launch / bases per launch; x64 = lane-instructions per base",
-    "emit_kernel": {"kernel": kernels["scan_emit"], "FETCH_SIZE_KiB": emi["FETCH_SIZE"][0], "WRITE_SIZE_KiB": emi["WRITE_SIZE"][0],
-                    "hbm_bytes_per_launch_measured": hbm(emi)},
-}
+pmc = {"provenance": prov, "bases_per_launch": BASES, "kernels": {k: dict(kernel=kernels[k], **{c: m for c, (m, n) in means[k].items()}) for k in kernels}}
+json.dump(pmc, open(os.path.join(dst, f"{RND}_pmc.json"), "w"), indent=1)
+
+hbm = lambda m: (2 * m["FETCH_SIZE"][0] + m["WRITE_SIZE"][0]) * 1024  # FETCH_SIZE doubled: gfx950 tallies a wide coalesced read stream at 1/2
+traffic = {"provenance": prov,
+           "method": "separate rocprofv3 --pmc passes (FETCH_SIZE; WRITE_SIZE; --kernel-trace only), one lane so that every counter belongs to one kernel; "
+                     "FETCH_SIZE doubled (gfx950 reports 1/2 of a wide coalesced read stream, MI355X_MICROARCH.md HBM section); mean over the dispatches; "
+                     "bench.py scales bytes per base by its own bases per launch"}
+for cfg, (kc, ke) in {"c3": ("c3_count", "c3_emit"), "c4": ("c4_count", "c4_emit"), "c5": ("c5_count", "c5_emit"), "c2": ("c2_kmer", None)}.items():
+    if "FETCH_SIZE" not in means[kc]:
+        continue
+    traffic[cfg] = {"count_kernel": {"kernel": kernels[kc], "FETCH_SIZE_KiB": means[kc]["FETCH_SIZE"][0], "WRITE_SIZE_KiB": means[kc]["WRITE_SIZE"][0],
+                                     "hbm_bytes_per_base": hbm(means[kc]) / BASES}}
+    if ke and "FETCH_SIZE" in means[ke]:
+        traffic[cfg]["emit_kernel"] = {"kernel": kernels[ke], "FETCH_SIZE_KiB": means[ke]["FETCH_SIZE"][0], "WRITE_SIZE_KiB": means[ke]["WRITE_SIZE"][0],
+                                       "hbm_bytes_per_base": hbm(means[ke]) / BASES}
 json.dump(traffic, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
-print(json.dumps({k: traffic[k] for k in ("hbm_bytes_per_base", "valu_wave_instr_per_base", "emit_valu_wave_instr_per_base")}))
+print(json.dumps({k: {c: round(v, 4) for c, v in ((c, m[0] / BASES) for c, m in means[k].items() if c in ("SQ_INSTS_VALU",))} for k in kernels}))

@@ -19,7 +19,7 @@
 
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); return 1; } } while (0)
 
-constexpr int ITERS = 2048;
+constexpr int ITERS = 8192;
 constexpr int UNROLL = 16;
 
 struct Stamp {
@@ -109,6 +109,12 @@ KERNEL32(k_add3, "v_add3_u32 %0, %0, %1, %1")
 KERNEL32(k_lshl_add, "v_lshl_add_u32 %0, %0, 3, %1")
 KERNEL32(k_min3, "v_min3_u32 %0, %0, %1, %1")
 KERNEL32(k_bfrev, "v_bfrev_b32 %0, %0")
+KERNEL32(k_not, "v_not_b32 %0, %0")
+KERNEL32(k_or3, "v_or3_b32 %0, %0, %1, %1")
+KERNEL32(k_bfi, "v_bfi_b32 %0, %0, %1, %1")
+KERNEL32(k_bcnt, "v_bcnt_u32_b32 %0, %0, %1")
+KERNEL32(k_ashrrev, "v_ashrrev_i32 %0, 3, %0")
+KERNEL32(k_readfirstlane, "v_readfirstlane_b32 s10, %0")
 KERNEL32(k_mov_dpp_wave_shl, "v_mov_b32_dpp %0, %0 wave_shl:1 row_mask:0xf bank_mask:0xf")
 KERNEL32(k_mov_dpp_row_shr, "v_mov_b32_dpp %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf")
 KERNEL32(k_add_dpp_wave_shl, "v_add_u32_dpp %0, %0, %1 wave_shl:1 row_mask:0xf bank_mask:0xf")
@@ -117,6 +123,7 @@ KERNEL64(k_lshlrev_b64, "v_lshlrev_b64 %0, 3, %0")
 KERNEL64(k_lshrrev_b64, "v_lshrrev_b64 %0, 3, %0")
 KERNEL64(k_cmp_lt_u64, "v_cmp_lt_u64 vcc, %0, %0")
 KERNEL64(k_lshl_add_u64, "v_lshl_add_u64 %0, %0, 0, %0")
+KERNEL64(k_mov_b64, "v_mov_b64 %0, %0")
 
 // compiler-generated compound operations (what the hash path is really made of)
 #define KERNELC(NAME, EXPR)                                                                                  \
@@ -178,10 +185,11 @@ int main(int argc, char** argv)
         {"v_mul_lo_u32", k_mul_lo_u32, 0}, {"v_mul_hi_u32", k_mul_hi_u32, 0}, {"v_mul_u32_u24", k_mul_u32_u24, 0}, {"v_mad_u32_u24", k_mad_u32_u24, 0},
         {"v_alignbit_b32", k_alignbit, 0}, {"v_perm_b32", k_perm, 0}, {"v_bfe_u32", k_bfe, 0}, {"v_lshl_or_b32", k_lshl_or, 0},
         {"v_and_or_b32", k_and_or, 0}, {"v_xad_u32", k_xad, 0}, {"v_add3_u32", k_add3, 0}, {"v_lshl_add_u32", k_lshl_add, 0}, {"v_min3_u32", k_min3, 0},
-        {"v_bfrev_b32", k_bfrev, 0}, {"v_mov_b32_dpp wave_shl", k_mov_dpp_wave_shl, 0}, {"v_mov_b32_dpp row_shr", k_mov_dpp_row_shr, 0},
+        {"v_bfrev_b32", k_bfrev, 0}, {"v_not_b32", k_not, 0}, {"v_or3_b32", k_or3, 0}, {"v_bfi_b32", k_bfi, 0}, {"v_bcnt_u32_b32", k_bcnt, 0},
+        {"v_ashrrev_i32", k_ashrrev, 0}, {"v_readfirstlane_b32", k_readfirstlane, 0}, {"v_mov_b32_dpp wave_shl", k_mov_dpp_wave_shl, 0}, {"v_mov_b32_dpp row_shr", k_mov_dpp_row_shr, 0},
         {"v_add_u32_dpp wave_shl", k_add_dpp_wave_shl, 0},
         {"v_mad_u64_u32", k_mad_u64_u32, 0}, {"v_lshlrev_b64", k_lshlrev_b64, 0}, {"v_lshrrev_b64", k_lshrrev_b64, 0}, {"v_cmp_lt_u64", k_cmp_lt_u64, 0},
-        {"v_lshl_add_u64", k_lshl_add_u64, 0},
+        {"v_lshl_add_u64", k_lshl_add_u64, 0}, {"v_mov_b64", k_mov_b64, 0},
         {"C: x + k (u64)", k_add64, 1}, {"C: x * const (u64)", k_mul64c, 1}, {"C: x ^ (x >> 33)", k_xorshift33, 1}, {"C: rotl64(x, 31)", k_rotl31, 1},
         {"C: fmix64", k_fmix64, 1}, {"C: murmur64 (whole hash)", k_murmur64, 1}, {"C: min(x, k) (u64)", k_min64, 1},
     };
@@ -202,7 +210,7 @@ int main(int argc, char** argv)
         for (int wps : wps_list) {
             const int blocks = n_cu * wps;  // 4 waves per workgroup = one per SIMD
             // the chip settles its clock under load over tens of milliseconds: run the kernel back to back for ~0.2 s first
-            for (int rep = 0; rep < (k.compound ? 6 : 40); ++rep) hipLaunchKernelGGL(k.fn, dim3(blocks), dim3(256), 0, 0, d_out, d_sink, 1u);
+            for (int rep = 0; rep < (k.compound ? 3 : 10); ++rep) hipLaunchKernelGGL(k.fn, dim3(blocks), dim3(256), 0, 0, d_out, d_sink, 1u);
             CHECK(hipDeviceSynchronize());
             CHECK(hipEventRecord(e0));
             hipLaunchKernelGGL(k.fn, dim3(blocks), dim3(256), 0, 0, d_out, d_sink, 1u);
