@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cstring>
 #include <new>
+#include <vector>
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_select.hpp>
 
@@ -331,5 +332,92 @@ extern "C" int bl_clock_probe_finish(bl_clock_probe* p, double* shader_ghz)
     delete p;
     if (e != hipSuccess) return bl_set_error(BL_ERR_HIP, hipGetErrorString(e));
     if (shader_ghz) *shader_ghz = ticks > 0 ? cycles / ticks * 0.1 : 0.0;
+    return BL_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Read side of the spill format: run files / stored vectors biolib wrote -> device arrays, and the
+// k-way merge the reference's external_memory_vector iterator performs (external_memory_vector.hpp:265-347) as a tree of
+// pairwise device merges (rocprim::merge: library plumbing) over the runs loaded back to back.
+#include <rocprim/device/device_merge.hpp>
+
+extern "C" int bl_read_file_u64(bl_ctx* ctx, const char* path, int with_count, uint64_t* d_out, uint64_t capacity, uint64_t* n)
+{
+    if (!ctx || !path) return bl_set_error(BL_ERR_INVALID, "NULL argument");
+    uint64_t cnt = 0;
+    int rc = bl_file_count_u64(path, with_count, &cnt);
+    if (rc != BL_OK) return rc;
+    if (n) *n = cnt;
+    if (cnt > capacity) return bl_set_error(BL_ERR_CAPACITY, "device array too small for the file");
+    if (cnt == 0) return BL_OK;
+    if (!d_out) return bl_set_error(BL_ERR_INVALID, "NULL argument");
+    std::vector<uint64_t> host(cnt);
+    rc = bl_read_file_u64_host(path, with_count, host.data(), cnt, nullptr);
+    if (rc != BL_OK) return rc;
+    SET_HIP(hipSetDevice(bl_ctx_device(ctx)));
+    hipStream_t s = bl_ctx_stream(ctx);
+    SET_HIP(hipMemcpyAsync(d_out, host.data(), cnt * sizeof(uint64_t), hipMemcpyHostToDevice, s));
+    SET_HIP(hipStreamSynchronize(s));  // `host` goes away
+    return BL_OK;
+}
+
+extern "C" int bl_merge_runs_u64(bl_ctx* ctx, const char* const* paths, uint32_t n_paths, uint64_t* d_out, uint64_t capacity, uint64_t* n_total)
+{
+    if (!ctx || (n_paths && !paths) || !n_total) return bl_set_error(BL_ERR_INVALID, "NULL argument");
+    std::vector<uint64_t> len(n_paths), off(n_paths + 1, 0);
+    for (uint32_t i = 0; i < n_paths; ++i) {
+        int rc = bl_file_count_u64(paths[i], 0, &len[i]);
+        if (rc != BL_OK) return rc;
+        off[i + 1] = off[i] + len[i];
+    }
+    const uint64_t total = off[n_paths];
+    *n_total = total;
+    if (total > capacity) return bl_set_error(BL_ERR_CAPACITY, "device array too small for the merged runs");
+    if (total == 0) return BL_OK;
+    if (!d_out) return bl_set_error(BL_ERR_INVALID, "NULL argument");
+    for (uint32_t i = 0; i < n_paths; ++i) {
+        int rc = bl_read_file_u64(ctx, paths[i], 0, d_out + off[i], len[i], nullptr);
+        if (rc != BL_OK) return rc;
+    }
+    SET_HIP(hipSetDevice(bl_ctx_device(ctx)));
+    hipStream_t s = bl_ctx_stream(ctx);
+    // runs = [off[i], off[i+1]); merge neighbours pairwise, ping-ponging between d_out and a scratch array
+    unsigned long long* a = reinterpret_cast<unsigned long long*>(d_out);
+    unsigned long long* b = nullptr;
+    void* tmp = nullptr;
+    size_t tmp_bytes = 0;
+    hipError_t e = hipSuccess;
+    std::vector<uint64_t> cur(off);
+    bool in_a = true;
+    while (cur.size() > 2 && e == hipSuccess) {
+        if (!b) e = hipMalloc(reinterpret_cast<void**>(&b), total * sizeof(unsigned long long));
+        unsigned long long* src = in_a ? a : b;
+        unsigned long long* dst = in_a ? b : a;
+        std::vector<uint64_t> next(1, 0);
+        for (size_t i = 0; i + 1 < cur.size() && e == hipSuccess; i += 2) {
+            const uint64_t lo = cur[i], mid = cur[i + 1], hi = i + 2 < cur.size() ? cur[i + 2] : cur[i + 1];
+            if (hi == mid) {  // odd run out: copied through
+                if (mid > lo) e = hipMemcpyAsync(dst + lo, src + lo, (mid - lo) * sizeof(unsigned long long), hipMemcpyDeviceToDevice, s);
+            } else {
+                size_t need = 0;
+                e = rocprim::merge(nullptr, need, src + lo, src + mid, dst + lo, mid - lo, hi - mid, rocprim::less<unsigned long long>(), s);
+                if (e == hipSuccess && need > tmp_bytes) {
+                    if (tmp) { (void)hipStreamSynchronize(s); (void)hipFree(tmp); tmp = nullptr; }
+                    tmp_bytes = need;
+                    e = hipMalloc(&tmp, tmp_bytes);
+                }
+                if (e == hipSuccess) e = rocprim::merge(tmp, need, src + lo, src + mid, dst + lo, mid - lo, hi - mid, rocprim::less<unsigned long long>(), s);
+            }
+            next.push_back(hi);
+        }
+        cur.swap(next);
+        in_a = !in_a;
+    }
+    if (e == hipSuccess && !in_a) e = hipMemcpyAsync(a, b, total * sizeof(unsigned long long), hipMemcpyDeviceToDevice, s);
+    const hipError_t se = hipStreamSynchronize(s);
+    if (e == hipSuccess) e = se;
+    if (b) (void)hipFree(b);
+    if (tmp) (void)hipFree(tmp);
+    if (e != hipSuccess) return bl_set_error(e == hipErrorOutOfMemory ? BL_ERR_OOM : BL_ERR_HIP, hipGetErrorString(e));
     return BL_OK;
 }

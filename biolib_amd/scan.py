@@ -201,6 +201,27 @@ class Context:
             check(self._lib.bl_expand_super_kmers(self._h, C.c_void_p(records.data_ptr()), n, int(k), flags, C.c_void_p(out.data_ptr()), need.value, C.byref(need)))
         return out[: need.value]
 
+    def read_file_u64(self, path, with_count=False):
+        """a run file (raw sorted u64) or, with_count, an io::basic_store'd vector<uint64_t> of biolib -> device tensor"""
+        n = C.c_uint64()
+        check(self._lib.bl_file_count_u64(str(path).encode(), 1 if with_count else 0, C.byref(n)))
+        out = self.empty_u64(n.value)
+        check(self._lib.bl_read_file_u64(self._h, str(path).encode(), 1 if with_count else 0, C.c_void_p(out.data_ptr()), n.value, C.byref(n)))
+        return out[: n.value]
+
+    def merge_runs(self, paths):
+        """the sorted union (duplicates kept) of biolib run files, on the device: what iterating the reference's
+        external_memory_vector yields"""
+        arr = (C.c_char_p * len(paths))(*[str(p).encode() for p in paths])
+        total = C.c_uint64()
+        rc = self._lib.bl_merge_runs_u64(self._h, arr, len(paths), None, 0, C.byref(total))
+        if rc not in (0, capi.BL_ERR_CAPACITY):
+            check(rc)
+        out = self.empty_u64(total.value)
+        if total.value:
+            check(self._lib.bl_merge_runs_u64(self._h, arr, len(paths), C.c_void_p(out.data_ptr()), total.value, C.byref(total)))
+        return out[: total.value]
+
     def probe_hbm(self, n_bytes=8 << 30, iters=5):
         """(read GB/s, copy GB/s) sustained by this device: read-only stream kernel and DtoD copy"""
         r, c = C.c_double(), C.c_double()
@@ -438,11 +459,17 @@ class Batch:
 class Reader:
     """FASTA / FASTQ (plain or gzip) reader of the library (bl_reader_*): host records or device batches."""
 
-    def __init__(self, path):
+    def __init__(self, path, threads=0):
+        """threads: inflate workers for BGZF input (0 = one per core, at most 16); other inputs use one read-ahead thread"""
         self._lib = capi.lib()
         h = C.c_void_p()
-        check(self._lib.bl_reader_open(str(path).encode(), C.byref(h)))
+        check(self._lib.bl_reader_open_threads(str(path).encode(), int(threads), C.byref(h)))
         self._h = h
+
+    @property
+    def kind(self):
+        """'plain', 'gzip' or 'bgzf'"""
+        return self._lib.bl_reader_kind(self._h).decode()
 
     def close(self):
         if getattr(self, "_h", None):
@@ -464,6 +491,26 @@ class Reader:
                 return
             check(rc)
             yield name.value.decode("latin1"), C.string_at(seq.value, n.value) if n.value else b""
+
+    def text_spans(self, max_bytes=0):
+        """yield the decompressed text as bytes objects cut at record boundaries (what the device-side parser takes)"""
+        p, n = C.c_void_p(), C.c_uint64()
+        while True:
+            rc = self._lib.bl_reader_next_text(self._h, int(max_bytes), C.byref(p), C.byref(n))
+            if rc == 1:
+                return
+            check(rc)
+            yield C.string_at(p.value, n.value)
+
+    def device_batches(self, ctx, max_text_bytes=0):
+        """yield Batch objects parsed ON THE DEVICE from spans of the decompressed text (regular FASTA / 4-line FASTQ only;
+        names are not kept): parallel inflate -> one H2D copy -> bl_batch_from_text"""
+        while True:
+            b, ns, nb = C.c_void_p(), C.c_uint64(), C.c_uint64()
+            check(self._lib.bl_reader_next_batch_device(ctx._h, self._h, int(max_text_bytes), C.byref(b), C.byref(ns), C.byref(nb)))
+            if not b.value:
+                return
+            yield Batch(ctx, b)
 
     def batches(self, ctx, max_bases=0):
         """yield (Batch, names, offsets) of whole records holding at most max_bases bases each"""

@@ -178,13 +178,26 @@ int bl_ctx_kernel_time(bl_ctx* ctx, double* total_ms, uint64_t* launches);
  * line-final '\r' dropped; FASTQ quality must match the sequence length.  Bases are not altered: the scans treat
  * everything but ACGTUacgtu as a break, exactly as the reference table does (constants.hpp:12-21). */
 typedef struct bl_reader bl_reader;
+/* The file is decompressed by background threads that run ahead of the parser: BGZF (bgzip) members are inflated in parallel
+ * by `threads` workers (0 = one per core, at most 16), any other gzip stream by one thread, plain files are read ahead. */
 int bl_reader_open(const char* path, bl_reader** out);
+int bl_reader_open_threads(const char* path, int threads, bl_reader** out);
 int bl_reader_close(bl_reader* reader);
+/* "plain", "gzip" or "bgzf": how the file is being read */
+const char* bl_reader_kind(bl_reader* reader);
 /* Host only: next record.  Returns BL_OK, 1 at end of file, or an error.  Pointers stay valid until the next call. */
 int bl_reader_next_record(bl_reader* reader, const char** name, const char** seq, uint64_t* seq_len);
 /* Next batch of whole records holding at most max_bases bases (0 = the rest of the file; always at least one
  * record), uploaded to the device.  At end of file *out is NULL and *n_seqs is 0. */
 int bl_reader_next_batch(bl_ctx* ctx, bl_reader* reader, uint64_t max_bases, bl_batch** out, uint64_t* n_seqs, uint64_t* n_bases);
+/* The high-throughput path for regular files: the decompressed TEXT, cut at record boundaries (FASTQ: every 4 lines; FASTA: before
+ * a line-initial '>'), goes to the device-side parser (bl_batch_from_text) — parallel inflate, one H2D copy, parsing on the GPU.
+ * bl_reader_next_text hands out the next span of at most max_bytes (0 = 256 MiB; a longer single record is not split), valid
+ * until the next call, 1 at end of file; bl_reader_next_batch_device parses it on the device (names are not kept; *out NULL at
+ * end of file; BL_ERR_INVALID for layouts the device parser refuses — reopen and use the record calls).  Records and spans
+ * cannot be mixed on one reader. */
+int bl_reader_next_text(bl_reader* reader, uint64_t max_bytes, const char** text, uint64_t* n_bytes);
+int bl_reader_next_batch_device(bl_ctx* ctx, bl_reader* reader, uint64_t max_text_bytes, bl_batch** out, uint64_t* n_seqs, uint64_t* n_bases);
 /* Host copy of the batch produced last: concatenated bases, offsets[n_seqs+1], names. */
 int bl_reader_last_batch(bl_reader* reader, const char** bases, const uint64_t** offsets, uint64_t* n_seqs);
 const char* bl_reader_last_name(bl_reader* reader, uint64_t i);
@@ -205,6 +218,12 @@ int bl_jaccard_sorted_u64(bl_ctx* ctx, const uint64_t* d_a, uint64_t na, const u
 int bl_partition_u64(bl_ctx* ctx, const uint64_t* d_keys, uint64_t n, uint32_t parts, uint64_t seed, uint64_t* d_out, uint64_t* counts);
 int bl_sort_u64(bl_ctx* ctx, uint64_t* d_keys, uint64_t n);
 int bl_count_sorted_u64(bl_ctx* ctx, const uint64_t* d_sorted, uint64_t n, uint64_t* d_unique, uint32_t* d_counts, uint64_t* n_unique);
+
+/* Count reduction across the GPUs of one node: ctxs[g] is the context of device g (all distinct devices),
+ * counters holds n_gpu rows of n 64-bit counters — row g = GPU g's local counts in, the column sums out (in every row).  One
+ * ncclAllReduce(sum, uint64) per GPU over RCCL / xGMI, called on RCCL's C API directly (librccl.so.1 is loaded on first use);
+ * communicators are created once per device set and cached.  XOR digests have no RCCL reduction: fold them on the host. */
+int bl_count_allreduce(bl_ctx* const* ctxs, int n_gpu, uint64_t* counters, int n);
 
 /* Super-k-mer bucket exchange (record of reference super_kmer_view.hpp:20-24 made self-contained).
  * bl_pack_super_kmers: one 16-byte record per group of bl_scan_super_kmers — d_records[2g] = bases 0..31 of the group's
@@ -246,6 +265,16 @@ int bl_batch_from_text(bl_ctx* ctx, const char* text, uint64_t n_bytes, bl_batch
 int bl_run_file_name(const char* dir, const char* name, uint64_t id, char* out, uint64_t out_len);
 int bl_write_run_u64(bl_ctx* ctx, const uint64_t* d_sorted_keys, uint64_t n, const char* path);
 int bl_write_vector_u64(bl_ctx* ctx, const uint64_t* d_keys, uint64_t n, const char* path);
+/* The read side (reference io::basic_load io.hpp:114-122; external_memory_vector::const_iterator :265-347, a k-way merge over
+ * the run files): files biolib wrote feed the device set operations.
+ * bl_file_count_u64: elements in a run file (with_count = 0) or a basic_store'd vector (with_count = 1, checked against the size).
+ * bl_read_file_u64_host / bl_read_file_u64: its elements into a host / device array of `capacity` elements.
+ * bl_merge_runs_u64: the sorted union (duplicates kept) of n_paths run files in one device array — what iterating the
+ *   reference's external_memory_vector yields; BL_ERR_CAPACITY with *n_total = need when d_out is too small. */
+int bl_file_count_u64(const char* path, int with_count, uint64_t* n);
+int bl_read_file_u64_host(const char* path, int with_count, uint64_t* out, uint64_t capacity, uint64_t* n);
+int bl_read_file_u64(bl_ctx* ctx, const char* path, int with_count, uint64_t* d_out, uint64_t capacity, uint64_t* n);
+int bl_merge_runs_u64(bl_ctx* ctx, const char* const* paths, uint32_t n_paths, uint64_t* d_out, uint64_t capacity, uint64_t* n_total);
 
 /* ---- device memory helpers (for callers without their own allocator) ----------------------------- */
 int bl_device_alloc(bl_ctx* ctx, uint64_t bytes, void** d_ptr);

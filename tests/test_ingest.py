@@ -203,3 +203,120 @@ def test_fuzz_device_parser_vs_reference_reader(tmp_path):
         b.close()
     assert accepted >= 80  # the unmutated texts and the harmless mutations
     ctx.close()
+
+
+# ---- compressed inputs: stream gzip (one inflate thread running ahead), concatenated members, BGZF (parallel inflate) ----------
+def _bgzf(data, block=60000):
+    """BGZF (SAM spec §4.1): gzip members of <= 64 KiB with a 'BC' extra field that holds the member's size - 1, then the EOF marker"""
+    import struct
+    import zlib
+
+    out = bytearray()
+    for a in list(range(0, len(data), block)) + [None]:
+        chunk = b"" if a is None else data[a:a + block]
+        z = zlib.compressobj(6, zlib.DEFLATED, -15)
+        body = z.compress(chunk) + z.flush()
+        bsize = 12 + 6 + len(body) + 8
+        out += b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, bsize - 1)
+        out += body + struct.pack("<II", zlib.crc32(chunk) & 0xFFFFFFFF, len(chunk))
+    return bytes(out)
+
+
+def _fastq(n_reads, seed=1):
+    rng = np.random.default_rng(seed)
+    seqs = [bytes(rng.choice(np.frombuffer(b"ACGTN", np.uint8), int(rng.integers(1, 300)), p=[.24, .24, .24, .24, .04]).tobytes()) for _ in range(n_reads)]
+    text = b"".join(b"@r%d extra\n" % i + s + b"\n+\n" + b"I" * len(s) + b"\n" for i, s in enumerate(seqs))
+    return seqs, text
+
+
+@pytest.mark.parametrize("form", ["plain", "gzip", "multi_member", "bgzf", "bgzf_1thread"])
+def test_compressed_inputs_host_records(tmp_path, form):
+    import gzip
+
+    import biolib_amd
+
+    seqs, text = _fastq(20_000)
+    path = tmp_path / ("r.fq" if form == "plain" else "r.fq.gz")
+    if form == "plain":
+        path.write_bytes(text)
+    elif form == "gzip":
+        path.write_bytes(gzip.compress(text, 1))
+    elif form == "multi_member":  # cat a.gz b.gz c.gz
+        cuts = [0, len(text) // 3, len(text) // 2, len(text)]
+        path.write_bytes(b"".join(gzip.compress(text[a:b], 1) for a, b in zip(cuts, cuts[1:])))
+    else:
+        path.write_bytes(_bgzf(text))
+    r = biolib_amd.Reader(path, threads=1 if form == "bgzf_1thread" else 4)
+    assert r.kind == {"plain": "plain", "gzip": "gzip", "multi_member": "gzip"}.get(form, "bgzf")
+    got = list(r.records())
+    assert [s for _, s in got] == seqs and got[7][0] == "r7"
+
+
+@pytest.mark.parametrize("form", ["gzip", "bgzf"])
+def test_damaged_compressed_inputs_fail_loudly(tmp_path, form):
+    import gzip
+
+    import biolib_amd
+
+    _, text = _fastq(5_000, seed=2)
+    blob = gzip.compress(text, 1) if form == "gzip" else _bgzf(text)
+    for damage in ("truncated", "flipped"):
+        bad = bytearray(blob)
+        if damage == "truncated":
+            bad = bad[: len(bad) // 2]
+        else:
+            bad[len(bad) // 2] ^= 0x55
+        path = tmp_path / f"{damage}.gz"
+        path.write_bytes(bytes(bad))
+        with pytest.raises(biolib_amd.BiolibError):
+            list(biolib_amd.Reader(path).records())
+
+
+@pytest.mark.parametrize("kind", ["fastq", "fasta"])
+def test_text_spans_cut_at_record_boundaries(tmp_path, kind):
+    """the spans handed to the device parser: their concatenation is the decompressed text and each one ends where a record ends"""
+    import biolib_amd
+
+    seqs, fq = _fastq(30_000, seed=3)
+    if kind == "fastq":
+        text = fq
+    else:
+        text = b"".join(b">c%d\n" % i + b"\n".join(s[j:j + 60] for j in range(0, len(s), 60)) + b"\n" for i, s in enumerate(seqs))
+    path = tmp_path / "t.gz"
+    path.write_bytes(_bgzf(text))
+    for limit in (1 << 16, 1 << 20, 0):
+        spans = list(biolib_amd.Reader(path).text_spans(limit))
+        assert b"".join(spans) == text
+        for s in spans:
+            assert s[:1] == (b"@" if kind == "fastq" else b">") and s[-1:] == b"\n"
+            if kind == "fastq":
+                assert s.count(b"\n") % 4 == 0
+        if limit:
+            assert max(len(s) for s in spans) <= limit and len(spans) >= len(text) // limit
+
+
+@pytest.mark.gpu
+def test_bgzf_to_device_parser_to_scan(tmp_path):
+    """.gz -> parallel inflate -> text spans -> device-side parser -> scan, against the oracle on the same reads"""
+    import biolib_amd
+
+    rng = np.random.default_rng(8)
+    n_reads, L = 200_000, 150
+    seq = O.synth(21, n_reads * L)
+    seq[rng.integers(0, len(seq), len(seq) // 2000)] = ord("N")
+    text = b"".join(b"@r%d\n" % i + seq[i * L:(i + 1) * L].tobytes() + b"\n+\n" + b"I" * L + b"\n" for i in range(n_reads))
+    path = tmp_path / "reads.fq.gz"
+    path.write_bytes(_bgzf(text))
+    ctx = biolib_amd.Context(0)
+    cnt = xh = xp = 0
+    total = 0
+    for b in biolib_amd.Reader(path, threads=8).device_batches(ctx, 8 << 20):
+        g = b.minimizers_raw(31, 11, 42, biolib_amd.FLAG_CANONICAL | biolib_amd.FLAG_SYNC)
+        assert b.n_bases % L == 0
+        pos = b.minimizers(31, 11, seed=42, canonical=True)["positions"] + np.uint64(total)
+        cnt += int(g.count); xh ^= int(g.xor_hash); xp ^= O.xor_reduce(pos)
+        total += b.n_bases
+        b.close()
+    d = O.minimizer_digest(seq, O.fixed_offsets(len(seq), L), 31, 11, 42, True, threads=8)
+    assert total == len(seq) and (cnt, xh, xp) == (d["count"], d["xor_hash"], d["xor_pos"])
+    ctx.close()

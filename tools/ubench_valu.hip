@@ -114,7 +114,6 @@ KERNEL32(k_or3, "v_or3_b32 %0, %0, %1, %1")
 KERNEL32(k_bfi, "v_bfi_b32 %0, %0, %1, %1")
 KERNEL32(k_bcnt, "v_bcnt_u32_b32 %0, %0, %1")
 KERNEL32(k_ashrrev, "v_ashrrev_i32 %0, 3, %0")
-KERNEL32(k_readfirstlane, "v_readfirstlane_b32 s10, %0")
 KERNEL32(k_mov_dpp_wave_shl, "v_mov_b32_dpp %0, %0 wave_shl:1 row_mask:0xf bank_mask:0xf")
 KERNEL32(k_mov_dpp_row_shr, "v_mov_b32_dpp %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf")
 KERNEL32(k_add_dpp_wave_shl, "v_add_u32_dpp %0, %0, %1 wave_shl:1 row_mask:0xf bank_mask:0xf")
@@ -186,7 +185,7 @@ int main(int argc, char** argv)
         {"v_alignbit_b32", k_alignbit, 0}, {"v_perm_b32", k_perm, 0}, {"v_bfe_u32", k_bfe, 0}, {"v_lshl_or_b32", k_lshl_or, 0},
         {"v_and_or_b32", k_and_or, 0}, {"v_xad_u32", k_xad, 0}, {"v_add3_u32", k_add3, 0}, {"v_lshl_add_u32", k_lshl_add, 0}, {"v_min3_u32", k_min3, 0},
         {"v_bfrev_b32", k_bfrev, 0}, {"v_not_b32", k_not, 0}, {"v_or3_b32", k_or3, 0}, {"v_bfi_b32", k_bfi, 0}, {"v_bcnt_u32_b32", k_bcnt, 0},
-        {"v_ashrrev_i32", k_ashrrev, 0}, {"v_readfirstlane_b32", k_readfirstlane, 0}, {"v_mov_b32_dpp wave_shl", k_mov_dpp_wave_shl, 0}, {"v_mov_b32_dpp row_shr", k_mov_dpp_row_shr, 0},
+        {"v_ashrrev_i32", k_ashrrev, 0}, {"v_mov_b32_dpp wave_shl", k_mov_dpp_wave_shl, 0}, {"v_mov_b32_dpp row_shr", k_mov_dpp_row_shr, 0},
         {"v_add_u32_dpp wave_shl", k_add_dpp_wave_shl, 0},
         {"v_mad_u64_u32", k_mad_u64_u32, 0}, {"v_lshlrev_b64", k_lshlrev_b64, 0}, {"v_lshrrev_b64", k_lshrrev_b64, 0}, {"v_cmp_lt_u64", k_cmp_lt_u64, 0},
         {"v_lshl_add_u64", k_lshl_add_u64, 0}, {"v_mov_b64", k_mov_b64, 0},
