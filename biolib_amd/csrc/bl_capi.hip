@@ -879,6 +879,16 @@ int bl_copy_to_host(bl_ctx* c, void* dst, const void* d_src, uint64_t bytes)
     return BL_OK;
 }
 
+int bl_copy_to_device(bl_ctx* c, void* d_dst, const void* src, uint64_t bytes)
+{
+    if (!c || (bytes && (!d_dst || !src))) return fail(BL_ERR_INVALID, "NULL argument");
+    BL_HIP(hipSetDevice(c->device));
+    int rc = sync_ctx(c);
+    if (rc != BL_OK) return rc;
+    if (bytes) BL_HIP(hipMemcpy(d_dst, src, bytes, hipMemcpyHostToDevice));
+    return BL_OK;
+}
+
 uint64_t bl_hash64_u64(uint64_t value, uint64_t seed) { return bl::murmur64(value, (uint32_t)seed); }
 
 }  // extern "C"

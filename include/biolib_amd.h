@@ -280,6 +280,7 @@ int bl_merge_runs_u64(bl_ctx* ctx, const char* const* paths, uint32_t n_paths, u
 int bl_device_alloc(bl_ctx* ctx, uint64_t bytes, void** d_ptr);
 int bl_device_free(bl_ctx* ctx, void* d_ptr);
 int bl_copy_to_host(bl_ctx* ctx, void* dst, const void* d_src, uint64_t bytes); /* synchronous */
+int bl_copy_to_device(bl_ctx* ctx, void* d_dst, const void* src, uint64_t bytes); /* synchronous */
 
 /* ---- host-side scalar helper (bit-exact with the device hash) ------------------------------------- */
 uint64_t bl_hash64_u64(uint64_t value, uint64_t seed);

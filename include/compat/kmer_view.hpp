@@ -11,6 +11,8 @@
 // reference reads out of bounds (length < k, break followed by fewer than k bases at the end; Q2)
 // terminate cleanly instead.  KmerType must fit 64 bits and k <= 32 (the reference's own limit for
 // uint64_t, kmer_view.hpp:195).
+// Views built on memory handed out by a biolib_amd::read_pool (read_pool.hpp) do not go to the GPU one by one: they
+// index into the single scan of the pool's current batch.
 #ifndef BIOLIB_AMD_COMPAT_KMER_VIEW_HPP
 #define BIOLIB_AMD_COMPAT_KMER_VIEW_HPP
 
@@ -21,6 +23,7 @@
 #include <type_traits>
 
 #include "biolib_amd_runtime.hpp"
+#include "read_pool.hpp"
 #include "constants.hpp"
 #include "hash.hpp"
 
@@ -40,8 +43,11 @@ class kmer_view
     static_assert(sizeof(KmerType) <= 8, "the GPU path packs k-mers in 64 bits (k <= 32)");
 
     struct materialised {
-        std::string chars;             // host copy of [start, stop)
-        std::vector<uint64_t> values;  // per position: packed (canonical) k-mer, 0 where none starts
+        std::string own_chars;             // host copy of [start, stop) (empty for pooled views)
+        std::vector<uint64_t> own_values;  // per position: packed (canonical) k-mer, 0 where none starts
+        char const* chars = nullptr;       // what the iterators read: the copies above, or a read_pool's arena and its batch scan
+        uint64_t const* values = nullptr;
+        std::size_t n = 0;
     };
 
     public:
@@ -130,8 +136,18 @@ class kmer_view
         bool is_canonical() const noexcept {return canon;}
 
         // bulk access: the whole view as arrays (what a GPU-aware caller should use instead of iterating)
-        std::string const& chars() const {return materialise()->chars;}
-        std::vector<uint64_t> const& values() const {return materialise()->values;}
+        std::string const& chars() const
+        {
+            auto const* m = materialise();
+            if (m->own_chars.size() != m->n) cache->own_chars.assign(m->chars, m->n);  // pooled view: copy on demand
+            return cache->own_chars;
+        }
+        std::vector<uint64_t> const& values() const
+        {
+            auto const* m = materialise();
+            if (m->own_values.size() != m->n) cache->own_values.assign(m->values, m->values + m->n);
+            return cache->own_values;
+        }
 
     private:
         Iterator itr_start;
@@ -142,7 +158,8 @@ class kmer_view
 
         std::size_t length() const
         {
-            if (cache) return cache->chars.size();
+            if (cache) return cache->n;
+            if constexpr (std::is_same<Iterator, char_iterator>::value) return static_cast<std::size_t>(itr_stop.base() - itr_start.base());
             std::size_t n = 0;
             for (Iterator it = itr_start; it != itr_stop; ++it) ++n;
             return n;
@@ -152,17 +169,31 @@ class kmer_view
         {
             if (cache) return cache.get();
             auto m = std::make_shared<materialised>();
-            for (Iterator it = itr_start; it != itr_stop; ++it) m->chars.push_back(*it);
-            const std::size_t n = m->chars.size();
-            m->values.assign(n, 0);
+            if constexpr (std::is_same<Iterator, char_iterator>::value) {
+                // contiguous memory: is it a record a read_pool handed out?  then the batch scan already holds its k-mers
+                const std::size_t n = static_cast<std::size_t>(itr_stop.base() - itr_start.base());
+                if (uint64_t const* pooled = biolib_amd::read_pool::lookup(itr_start.base(), n, klen, canon)) {
+                    m->chars = itr_start.base();
+                    m->values = pooled;
+                    m->n = n;
+                    cache = m;
+                    return cache.get();
+                }
+            }
+            for (Iterator it = itr_start; it != itr_stop; ++it) m->own_chars.push_back(*it);
+            const std::size_t n = m->own_chars.size();
+            m->own_values.assign(n, 0);
             if (n >= klen) {
-                biolib_amd::batch_handle batch(m->chars.data(), n);
+                biolib_amd::batch_handle batch(m->own_chars.data(), n);
                 biolib_amd::device_array<uint64_t> d_values(n);
                 bl_result res;
                 biolib_amd::check(bl_scan_kmers(biolib_amd::context::get(), batch.b, 0, 0, klen, 0, (canon ? (uint32_t)BL_FLAG_CANONICAL : 0u) | BL_FLAG_SYNC,
                                                 d_values.d, nullptr, nullptr, &res), "bl_scan_kmers");
-                m->values = d_values.to_host(n);
+                m->own_values = d_values.to_host(n);
             }
+            m->chars = m->own_chars.data();
+            m->values = m->own_values.data();
+            m->n = n;
             cache = m;
             return cache.get();
         }

@@ -1,0 +1,180 @@
+// multi_gpu.hpp — the host side of the path on the GPUs of one node, in C++ (north_star: "host side stays C++ ... input
+// sequences shard by read/contig across the 8 GPUs of one node, with RCCL over xGMI used only for the optional final k-mer-count
+// reduction").  No counterpart in biolib, which is single-threaded; the unit of sharding is the reference's own: one view per
+// sequence (tests/test_kmer_view.cpp:35-36), so whole reads go to one GPU and no window ever spans two shards.
+//
+// biolib_amd::multi_gpu owns one context and one host thread per device.  A scan call splits the reads into contiguous
+// shards balanced by bases, every thread uploads (or synthesises) its shard, scans it in ranges of <= 1.5 Gbp and folds the
+// per-range digests; counts are then summed across the devices with bl_count_allreduce (ncclAllReduce over RCCL), XOR digests
+// — for which RCCL has no reduction — are folded on the host.  Shards are independent: there is no data-path collective.
+#ifndef BIOLIB_AMD_COMPAT_MULTI_GPU_HPP
+#define BIOLIB_AMD_COMPAT_MULTI_GPU_HPP
+
+#include <algorithm>
+#include <exception>
+#include <functional>
+#include <thread>
+
+#include "biolib_amd_runtime.hpp"
+
+namespace biolib_amd {
+
+struct scan_digest {
+    uint64_t count = 0, xor_value = 0, xor_hash = 0, xor_pos = 0;
+};
+
+class multi_gpu
+{
+    public:
+        // n_devices <= 0: every visible device
+        explicit multi_gpu(int n_devices = 0)
+        {
+            int visible = 0;
+            check(bl_device_count(&visible), "bl_device_count");
+            const int n = n_devices <= 0 ? visible : std::min(n_devices, visible);
+            if (n < 1) throw std::runtime_error("[biolib_amd] no GPU visible: there is no CPU fallback");
+            for (int d = 0; d < n; ++d) {
+                bl_ctx* c = nullptr;
+                check(bl_ctx_create(d, &c), "bl_ctx_create");
+                ctxs.push_back(c);
+            }
+        }
+        ~multi_gpu() {for (bl_ctx* c : ctxs) bl_ctx_destroy(c);}
+        multi_gpu(multi_gpu const&) = delete;
+        int devices() const noexcept {return static_cast<int>(ctxs.size());}
+
+        // contiguous range of sequences [first, end) for shard g of n: about the same number of bases each
+        static std::pair<uint64_t, uint64_t> shard_of(uint64_t const* offsets, uint64_t n_seqs, int g, int n)
+        {
+            const uint64_t total = offsets[n_seqs];
+            auto cut = [&](int i) -> uint64_t {
+                if (i <= 0) return 0;
+                if (i >= n) return n_seqs;
+                const uint64_t want = total / n * i + total % n * i / n;
+                return static_cast<uint64_t>(std::lower_bound(offsets, offsets + n_seqs + 1, want) - offsets);
+            };
+            const uint64_t lo = std::min(cut(g), n_seqs), hi = std::min(std::max(cut(g + 1), lo), n_seqs);
+            return {lo, hi};
+        }
+
+        // minimizer scan (unit-mers, window w) of host sequences; digest over all shards, positions relative to each shard's first base
+        scan_digest minimizers(char const* bases, uint64_t const* offsets, uint64_t n_seqs, uint32_t unit, uint32_t w, uint64_t seed, bool canonical)
+        {
+            return run(bases, offsets, n_seqs, [=](bl_ctx* c, bl_batch* b, uint64_t first, uint64_t n, bl_result* r) {
+                return bl_scan_minimizers(c, b, first, n, unit, w, seed, canonical ? (uint32_t)BL_FLAG_CANONICAL : 0u, nullptr, nullptr, nullptr, 0, r);
+            });
+        }
+        // syncmer count (BASELINE C5): k-mers whose minimum s-mer sits at one of the two offsets
+        scan_digest syncmers(char const* bases, uint64_t const* offsets, uint64_t n_seqs, uint32_t k, uint32_t s, uint32_t start_offset, uint32_t end_offset,
+                             bool canonical)
+        {
+            return run(bases, offsets, n_seqs, [=](bl_ctx* c, bl_batch* b, uint64_t first, uint64_t n, bl_result* r) {
+                return bl_scan_syncmers(c, b, first, n, k, s, start_offset, end_offset, 0, canonical ? (uint32_t)BL_FLAG_CANONICAL : 0u, nullptr, 0, r);
+            });
+        }
+        // the same over synthetic shards generated on the devices (SURVEY.md §8d generator, seed + device index), read_len-base reads
+        scan_digest syncmers_synth(uint64_t seed, uint64_t bases_per_device, uint64_t read_len, uint32_t k, uint32_t s, uint32_t start_offset, uint32_t end_offset,
+                                   bool canonical)
+        {
+            return run_synth(seed, bases_per_device, read_len, [=](bl_ctx* c, bl_batch* b, uint64_t first, uint64_t n, bl_result* r) {
+                return bl_scan_syncmers(c, b, first, n, k, s, start_offset, end_offset, 0, canonical ? (uint32_t)BL_FLAG_CANONICAL : 0u, nullptr, 0, r);
+            });
+        }
+        scan_digest minimizers_synth(uint64_t seed, uint64_t bases_per_device, uint64_t read_len, uint32_t unit, uint32_t w, uint64_t hash_seed, bool canonical)
+        {
+            return run_synth(seed, bases_per_device, read_len, [=](bl_ctx* c, bl_batch* b, uint64_t first, uint64_t n, bl_result* r) {
+                return bl_scan_minimizers(c, b, first, n, unit, w, hash_seed, canonical ? (uint32_t)BL_FLAG_CANONICAL : 0u, nullptr, nullptr, nullptr, 0, r);
+            });
+        }
+        std::vector<scan_digest> const& per_device() const noexcept {return last;}
+
+    private:
+        using scan_fn = std::function<int(bl_ctx*, bl_batch*, uint64_t, uint64_t, bl_result*)>;
+        static constexpr uint64_t RANGE = 1500000000ull;
+        std::vector<bl_ctx*> ctxs;
+        std::vector<scan_digest> last;
+
+        // scan a whole batch in ranges that end on sequence boundaries where offsets are known (fixed read length otherwise)
+        static scan_digest scan_batch(bl_ctx* c, bl_batch* b, uint64_t n_bases, uint64_t align, scan_fn const& scan)
+        {
+            std::vector<bl_result> res;
+            const uint64_t step = align ? std::max<uint64_t>(align, RANGE / align * align) : RANGE;
+            res.reserve(n_bases / step + 1);
+            for (uint64_t a = 0; a < n_bases; a += step) {
+                res.emplace_back();
+                check(scan(c, b, a, std::min(step, n_bases - a), &res.back()), "scan");
+            }
+            check(bl_ctx_sync(c), "bl_ctx_sync");
+            scan_digest d;
+            for (bl_result const& r : res) {
+                if (r.status != BL_OK) throw std::runtime_error("[biolib_amd] a scan range failed");
+                d.count += r.count;
+                d.xor_value ^= r.xor_value;
+                d.xor_hash ^= r.xor_hash;
+                d.xor_pos ^= r.xor_pos;
+            }
+            return d;
+        }
+        scan_digest reduce()
+        {
+            // counts: summed across the devices over RCCL; XOR digests: folded on the host (no XOR reduction in RCCL)
+            const int n = devices();
+            std::vector<uint64_t> counters(n);
+            for (int g = 0; g < n; ++g) counters[g] = last[g].count;
+            check(bl_count_allreduce(ctxs.data(), n, counters.data(), 1), "bl_count_allreduce");
+            scan_digest total;
+            total.count = counters[0];
+            for (int g = 0; g < n; ++g) {
+                if (counters[g] != counters[0]) throw std::runtime_error("[biolib_amd] the all-reduce left different sums on different devices");
+                total.xor_value ^= last[g].xor_value;
+                total.xor_hash ^= last[g].xor_hash;
+                total.xor_pos ^= last[g].xor_pos;
+            }
+            return total;
+        }
+        void in_parallel(std::function<void(int)> const& work)
+        {
+            const int n = devices();
+            std::vector<std::exception_ptr> errors(n);
+            std::vector<std::thread> threads;
+            for (int g = 0; g < n; ++g)
+                threads.emplace_back([&, g] {
+                    try { work(g); } catch (...) { errors[g] = std::current_exception(); }
+                });
+            for (auto& t : threads) t.join();
+            for (auto const& e : errors)
+                if (e) std::rethrow_exception(e);
+        }
+        scan_digest run(char const* bases, uint64_t const* offsets, uint64_t n_seqs, scan_fn scan)
+        {
+            const int n = devices();
+            last.assign(n, scan_digest());
+            in_parallel([&](int g) {
+                auto [lo, hi] = shard_of(offsets, n_seqs, g, n);
+                if (hi == lo) return;
+                std::vector<uint64_t> local(hi - lo + 1);
+                for (uint64_t q = lo; q <= hi; ++q) local[q - lo] = offsets[q] - offsets[lo];
+                bl_batch* b = nullptr;
+                check(bl_batch_upload(ctxs[g], bases + offsets[lo], local.back(), local.data(), hi - lo, &b), "bl_batch_upload");
+                try { last[g] = scan_batch(ctxs[g], b, local.back(), 0, scan); } catch (...) { bl_batch_destroy(b); throw; }
+                bl_batch_destroy(b);
+            });
+            return reduce();
+        }
+        scan_digest run_synth(uint64_t seed, uint64_t bases_per_device, uint64_t read_len, scan_fn scan)
+        {
+            const int n = devices();
+            last.assign(n, scan_digest());
+            in_parallel([&](int g) {
+                bl_batch* b = nullptr;
+                check(bl_batch_synth(ctxs[g], seed + g, bases_per_device, read_len, &b), "bl_batch_synth");
+                try { last[g] = scan_batch(ctxs[g], b, bases_per_device, read_len, scan); } catch (...) { bl_batch_destroy(b); throw; }
+                bl_batch_destroy(b);
+            });
+            return reduce();
+        }
+};
+
+}  // namespace biolib_amd
+
+#endif

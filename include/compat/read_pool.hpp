@@ -1,0 +1,106 @@
+// read_pool.hpp — batched front end for the drop-in views (no counterpart in biolib: it exists because of how biolib's own
+// drivers use the views).  The reference builds one view per sequence inside its read loop (tests/test_kmer_view.cpp:30-42):
+//     while (kseq_read(seq) >= 0) { auto view = wrapper::kmer_view_from_cstr<kmer_t>(seq->seq.s, seq->seq.l, k, canonical); for (...) ... }
+// On short reads a GPU round trip per view costs far more than the work it carries.  A read_pool reads AHEAD: it parses the next
+// records of the file into one arena, uploads them as one batch, and hands out pointers into that arena.  When a view is then
+// built on such a pointer, kmer_view finds the arena through the pool registry and takes its k-mers from ONE scan of the whole
+// batch (run when the first view of the batch asks, with that view's k and canonical flag): the loop body stays unchanged,
+//     biolib_amd::read_pool pool(path);
+//     while (pool.next(s, len)) { auto view = wrapper::kmer_view_from_cstr<kmer_t>(s, len, k, canonical); for (...) ... }
+// and pays one upload + one scan + one download per batch (default 32 Mbases) instead of per read.
+#ifndef BIOLIB_AMD_COMPAT_READ_POOL_HPP
+#define BIOLIB_AMD_COMPAT_READ_POOL_HPP
+
+#include <map>
+#include <utility>
+
+#include "biolib_amd_runtime.hpp"
+
+namespace biolib_amd {
+
+class read_pool
+{
+    public:
+        explicit read_pool(std::string const& path, uint64_t max_bases_per_batch = uint64_t(32) << 20) : max_bases(max_bases_per_batch)
+        {
+            check(bl_reader_open(path.c_str(), &reader), "bl_reader_open");
+            next_in_chain = head();
+            head() = this;
+        }
+        ~read_pool()
+        {
+            for (read_pool** p = &head(); *p; p = &(*p)->next_in_chain)
+                if (*p == this) { *p = next_in_chain; break; }
+            drop_batch();
+            bl_reader_close(reader);
+        }
+        read_pool(read_pool const&) = delete;
+
+        // next record of the file; the pointers stay valid until next() has returned the last record of the current batch and is called again
+        bool next(char const*& seq, std::size_t& len, char const** name = nullptr)
+        {
+            if (at == n_seqs and not refill()) return false;
+            seq = bases + offsets[at];
+            len = static_cast<std::size_t>(offsets[at + 1] - offsets[at]);
+            if (name) *name = bl_reader_last_name(reader, at);
+            ++at;
+            return true;
+        }
+        uint64_t batches_scanned() const noexcept {return scans;}
+
+        // used by kmer_view: if [p, p + len) lies in the current batch of a live pool of this thread, the k-mer values of that stretch
+        static uint64_t const* lookup(char const* p, std::size_t len, unsigned k, bool canonical)
+        {
+            for (read_pool* q = head(); q; q = q->next_in_chain)
+                if (q->bases and p >= q->bases and p + len <= q->bases + q->n_bases) return q->values(k, canonical) + (p - q->bases);
+            return nullptr;
+        }
+
+    private:
+        bl_reader* reader = nullptr;
+        bl_batch* batch = nullptr;
+        char const* bases = nullptr;
+        uint64_t const* offsets = nullptr;
+        uint64_t n_seqs = 0, n_bases = 0, at = 0, max_bases, scans = 0;
+        std::map<std::pair<unsigned, bool>, std::vector<uint64_t>> cache;  // (k, canonical) -> per-position k-mer values of the batch
+        read_pool* next_in_chain = nullptr;
+
+        static read_pool*& head() {thread_local read_pool* h = nullptr; return h;}
+
+        void drop_batch()
+        {
+            if (batch) bl_batch_destroy(batch);
+            batch = nullptr;
+            bases = nullptr;
+            cache.clear();
+            n_seqs = n_bases = at = 0;
+        }
+        bool refill()
+        {
+            drop_batch();
+            uint64_t ns = 0, nb = 0;
+            check(bl_reader_next_batch(context::get(), reader, max_bases, &batch, &ns, &nb), "bl_reader_next_batch");
+            if (not batch) return false;
+            check(bl_reader_last_batch(reader, &bases, &offsets, &n_seqs), "bl_reader_last_batch");
+            n_bases = nb;
+            return n_seqs != 0;
+        }
+        uint64_t const* values(unsigned k, bool canonical)
+        {
+            auto key = std::make_pair(k, canonical);
+            auto it = cache.find(key);
+            if (it == cache.end()) {  // the first view of this batch with these parameters: one scan for all its reads
+                device_array<uint64_t> d_values(n_bases);
+                bl_result res;
+                check(bl_scan_kmers(context::get(), batch, 0, 0, k, 0, (canonical ? (uint32_t)BL_FLAG_CANONICAL : 0u) | BL_FLAG_SYNC, d_values.d, nullptr, nullptr, &res),
+                      "bl_scan_kmers");
+                it = cache.emplace(key, d_values.to_host(n_bases)).first;
+                ++scans;
+            }
+            return it->second.data();
+        }
+};
+
+}  // namespace biolib_amd
+
+#endif

@@ -1,0 +1,60 @@
+// Throughput of the UNCHANGED per-read loop of the reference's driver (tests/test_kmer_view.cpp:30-42 in the reference tree)
+// through the drop-in kmer_view:  one view per read, iterate, use every k-mer.
+//   pooled    records come from a biolib_amd::read_pool: one upload + one scan per batch of reads, views index into it
+//   per_view  records come from a plain host buffer: every view uploads, scans and downloads by itself (first N reads only)
+// usage: bench_view_loop file.fq k canonical [per_view_reads]   -> one JSON line
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+#include <vector>
+
+#include "kmer_view.hpp"
+
+typedef uint64_t kmer_t;
+
+int main(int argc, char* argv[])
+{
+    if (argc < 4) { std::fprintf(stderr, "usage: %s file k canonical [per_view_reads]\n", argv[0]); return 2; }
+    const std::string path = argv[1];
+    const uint8_t k = (uint8_t)std::atoi(argv[2]);
+    const bool canonical = std::atoi(argv[3]) != 0;
+    const size_t per_view_reads = argc > 4 ? (size_t)std::atoll(argv[4]) : 2000;
+    using clock = std::chrono::steady_clock;
+    (void)biolib_amd::context::get();  // context creation is not part of either loop
+
+    uint64_t reads = 0, kmers = 0, x = 0, bases = 0;
+    std::vector<std::string> keep;  // the first reads again, for the per-view loop
+    const auto t0 = clock::now();
+    uint64_t scans = 0;
+    {
+        biolib_amd::read_pool pool(path);
+        char const* s; std::size_t l;
+        while (pool.next(s, l)) {
+            auto view = wrapper::kmer_view_from_cstr<kmer_t>(s, l, k, canonical);
+            for (auto itr = view.cbegin(); itr != view.cend(); ++itr) {
+                if ((*itr).value) { x ^= *((*itr).value); ++kmers; }
+            }
+            ++reads;
+            bases += l;
+            if (keep.size() < per_view_reads) keep.emplace_back(s, l);
+        }
+        scans = pool.batches_scanned();
+    }
+    const double pooled_s = std::chrono::duration<double>(clock::now() - t0).count();
+
+    uint64_t x2 = 0, kmers2 = 0;
+    const auto t1 = clock::now();
+    for (auto const& r : keep) {
+        auto view = wrapper::kmer_view_from_cstr<kmer_t>(r.c_str(), r.size(), k, canonical);
+        for (auto itr = view.cbegin(); itr != view.cend(); ++itr) {
+            if ((*itr).value) { x2 ^= *((*itr).value); ++kmers2; }
+        }
+    }
+    const double per_view_s = std::chrono::duration<double>(clock::now() - t1).count();
+    std::printf("{\"reads\": %llu, \"bases\": %llu, \"kmers\": %llu, \"xor_values\": %llu, \"batch_scans\": %llu, \"pooled_seconds\": %.4f, \"pooled_reads_per_s\": %.0f, "
+                "\"pooled_Mbp_per_s\": %.1f, \"per_view_reads\": %zu, \"per_view_kmers\": %llu, \"per_view_xor\": %llu, \"per_view_seconds\": %.4f, \"per_view_reads_per_s\": %.0f}\n",
+                (unsigned long long)reads, (unsigned long long)bases, (unsigned long long)kmers, (unsigned long long)x, (unsigned long long)scans, pooled_s, reads / pooled_s,
+                bases / pooled_s / 1e6, keep.size(), (unsigned long long)kmers2, (unsigned long long)x2, per_view_s, keep.size() / per_view_s);
+    return 0;
+}

@@ -15,6 +15,7 @@
 #include "super_kmer_view.hpp"
 #include "syncmer_sampler.hpp"
 #include "hash_sampler.hpp"
+#include "minimizer_sampler.hpp"
 
 extern "C" {
 #include "../../oracle/bl_oracle.h"
@@ -171,6 +172,30 @@ int main()
             for (auto it = smp.cbegin(); it != smp.cend(); ++it, ++i)
                 if (i < exp.size()) CHECK(*it == exp[i], "hash_sampler rate %.1f item %zu", rate, i);
             CHECK(i == exp.size(), "hash_sampler rate %.1f: %zu vs %zu", rate, i, exp.size());
+        }
+        for (int canon = 0; canon < 2; ++canon) {  // minimizer_sampler(w = 11) over kmer_view(k = 31), hash64: the literal "k=31, w=11" entry point
+            using view_t = wrapper::kmer_view<kmer_t, char_iterator>;
+            auto view = wrapper::kmer_view_from_cstr<kmer_t>(s.c_str(), s.size(), 31, canon);
+            sampler::minimizer_sampler<view_t::const_iterator, hash::hash64> smp(view.cbegin(), view.cend(), hash::hash64(), 42, 11);
+            CHECK(smp.get_w() == 11, "get_w");
+            // the idiom never reaches the k-mer that ends the sequence (Q1) = the sequence without its last base
+            std::vector<uint64_t> ov(s.size()), op(s.size()), oh(s.size());
+            const uint64_t cut[2] = {0, s.size() - 1};
+            size_t n = blo_minimizers(s.data(), cut, 1, 31, 11, 42, canon, 1, ov.data(), op.data(), oh.data(), ov.size());
+            size_t i = 0;
+            for (auto it = smp.cbegin(); it != smp.cend(); ++it, ++i) {
+                auto const& kc = *it;
+                if (i < n) CHECK(kc.value && *kc.value == ov[i] && kc.position == op[i], "minimizer_sampler canon %d item %zu", canon, i);
+            }
+            CHECK(i == n && n > 0, "minimizer_sampler canon %d: %zu vs %zu", canon, i, n);
+        }
+        {   // the host form of the sampler over optional items with a break in the middle: leftmost minimum, window restarts
+            struct idhash { typedef uint64_t hash_type; hash_type operator()(uint64_t v, uint64_t) const {return v;} };
+            std::vector<std::optional<uint64_t>> items = {5, 3, 3, 9, std::nullopt, 7, 1, 8, 1, 1};
+            sampler::minimizer_sampler<std::vector<std::optional<uint64_t>>::const_iterator, idhash> smp(items.cbegin(), items.cend(), idhash(), 0, 3);
+            std::vector<uint64_t> got;
+            for (auto it = smp.cbegin(); it != smp.cend(); ++it) got.push_back(**it);
+            CHECK((got == std::vector<uint64_t>{3, 3, 1, 1}), "host minimizer_sampler");  // windows 5 3 3 | 3 3 9 (2nd 3 leaves: new leftmost 3) | 7 1 8 | 1 8 1 | 8 1 1 (leftmost 1 moves)
         }
         {   // generic path of the sampler: any iterator + any extractor (here: even numbers)
             struct even_extractor { using value_type = int; std::size_t operator()(int v) const {return v % 2;} };

@@ -1,0 +1,91 @@
+// GPU test of the C++ multi-device driver (include/compat/multi_gpu.hpp) and of bl_count_allreduce (RCCL's C API): run with
+// every visible device — ONE on the test box, so what is exercised is the whole flow (threads, shards, ncclCommInitAll,
+// ncclAllReduce) at world size 1; N > 1 needs hardware this box does not have.
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "multi_gpu.hpp"
+
+extern "C" {
+#include "../../oracle/bl_oracle.h"
+}
+
+static int g_fail = 0;
+#define CHECK(cond, ...) do { if (!(cond)) { if (g_fail < 20) { std::printf("FAIL %s:%d: ", __FILE__, __LINE__); std::printf(__VA_ARGS__); std::printf("\n"); } ++g_fail; } } while (0)
+
+int main()
+{
+    biolib_amd::multi_gpu node;
+    std::printf("devices: %d\n", node.devices());
+    // shard_of: contiguous, covering, balanced
+    {
+        std::vector<uint64_t> offs = {0};
+        for (int i = 0; i < 1000; ++i) offs.push_back(offs.back() + 50 + (i * 37) % 400);
+        for (int n : {1, 2, 3, 8}) {
+            uint64_t expect_lo = 0;
+            for (int g = 0; g < n; ++g) {
+                auto [lo, hi] = biolib_amd::multi_gpu::shard_of(offs.data(), 1000, g, n);
+                CHECK(lo == expect_lo && hi >= lo, "shard %d of %d: [%llu, %llu)", g, n, (unsigned long long)lo, (unsigned long long)hi);
+                const double share = double(offs[hi] - offs[lo]) / double(offs.back());
+                CHECK(share > 0.8 / n && share < 1.2 / n, "shard %d of %d holds %.3f of the bases", g, n, share);
+                expect_lo = hi;
+            }
+            CHECK(expect_lo == 1000, "shards cover the reads");
+        }
+    }
+    // host reads: ragged lengths, the digest equals the oracle's over the whole input when one device takes everything,
+    // and count / XOR(value) / XOR(hash) equal it for any number of devices (positions are shard-relative)
+    {
+        const uint64_t n = 3000000;
+        std::string s(n, 'A');
+        blo_synth(9, 0, n, s.data());
+        for (uint64_t p = 1000; p < n; p += 7919) s[p] = 'N';
+        std::vector<uint64_t> offs = {0};
+        while (offs.back() < n) offs.push_back(std::min<uint64_t>(n, offs.back() + 100 + (offs.size() * 131) % 300));
+        const uint64_t n_seqs = offs.size() - 1;
+        uint64_t dg[4];
+        blo_minimizer_digest(s.data(), offs.data(), n_seqs, 31, 11, 42, 1, 1, dg);
+        auto got = node.minimizers(s.data(), offs.data(), n_seqs, 31, 11, 42, true);
+        CHECK(got.count == dg[0] && got.xor_value == dg[1] && got.xor_hash == dg[2], "minimizers over %d device(s): %llu vs %llu", node.devices(),
+              (unsigned long long)got.count, (unsigned long long)dg[0]);
+        if (node.devices() == 1) CHECK(got.xor_pos == dg[3], "position digest");
+        std::vector<uint64_t> pos(n);
+        const uint64_t cnt = blo_syncmers(s.data(), offs.data(), n_seqs, 31, 11, 0, 20, 1, 0, 1, pos.data(), pos.size());
+        auto sy = node.syncmers(s.data(), offs.data(), n_seqs, 31, 11, 0, 20, true);
+        CHECK(sy.count == cnt, "syncmers: %llu vs %llu", (unsigned long long)sy.count, (unsigned long long)cnt);
+    }
+    // synthetic shards on the devices (BASELINE C5's shape, small): per-device counts add up; device 0's shard = the oracle's seed
+    {
+        const uint64_t L = 10000, per = 2000 * L;
+        auto sy = node.syncmers_synth(42, per, L, 31, 11, 0, 20, true);
+        uint64_t sum = 0;
+        for (auto const& d : node.per_device()) sum += d.count;
+        CHECK(sy.count == sum && sum > 0, "all-reduced count %llu vs sum of shards %llu", (unsigned long long)sy.count, (unsigned long long)sum);
+        std::string s(per, 'A');
+        blo_synth(42, 0, per, s.data());
+        std::vector<uint64_t> offs;
+        for (uint64_t p = 0; p <= per; p += L) offs.push_back(p);
+        const uint64_t cnt = blo_syncmers(s.data(), offs.data(), offs.size() - 1, 31, 11, 0, 20, 1, 0, 1, nullptr, 0);
+        CHECK(node.per_device()[0].count == cnt, "device 0's shard: %llu vs oracle %llu", (unsigned long long)node.per_device()[0].count, (unsigned long long)cnt);
+        auto mm = node.minimizers_synth(42, 1500000, 150, 31, 11, 42, true);
+        CHECK(mm.count > 0 && mm.count == [&] { uint64_t t = 0; for (auto const& d : node.per_device()) t += d.count; return t; }(), "minimizer shards add up");
+    }
+    // the collective itself, several counters, wrap-around sums; bad arguments are refused
+    {
+        bl_ctx* c0 = nullptr;
+        biolib_amd::check(bl_ctx_create(0, &c0), "bl_ctx_create");
+        uint64_t counters[3] = {5, ~0ull, 1234567890123ull};
+        bl_ctx* one[1] = {c0};
+        CHECK(bl_count_allreduce(one, 1, counters, 3) == BL_OK, "allreduce: %s", bl_last_error());
+        CHECK(counters[0] == 5 && counters[1] == ~0ull && counters[2] == 1234567890123ull, "world 1: sums = inputs");
+        bl_ctx* twice[2] = {c0, c0};
+        uint64_t two[2] = {1, 2};
+        CHECK(bl_count_allreduce(twice, 2, two, 1) == BL_ERR_INVALID, "two ranks on one device must be refused");
+        CHECK(bl_count_allreduce(one, 0, counters, 3) == BL_ERR_INVALID && bl_count_allreduce(nullptr, 1, counters, 3) == BL_ERR_INVALID, "bad arguments");
+        bl_ctx_destroy(c0);
+    }
+    if (g_fail) { std::printf("test_multi_gpu: %d failures\n", g_fail); return 1; }
+    std::printf("test_multi_gpu: OK\n");
+    return 0;
+}

@@ -19,6 +19,63 @@ def test_cpp_compat_views():
     assert "test_compat_views: OK" in out.stdout
 
 
+@pytest.mark.gpu
+def test_cpp_compat_jaccard(tmp_path):
+    """the reference's Jaccard tool body (tests/test_jaccard.cpp:55-130) over external_memory_vector / ordered_unique_sampler /
+    jaccard from include/compat/, on two fixture files"""
+    exe = os.path.join(ROOT, "tests", "cpp", "_build", "test_compat_jaccard")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "cpp")])
+    ing = os.path.join(ROOT, "tests", "golden", "ingest")
+    out = subprocess.run([exe, os.path.join(ing, "many.fa"), os.path.join(ing, "many.fa.gz"), str(tmp_path)], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "Jaccard : " in out.stdout, out.stdout[-4000:] + out.stderr[-4000:]
+    assert " = 1\n" in out.stdout  # the same sequences, plain and gzip: every set equals itself
+    out = subprocess.run([exe, os.path.join(ing, "many.fa"), os.path.join(ing, "mixed.fa"), str(tmp_path)], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "test_compat_jaccard: OK" in out.stdout, out.stdout[-4000:] + out.stderr[-4000:]
+    assert not [f for f in os.listdir(tmp_path) if f.startswith("tmp.run")]  # the vectors removed their run files
+
+
+@pytest.mark.gpu
+def test_cpp_multi_gpu_driver():
+    """include/compat/multi_gpu.hpp + bl_count_allreduce (RCCL C API) with every visible device (one on the test box)"""
+    exe = os.path.join(ROOT, "tests", "cpp", "_build", "test_multi_gpu")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "cpp")])
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0 and "test_multi_gpu: OK" in out.stdout, out.stdout[-4000:] + out.stderr[-4000:]
+
+
+@pytest.mark.gpu
+def test_cpp_view_loop_pooled_vs_per_view(tmp_path):
+    """the reference driver's per-read loop through a read_pool: same k-mers as view-by-view, a handful of batch scans
+    instead of one GPU round trip per read"""
+    import json
+
+    import numpy as np
+
+    import oracle_lib as O
+
+    exe = os.path.join(ROOT, "tests", "cpp", "_build", "bench_view_loop")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "cpp")])
+    n_reads, L = 20_000, 150
+    seq = O.synth(3, n_reads * L)
+    seq[::1009] = ord("N")
+    path = tmp_path / "reads.fq"
+    with open(path, "wb") as f:
+        for i in range(n_reads):
+            f.write(b"@r%d\n" % i + seq[i * L:(i + 1) * L].tobytes() + b"\n+\n" + b"I" * L + b"\n")
+    out = subprocess.run([exe, str(path), "21", "1", "500"], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    d = json.loads(out.stdout.strip().splitlines()[-1])
+    dg = O.kmer_digest(seq, O.fixed_offsets(len(seq), L), 21, True, 0, drop_last=True)  # the idiom skips each read's last k-mer
+    assert (d["reads"], d["kmers"], d["xor_values"]) == (n_reads, dg["count"], dg["xor_value"])
+    d500 = O.kmer_digest(seq[:500 * L], O.fixed_offsets(500 * L, L), 21, True, 0, drop_last=True)
+    assert (d["per_view_kmers"], d["per_view_xor"]) == (d500["count"], d500["xor_value"])
+    assert d["batch_scans"] <= 2 and d["pooled_reads_per_s"] > 5 * d["per_view_reads_per_s"]
+
+
 def test_cpp_compat_headers_compile():
     """CPU-only: the drop-in headers and their test compile and link against the C ABI."""
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "biolib_amd", "csrc")])
