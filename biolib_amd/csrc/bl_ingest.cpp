@@ -425,11 +425,10 @@ private:
         while (in_.more()) {
             const unsigned char* p = in_.here();
             const size_t n = in_.left();
-            const void* a = std::memchr(p, '>', n);
-            const void* b = std::memchr(p, '@', a ? (size_t)(static_cast<const unsigned char*>(a) - p) : n);
-            const void* hit = b ? b : a;
-            if (hit) {
-                in_.skip((size_t)(static_cast<const unsigned char*>(hit) - p) + 1);
+            size_t i = 0;
+            while (i < n && p[i] != '>' && p[i] != '@') ++i;  // normally the very next byte: nothing stands between records
+            if (i < n) {
+                in_.skip(i + 1);
                 return true;
             }
             in_.skip(n);
@@ -497,20 +496,45 @@ public:
         for (;;) {
             if (!buf.empty() && !fmt_) fmt_ = buf[0] == '@' ? 'q' : 'a';
             bool decided = false;
-            while (scanned < buf.size()) {
+            if (fmt_ == 'q') {
+                // FASTQ: only the line COUNT matters (a record is 4 lines): count the newlines of what is new in one pass
+                // (the compiler vectorises the loop), then walk back from the last one to the last multiple of four
+                const size_t upto = buf.size() < limit ? buf.size() : limit;
+                if (scanned < upto) {
+                    const char* q = buf.data();
+                    uint64_t add = 0;
+                    for (size_t i = scanned; i < upto; ++i) add += q[i] == '\n';
+                    lines += add;
+                    scanned = upto;
+                    size_t back = (size_t)(lines % 4), at = upto;  // drop `back` newlines from the end, then cut after the one before them
+                    bool found = lines >= 4;
+                    for (size_t drop = 0; found && drop <= back; ++drop) {
+                        const void* nl = at ? memrchr(q, '\n', at) : nullptr;
+                        if (!nl) { found = false; break; }
+                        at = (size_t)(static_cast<const char*>(nl) - q);
+                        if (drop == back) { best = at + 1; have_best = true; }
+                    }
+                }
+                if (buf.size() > limit && !have_best) {  // a single record longer than the limit: the first boundary beyond it
+                    while (scanned < buf.size()) {
+                        const void* nl = std::memchr(buf.data() + scanned, '\n', buf.size() - scanned);
+                        if (!nl) { scanned = buf.size(); break; }
+                        scanned = (size_t)(static_cast<const char*>(nl) - buf.data()) + 1;
+                        if (++lines % 4 == 0) { cut = scanned; decided = true; break; }
+                    }
+                } else if (buf.size() > limit) {
+                    scanned = limit + 1;  // everything up to the limit has been counted: `best` stands
+                }
+            }
+            while (fmt_ != 'q' && scanned < buf.size()) {
                 const void* nl = std::memchr(buf.data() + scanned, '\n', buf.size() - scanned);
                 if (!nl) {
                     scanned = buf.size();
                     break;
                 }
                 const size_t p = (size_t)(static_cast<const char*>(nl) - buf.data()) + 1;  // first byte of the next line
-                bool boundary;
-                if (fmt_ == 'q') {
-                    boundary = (++lines % 4 == 0);
-                } else {
-                    if (p >= buf.size()) break;  // the byte that decides is not here yet: this newline is looked at again
-                    boundary = buf[p] == '>';
-                }
+                if (p >= buf.size()) break;  // the byte that decides is not here yet: this newline is looked at again
+                const bool boundary = buf[p] == '>';
                 scanned = p;
                 if (!boundary) continue;
                 if (p <= limit) {

@@ -5,6 +5,11 @@
 #include <cstdint>
 #include <cstring>
 #include <string>
+#include <vector>
+#include <optional>
+#include <cassert>
+#include <iterator>
+#include "kmer_view.hpp"
 
 extern "C" {
 #include "kseq.h"
@@ -37,6 +42,28 @@ long ref_kseq_read_all(const char* path, char* bases, uint64_t cap_bases, uint64
     kseq_destroy(seq);
     gzclose(fp);
     return n;
+}
+
+// The reference driver's own loop (tests/test_kmer_view.cpp:30-42): its reader, one kmer_view per record, every k-mer used.
+// Timed by tests/perf/view_loop_bench.py as the CPU figure beside the drop-in's pooled loop.  Returns the XOR of the values.
+uint64_t ref_read_loop_kmers_xor(const char* path, uint8_t k, int canonical, uint64_t* n_reads, uint64_t* n_kmers)
+{
+    gzFile fp = gzopen(path, "r");
+    if (!fp) return 0;
+    kseq_t* seq = kseq_init(fp);
+    uint64_t x = 0, reads = 0, kmers = 0;
+    while (kseq_read(seq) >= 0) {
+        auto view = wrapper::kmer_view_from_cstr<uint64_t>(seq->seq.s, seq->seq.l, k, canonical != 0);
+        for (auto itr = view.cbegin(); itr != view.cend(); ++itr) {
+            if ((*itr).value) { x ^= *((*itr).value); ++kmers; }
+        }
+        ++reads;
+    }
+    kseq_destroy(seq);
+    gzclose(fp);
+    if (n_reads) *n_reads = reads;
+    if (n_kmers) *n_kmers = kmers;
+    return x;
 }
 
 }  // extern "C"

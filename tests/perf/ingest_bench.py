@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
-"""Throughput of the FASTA/FASTQ ingest (host parse -> device batch) and of the scan on the ingested batches.
-Writes a synthetic FASTQ of 150-bp reads (plain and gzip), then times  reader -> batches -> minimizer scan."""
-import gzip, os, sys, tempfile, time
+"""Throughput of FASTA/FASTQ ingest into device batches, end to end with a minimizer scan behind it, for a synthetic FASTQ of
+150-bp reads as plain text, gzip and BGZF:
+  host records    bl_reader_next_batch: host record parser -> upload
+  device parser   bl_reader_next_batch_device: decompressed text spans -> H2D -> parse on the GPU (BGZF: parallel inflate)
+Writes one JSON line."""
+import gzip, json, os, struct, sys, tempfile, time, zlib
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -9,33 +12,44 @@ import numpy as np
 import biolib_amd as B
 import oracle_lib as O
 
-n_reads = int(sys.argv[1]) if len(sys.argv) > 1 else 2_000_000
+
+def bgzf(data, block=65280):
+    out = bytearray()
+    for a in list(range(0, len(data), block)) + [None]:
+        chunk = b"" if a is None else data[a:a + block]
+        z = zlib.compressobj(1, zlib.DEFLATED, -15)
+        body = z.compress(chunk) + z.flush()
+        out += b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, 12 + 6 + len(body) + 8 - 1)
+        out += body + struct.pack("<II", zlib.crc32(chunk) & 0xFFFFFFFF, len(chunk))
+    return bytes(out)
+
+
+n_reads = int(sys.argv[1]) if len(sys.argv) > 1 else 4_000_000
+threads = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 seq = O.synth(42, n_reads * 150).reshape(n_reads, 150)
+res = {"workload": f"{n_reads} reads x 150 bp FASTQ ({n_reads * 150 / 1e6:.0f} Mbp)", "inflate_threads": threads or "one per core (max 16)", "Gbp_per_s": {}}
 with tempfile.TemporaryDirectory() as d:
-    path = os.path.join(d, "reads.fq")
-    with open(path, "wb") as f:
-        qual = b"I" * 150
-        for i in range(n_reads):
-            f.write(b"@r%d\n" % i + seq[i].tobytes() + b"\n+\n" + qual + b"\n")
-    gz = path + ".gz"
-    with open(path, "rb") as fi, gzip.open(gz, "wb", compresslevel=1) as fo:
-        fo.write(fi.read())
+    text = b"".join(b"@r%d\n" % i + seq[i].tobytes() + b"\n+\n" + b"I" * 150 + b"\n" for i in range(n_reads))
+    files = {"plain": os.path.join(d, "r.fq"), "gzip": os.path.join(d, "r.fq.gz"), "bgzf": os.path.join(d, "r.bgzf.gz")}
+    open(files["plain"], "wb").write(text)
+    open(files["gzip"], "wb").write(gzip.compress(text, 1))
+    open(files["bgzf"], "wb").write(bgzf(text))
+    res["file_MB"] = {k: round(os.path.getsize(v) / 1e6) for k, v in files.items()}
     ctx = B.Context(0)
-    for p in (path, gz):
-        t0 = time.perf_counter(); nb = 0; cnt = 0
-        for batch, names, offs in B.Reader(p).batches(ctx, 256_000_000):
-            nb += batch.n_bases
-            cnt += batch.minimizers_raw(31, 11, 42, B.FLAG_CANONICAL | B.FLAG_SYNC).count
-        dt = time.perf_counter() - t0
-        print(f"{os.path.basename(p)}: {nb/1e6:.0f} Mbp, file {os.path.getsize(p)/1e6:.0f} MB, {nb/dt/1e6:.1f} Mbp/s end to end (host parse+upload+scan), {cnt} minimizers")
-    # device-side parser: the raw text goes to the GPU and is parsed there (bl_batch_from_text)
-    raw = np.fromfile(path, dtype=np.uint8)
-    for rep in range(3):
-        t0 = time.perf_counter()
-        batch = ctx.from_text(raw)
-        t1 = time.perf_counter()
-        cnt = batch.minimizers_raw(31, 11, 42, B.FLAG_CANONICAL | B.FLAG_SYNC).count
-        t2 = time.perf_counter()
-        print(f"device parser rep {rep}: {batch.n_bases/1e6:.0f} Mbp from {raw.size/1e6:.0f} MB of FASTQ text: parse+upload {batch.n_bases/(t1-t0)/1e9:.2f} Gbp/s "
-              f"({raw.size/(t1-t0)/1e9:.2f} GB/s of text), scan {batch.n_bases/(t2-t1)/1e9:.1f} Gbp/s, {cnt} minimizers")
-        batch.close()
+    want = None
+    for form, p in files.items():
+        for mode in ("host_records", "device_parser"):
+            t0 = time.perf_counter(); nb = 0; cnt = 0
+            r = B.Reader(p, threads=threads)
+            it = (b for b, _, _ in r.batches(ctx, 256_000_000)) if mode == "host_records" else r.device_batches(ctx, 512 << 20)
+            for batch in it:
+                nb += batch.n_bases
+                cnt += batch.minimizers_raw(31, 11, 42, B.FLAG_CANONICAL | B.FLAG_SYNC).count
+                batch.close()
+            dt = time.perf_counter() - t0
+            assert nb == n_reads * 150
+            want = cnt if want is None else want
+            assert cnt == want
+            res["Gbp_per_s"][f"{form}/{mode}"] = round(nb / dt / 1e9, 3)
+    res["minimizers"] = want
+print(json.dumps(res))
