@@ -105,6 +105,8 @@ struct bl_ctx {
     double kernel_ms = 0.0;
     uint64_t kernel_launches = 0;
     std::vector<bl_batch*> batches;  // live batches: destroyed with the context if the caller did not
+    void* scratch[4] = {nullptr, nullptr, nullptr, nullptr};  // grow-only device scratch of the non-scan entry points (bl_ctx_scratch)
+    size_t scratch_bytes[4] = {0, 0, 0, 0};
 
     unsigned long long* shards() const { return cur->shards(); }
     unsigned long long* result() const { return cur->result(); }
@@ -337,6 +339,29 @@ hipStream_t bl_ctx_stream(bl_ctx* c)
 int bl_batch_adopt_device(bl_ctx* ctx, void* d_bases, uint64_t n_bases, uint64_t* d_offsets, uint64_t n_seqs, bl_batch** out);
 int bl_ctx_device(bl_ctx* c) { return c->device; }
 
+// Device scratch that lives with the context (slot 0..3), grown on demand and never shrunk: the set operations and the
+// bucketed counter need gigabytes of temporary space per call, and hipMalloc / hipFree of that size costs more than their
+// kernels.  The caller has synchronised its previous use (these entry points are synchronous).  nullptr on failure.
+void* bl_ctx_scratch(bl_ctx* c, int slot, size_t bytes)
+{
+    if (!c || slot < 0 || slot >= 4) return nullptr;
+    if (bytes <= c->scratch_bytes[slot]) return c->scratch[slot];
+    (void)hipSetDevice(c->device);
+    if (c->scratch[slot]) {
+        (void)hipDeviceSynchronize();
+        (void)hipFree(c->scratch[slot]);
+        c->scratch[slot] = nullptr;
+        c->scratch_bytes[slot] = 0;
+    }
+    const size_t want = bytes + bytes / 8;
+    if (hipMalloc(&c->scratch[slot], want) != hipSuccess) {
+        c->scratch[slot] = nullptr;
+        return nullptr;
+    }
+    c->scratch_bytes[slot] = want;
+    return c->scratch[slot];
+}
+
 extern "C" {
 
 const char* bl_last_error(void) { return g_err.c_str(); }
@@ -424,6 +449,8 @@ int bl_ctx_destroy(bl_ctx* c)
         if (l.ev_stop) (void)hipEventDestroy(l.ev_stop);
         if (l.own) (void)hipStreamDestroy(l.own);
     }
+    for (void* p : c->scratch)
+        if (p) (void)hipFree(p);
     if (c->pinned) (void)hipHostFree(c->pinned);
     for (hipEvent_t ev : c->slot_ev)
         if (ev) (void)hipEventDestroy(ev);

@@ -6,25 +6,33 @@
 // value, hence the same owner, so the owner can count k-mers exactly with no further exchange:
 //
 //   rec[0]  bases 0..31, first base in the most significant pair (kmer_view.hpp:194 packing)
-//   rec[1]  bases 32..59 in bits 63..8 (same order), bits 7..0 = size (number of k-mers, 1 .. k-m+1)
+//   rec[1]  bases 32..58 in bits 63..10 (same order), bits 9..5 = mm_pos (offset of the minimizer in the first k-mer,
+//           super_kmer_view.hpp:132), bits 4..0 = size - 1 (number of k-mers, 1 .. k-m+1)
 //
-// so size + k - 1 <= 60 bases (k = 31, m = 15: at most 47).  8 B/k-mer become ~1.8 B/base on the links.
+// so size + k - 1 <= 59 bases (k = 31, m = 15: at most 47).  8 B/k-mer become ~1.8 B/base on the links.  mm_pos makes a record
+// self-describing: its owner can find the minimizer again (one m-mer extraction + one hash) and bucket the record by it,
+// which is what bl_count_super_kmers does to count k-mers in LDS-sized buckets instead of sorting them all.
 #include <hip/hip_runtime.h>
 
 #include <cstring>
 #include <rocprim/device/device_scan.hpp>
+#include <rocprim/device/device_radix_sort.hpp>
+
+#include <vector>
 
 #include "../../include/biolib_amd.h"
 #include "bl_partition.hpp"
+#include "bl_scan_core.hpp"
 
 extern int bl_set_error(int code, const char* msg);  // bl_capi.hip
 extern hipStream_t bl_ctx_stream(bl_ctx* ctx);
 extern int bl_ctx_device(bl_ctx* ctx);
+extern void* bl_ctx_scratch(bl_ctx* ctx, int slot, size_t bytes);  // bl_capi.hip: device scratch that lives with the context
 
 namespace {
 
 constexpr int MAX_PARTS = 64;
-constexpr int MAX_BASES = 60;
+constexpr int MAX_BASES = 59;
 
 #define SK_HIP(call)                                                                                                             \
     do {                                                                                                                         \
@@ -41,7 +49,7 @@ __device__ __forceinline__ unsigned base_at(unsigned long long hi, unsigned long
 
 __global__ __launch_bounds__(256) void pack_kernel(const unsigned char* __restrict__ bases, unsigned long long n_bases,
                                                    const unsigned long long* __restrict__ first_pos, const unsigned char* __restrict__ sizes,
-                                                   unsigned long long n, int k, ulonglong2* __restrict__ out)
+                                                   const unsigned char* __restrict__ mm_pos, unsigned long long n, int k, ulonglong2* __restrict__ out)
 {
     const unsigned long long g = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= n) return;
@@ -55,7 +63,8 @@ __global__ __launch_bounds__(256) void pack_kernel(const unsigned char* __restri
     if (n_hi < 32) hi <<= 2 * (32 - n_hi);
     for (int i = 32; i < nb; ++i) lo = (lo << 2) | code_of(bases[p + i]);
     if (nb > 32) lo <<= 64 - 2 * (nb - 32);
-    out[g] = make_ulonglong2(hi, (lo & ~0xffULL) | (unsigned long long)size);
+    const unsigned long long mp = mm_pos ? (unsigned long long)(mm_pos[g] & 31u) : 0ULL;
+    out[g] = make_ulonglong2(hi, (lo & ~0x3ffULL) | (mp << 5) | (unsigned long long)((size - 1) & 31));
 }
 
 struct HashArrayOwner {
@@ -66,7 +75,7 @@ struct HashArrayOwner {
 __global__ void sizes_kernel(const ulonglong2* recs, unsigned long long n, unsigned long long* sizes)
 {
     const unsigned long long g = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g < n) sizes[g] = recs[g].y & 0xffULL;
+    if (g < n) sizes[g] = (recs[g].y & 31ULL) + 1;
 }
 
 __global__ __launch_bounds__(256) void expand_kernel(const ulonglong2* __restrict__ recs, const unsigned long long* __restrict__ offsets,
@@ -75,7 +84,7 @@ __global__ __launch_bounds__(256) void expand_kernel(const ulonglong2* __restric
     const unsigned long long g = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= n) return;
     const unsigned long long hi = recs[g].x, lo = recs[g].y;
-    const int size = (int)(lo & 0xffULL);
+    const int size = (int)(lo & 31ULL) + 1;
     const unsigned long long mask = k == 32 ? ~0ULL : ((1ULL << (2 * k)) - 1);
     const int shift = 2 * (k - 1);
     unsigned long long fwd = 0, rc = 0;
@@ -97,16 +106,16 @@ __global__ __launch_bounds__(256) void expand_kernel(const ulonglong2* __restric
 
 extern "C" {
 
-int bl_pack_super_kmers(bl_ctx* ctx, const bl_batch* batch, const uint64_t* d_first_pos, const uint8_t* d_sizes, uint64_t n_groups, uint32_t k,
-                        uint32_t m, uint64_t* d_records)
+int bl_pack_super_kmers(bl_ctx* ctx, const bl_batch* batch, const uint64_t* d_first_pos, const uint8_t* d_sizes, const uint8_t* d_mm_pos, uint64_t n_groups,
+                        uint32_t k, uint32_t m, uint64_t* d_records)
 {
     if (!ctx || !batch || (n_groups && (!d_first_pos || !d_sizes || !d_records))) return bl_set_error(BL_ERR_INVALID, "NULL argument");
-    if (k < 1 || k > 32 || m < 1 || m > k || 2 * k - m > MAX_BASES) return bl_set_error(BL_ERR_INVALID, "need 1 <= m <= k <= 32 and 2k - m <= 60 (bases per packed record)");
+    if (k < 1 || k > 32 || m < 1 || m > k || 2 * k - m > MAX_BASES) return bl_set_error(BL_ERR_INVALID, "need 1 <= m <= k <= 32 and 2k - m <= 59 (bases per packed record)");
     if (n_groups == 0) return BL_OK;
     SK_HIP(hipSetDevice(bl_ctx_device(ctx)));
     hipStream_t s = bl_ctx_stream(ctx);
     hipLaunchKernelGGL(pack_kernel, dim3((unsigned)((n_groups + 255) / 256)), dim3(256), 0, s, static_cast<const unsigned char*>(bl_batch_device_bases(batch)),
-                       (unsigned long long)bl_batch_n_bases(batch), reinterpret_cast<const unsigned long long*>(d_first_pos), d_sizes,
+                       (unsigned long long)bl_batch_n_bases(batch), reinterpret_cast<const unsigned long long*>(d_first_pos), d_sizes, d_mm_pos,
                        (unsigned long long)n_groups, (int)k, reinterpret_cast<ulonglong2*>(d_records));
     SK_HIP(hipGetLastError());
     return BL_OK;

@@ -222,6 +222,32 @@ class Context:
             check(self._lib.bl_merge_runs_u64(self._h, arr, len(paths), C.c_void_p(out.data_ptr()), total.value, C.byref(total)))
         return out[: total.value]
 
+    def count_super_kmers(self, records, k, m, seed=0, canonical=True, n=None, out=None):
+        """(distinct k-mers, multiplicities) of the packed super-k-mer records, in no particular order: buckets by minimizer
+        hash counted in LDS hash tables (bl_count_super_kmers), no global sort"""
+        import torch
+
+        n = records.shape[0] if n is None else int(n)
+        self._inputs_ready()
+        flags = FLAG_CANONICAL if canonical else 0
+        need = C.c_uint64()
+        cap = int(n * (k - m + 1) * 0.62) + 4096  # groups average ~ (w+1)/2 k-mers; retried with the exact need if short
+        while True:
+            if out is not None:  # caller-owned (keys int64, counts int32) tensors: no allocation on this path
+                keys, cnts = out
+                cap = min(keys.numel(), cnts.numel())
+                out = None
+            else:
+                keys = self.empty_u64(cap)
+                cnts = torch.empty(max(cap, 1), dtype=torch.int32, device=self.torch_device)
+            rc = self._lib.bl_count_super_kmers(self._h, C.c_void_p(records.data_ptr()), n, int(k), int(m), int(seed), flags, C.c_void_p(keys.data_ptr()),
+                                                C.c_void_p(cnts.data_ptr()), cap, C.byref(need))
+            if rc == capi.BL_ERR_CAPACITY:
+                cap = int(need.value) + 64
+                continue
+            check(rc)
+            return keys[: need.value], cnts[: need.value]
+
     def probe_hbm(self, n_bytes=8 << 30, iters=5):
         """(read GB/s, copy GB/s) sustained by this device: read-only stream kernel and DtoD copy"""
         r, c = C.c_double(), C.c_double()
@@ -400,15 +426,16 @@ class Batch:
         c = self.ctx
 
         def run(cap):
-            fp, hs, sz = c.empty_u64(cap), c.empty_u64(cap), c.empty_u8(cap)
+            fp, hs, sz, mp = c.empty_u64(cap), c.empty_u64(cap), c.empty_u8(cap), c.empty_u8(cap)
             r = Result()
             try:
-                self.super_kmers_raw(k, m, seed, _flags(canonical, False, True), first, n, None, fp, None, sz, hs, cap, r)
+                self.super_kmers_raw(k, m, seed, _flags(canonical, False, True), first, n, None, fp, mp, sz, hs, cap, r)
             finally:
                 self._last_count = r.count
             cnt = int(r.count)
             recs = torch.empty((max(cnt, 1), 2), dtype=torch.int64, device=c.torch_device)
-            check(self._lib.bl_pack_super_kmers(c._h, self._h, C.c_void_p(fp.data_ptr()), C.c_void_p(sz.data_ptr()), cnt, int(k), int(m), C.c_void_p(recs.data_ptr())))
+            check(self._lib.bl_pack_super_kmers(c._h, self._h, C.c_void_p(fp.data_ptr()), C.c_void_p(sz.data_ptr()), C.c_void_p(mp.data_ptr()), cnt, int(k), int(m),
+                                                C.c_void_p(recs.data_ptr())))
             c.sync()
             return recs[:cnt], hs[:cnt]
 

@@ -111,17 +111,18 @@ def count_kmers_via_super_kmers(ctx, batch, k, m, seed=0, canonical=True, group=
       scan  -> super-k-mers of this rank's reads (bl_scan_super_kmers)
       pack  -> 16-byte sequence records (bl_pack_super_kmers)
       route -> bucket by minimizer hash % world (bl_partition_records), one all-to-all over RCCL / xGMI
-      count -> expand the received records to k-mers (bl_expand_super_kmers), sort, run-length count
+      count -> bucket the received records by minimizer hash and count every bucket's k-mers in an LDS hash table
+               (bl_count_super_kmers; the expand + sort + run-length path remains as its fallback for oversized buckets)
 
     All occurrences of a canonical k-mer share their minimizer value, so they meet on one rank and its local count is
     the global one.  ~1.8 bytes per input base cross the links instead of 8 bytes per k-mer.  Works without a process
     group (single GPU); force_exchange runs the all-to-all even at world size 1 (tests).  Returns (distinct k-mers,
-    multiplicities) owned by this rank, as device tensors."""
+    multiplicities) owned by this rank, as device tensors, in no particular order."""
     import torch.distributed as dist
 
     recs, hashes = batch.super_kmer_records(k, m, seed=seed, canonical=canonical)
     if dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or force_exchange):
         bucketed, counts = ctx.partition_records(hashes, recs, dist.get_world_size(group))
         recs = exchange(bucketed, counts, group)
-    kmers = ctx.expand_super_kmers(recs, k, canonical=canonical)
-    return ctx.sort_count(kmers)
+    # minimizer buckets counted in LDS hash tables (bl_count_super_kmers): no global sort; the pairs come in no particular order
+    return ctx.count_super_kmers(recs, k, m, seed=seed, canonical=canonical)

@@ -171,7 +171,15 @@ def test_exchange_and_count_single_rank_rccl(ctx):
             dist.destroy_process_group()
 
 
-def _np_pack(seq, fp, sz, k):
+def _sorted_counts(u, c):
+    """(keys ascending, multiplicities) from the unordered output of the bucketed counter"""
+    u = u.cpu().numpy().view(np.uint64)
+    c = c.cpu().numpy().astype(np.int64)
+    order = np.argsort(u, kind="stable")
+    return u[order], c[order]
+
+
+def _np_pack(seq, fp, sz, k, mp=None):
     """numpy restatement of the 16-byte packed super-k-mer record"""
     code = np.zeros(256, np.uint64)
     for ch, c in zip(b"ACGTUacgtu", (0, 1, 2, 3, 3, 0, 1, 2, 3, 3)):
@@ -183,14 +191,14 @@ def _np_pack(seq, fp, sz, k):
         hi = 0
         for i in range(min(nb, 32)):
             hi |= int(c[i]) << (62 - 2 * i)
-        lo = s
+        lo = (s - 1) | ((int(mp[g]) if mp is not None else 0) << 5)
         for i in range(32, nb):
             lo |= int(c[i]) << (62 - 2 * (i - 32))
         out[g] = (hi, lo)
     return out
 
 
-@pytest.mark.parametrize("k,m,canon", [(31, 15, True), (31, 15, False), (32, 4, True), (21, 11, True), (5, 5, True), (16, 1, False)])
+@pytest.mark.parametrize("k,m,canon", [(31, 15, True), (31, 15, False), (32, 5, True), (21, 11, True), (5, 5, True), (16, 1, False)])
 def test_super_kmer_records_pack_and_expand(ctx, k, m, canon):
     n, L = 120_000, 1500
     seq = O.synth(31, n)
@@ -200,7 +208,7 @@ def test_super_kmer_records_pack_and_expand(ctx, k, m, canon):
     mn, fp, mp, sz, hs = O.super_kmers(seq, offs, k, m, 9, canon)
     recs, hashes = b.super_kmer_records(k, m, seed=9, canonical=canon)
     assert recs.shape[0] == len(mn) and np.array_equal(hashes.cpu().numpy().view(np.uint64), hs)
-    assert np.array_equal(recs.cpu().numpy().view(np.uint64), _np_pack(seq, fp, sz, k))
+    assert np.array_equal(recs.cpu().numpy().view(np.uint64), _np_pack(seq, fp, sz, k, mp))
     # expansion = the k-mers of each group, group after group = the oracle's units at first_pos .. first_pos+size-1
     vals, ok = O.units(seq, offs, k, canon)
     idx = np.concatenate([np.arange(p, p + s) for p, s in zip(fp.tolist(), sz.tolist())]) if len(fp) else np.zeros(0, np.int64)
@@ -214,7 +222,7 @@ def test_super_kmer_records_pack_and_expand(ctx, k, m, canon):
         owner = hs % np.uint64(parts)
         assert counts == np.bincount(owner.astype(np.int64), minlength=parts).tolist()
         edges = np.concatenate([[0], np.cumsum(counts)])
-        exp = _np_pack(seq, fp, sz, k)
+        exp = _np_pack(seq, fp, sz, k, mp)
         for bkt in range(parts):
             a = got_r[edges[bkt]:edges[bkt + 1]]
             e = exp[owner == bkt]
@@ -226,7 +234,7 @@ def test_super_kmer_record_limits(ctx):
 
     b = ctx.synth(1, 10_000, 100)
     with pytest.raises(B.BiolibError):
-        b.super_kmer_records(32, 3)  # 2k - m = 61 bases do not fit a record
+        b.super_kmer_records(32, 4)  # 2k - m = 60 bases do not fit a record (59 do)
 
 
 def test_count_kmers_via_super_kmers_single_gpu(ctx):
@@ -242,8 +250,8 @@ def test_count_kmers_via_super_kmers_single_gpu(ctx):
     seq = O.synth(77, n)
     vals, ok = O.units(seq, O.fixed_offsets(n, L), 15, True)          # 4^15/2 canonical 15-mers over 2.7 M: repeats exist
     eu, ec = np.unique(vals[ok != 0], return_counts=True)
-    u, c = count_kmers_via_super_kmers(ctx, b, 15, 9, seed=42, canonical=True)
-    assert np.array_equal(u.cpu().numpy().view(np.uint64), eu) and np.array_equal(c.cpu().numpy().astype(np.int64), ec) and ec.max() > 1
+    u, c = _sorted_counts(*count_kmers_via_super_kmers(ctx, b, 15, 9, seed=42, canonical=True))
+    assert np.array_equal(u, eu) and np.array_equal(c, ec) and ec.max() > 1
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29534")
     created = not dist.is_initialized()
@@ -255,7 +263,7 @@ def test_count_kmers_via_super_kmers_single_gpu(ctx):
         inbox = exchange(bucketed, counts)
         assert inbox.shape == recs.shape
         u2, c2 = ctx.sort_count(ctx.expand_super_kmers(inbox, 15, canonical=True))
-        assert torch.equal(u2, u) and torch.equal(c2, c)
+        assert np.array_equal(u2.cpu().numpy().view(np.uint64), u) and np.array_equal(c2.cpu().numpy().astype(np.int64), c)
     finally:
         if created:
             dist.destroy_process_group()
@@ -282,12 +290,52 @@ def test_exchange_large_payload_rccl_own_streams():
         ref = B.Context(0)
         u1, c1 = count_kmers_via_super_kmers(own, own.synth(9, n, L), 31, 15, seed=42, canonical=True, group=dist.group.WORLD, force_exchange=True)
         u2, c2 = count_kmers_via_super_kmers(ref, ref.synth(9, n, L), 31, 15, seed=42, canonical=True)
-        assert u1.numel() > 40_000_000 and torch.equal(u1, u2) and torch.equal(c1, c2)
+        a, b2 = _sorted_counts(u1, c1), _sorted_counts(u2, c2)
+        assert u1.numel() > 40_000_000 and np.array_equal(a[0], b2[0]) and np.array_equal(a[1], b2[1])
         own.close()
         ref.close()
     finally:
         if created:
             dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("k,m,canon,kind", [(31, 15, True, "random"), (21, 11, False, "random"), (31, 15, True, "repeats"), (32, 9, True, "random"), (15, 9, True, "breaks")])
+def test_count_super_kmers_bucketed(ctx, k, m, canon, kind):
+    """bl_count_super_kmers (minimizer buckets counted in LDS hash tables, no global sort) against np.unique of the oracle's k-mers:
+    random reads; low-complexity reads whose few minimizers make buckets far too big for a table (the sort fallback counts
+    them); reads with breaks; capacity too small -> the exact need comes back"""
+    import biolib_amd as B
+
+    n, L = 1_200_000, 150
+    seq = O.synth(61 + k, n)
+    if kind == "repeats":  # a third of the reads are poly-A / dinucleotide repeats: thousands of copies of very few k-mers
+        r = seq.reshape(-1, L)
+        r[::3] = np.frombuffer(b"A" * L, np.uint8)
+        r[1::9] = np.frombuffer((b"AC" * L)[:L], np.uint8)
+    if kind == "breaks":
+        seq[np.random.default_rng(k).integers(0, n, n // 500)] = ord("N")
+    offs = O.fixed_offsets(n, L)
+    b = ctx.upload(seq, offs)
+    recs, _ = b.super_kmer_records(k, m, seed=7, canonical=canon)
+    u, c = _sorted_counts(*ctx.count_super_kmers(recs, k, m, seed=7, canonical=canon))
+    vals, ok = O.units(seq, offs, k, canon)
+    eu, ec = np.unique(vals[ok != 0], return_counts=True)
+    assert np.array_equal(u, eu) and np.array_equal(c, ec)
+    if kind == "repeats":
+        assert ec.max() > 10_000
+    # too small an output: the need is reported, nothing is written past the end
+    import ctypes as C
+
+    from biolib_amd import capi
+
+    need = C.c_uint64()
+    small = ctx.empty_u64(100)
+    import torch
+
+    cs = torch.empty(100, dtype=torch.int32, device="cuda")
+    rc = capi.lib().bl_count_super_kmers(ctx._h, C.c_void_p(recs.data_ptr()), recs.shape[0], k, m, 7, B.FLAG_CANONICAL if canon else 0, C.c_void_p(small.data_ptr()),
+                                         C.c_void_p(cs.data_ptr()), 100, C.byref(need))
+    assert rc == capi.BL_ERR_CAPACITY and need.value == len(eu)
 
 
 TWO_RANK_COUNTER = r"""
@@ -307,7 +355,7 @@ whole[::997] = ord("N")
 seq = whole[first * L:(first + cnt) * L]
 b = ctx.upload(seq, O.fixed_offsets(len(seq), L))
 u, c = count_kmers_via_super_kmers(ctx, b, k, m, seed=3, canonical=True)
-np.savez(os.path.join({out!r}, f"rank{{rank}}.npz"), u=u.cpu().numpy().view(np.uint64), c=c.cpu().numpy())
+np.savez(os.path.join({out!r}, f"rank{{rank}}.npz"), u=u.cpu().numpy().view(np.uint64), c=c.cpu().numpy())  # unordered: the test sorts
 ctx.close()
 dist.destroy_process_group()
 """
