@@ -102,6 +102,278 @@ __global__ __launch_bounds__(256) void expand_kernel(const ulonglong2* __restric
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// Counting without a global sort of the k-mers (bl_count_super_kmers).
+//   1. bucket_id_kernel   per record: the minimizer m-mer (at mm_pos of the first k-mer), canonical as the scan took it, hashed as
+//                         the scan hashed it; bucket = top bits of a multiplicative remix of that hash (independent of the
+//                         low bits used to pick the owner rank)
+//   2. rocprim::radix_sort_pairs (bucket id -> the 16-byte record itself): library plumbing, <= 26 key bits; the records of
+//                         a bucket end up contiguous
+//   3. bucket_starts_kernel  where each bucket begins in the sorted order (one thread per bucket, independent binary searches)
+//   4. count_buckets_kernel<false>  one WAVE per bucket (grid-stride over waves, 13 KB of LDS per wave, no workgroup barrier):
+//                         the bucket's k-mers go into an LDS hash table (1024 slots, linear probing, 64-bit compare-and-swap on
+//                         the key, 32-bit add on the count); only the number of distinct k-mers is kept.  A bucket with more
+//                         than CT_CAP k-mers or CT_RECS records is listed for the fallback instead.
+//   5. exclusive scan of those numbers = where every bucket writes
+//   6. count_buckets_kernel<true>   the tables are built again and written out at the buckets' offsets.  Two table passes
+//                         instead of one returning atomic per bucket on a single output cursor (~88 M/s on this chip: 48 ms for
+//                         4 M buckets); the output order is deterministic as a bonus.
+//   7. fallback           the records of listed buckets: gather -> expand -> radix sort -> run-length encode -> appended
+constexpr int CT_SLOTS = 1024;  // table slots of ONE WAVE
+constexpr int CT_CAP = 700;     // k-mers a bucket may hold to be counted in the table (load <= 0.68)
+constexpr int CT_RECS = 64;     // records a bucket may hold (one per lane)
+constexpr int CT_WAVES = 4;     // waves per workgroup
+constexpr unsigned long long CT_EMPTY = ~0ULL;  // never a k-mer for k < 32, nor a canonical 32-mer (its reverse complement is 0)
+
+__device__ __forceinline__ unsigned long long mmer_at(unsigned long long hi, unsigned long long lo, int pos, int m)
+{
+    // m bases from base `pos` (< 32) of the record: the top 2m bits of (hi:lo) << 2 pos
+    const unsigned long long lob = lo & ~0x3ffULL;
+    const unsigned long long top = pos == 0 ? hi : (hi << (2 * pos)) | (lob >> (64 - 2 * pos));
+    return top >> (64 - 2 * m);
+}
+
+__global__ __launch_bounds__(256) void bucket_id_kernel(const ulonglong2* __restrict__ recs, unsigned long long n, int m, int canonical, uint32_t seed, int bits,
+                                                        uint32_t* __restrict__ ids)
+{
+    const unsigned long long g = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n) return;
+    const ulonglong2 r = recs[g];
+    const int mp = (int)((r.y >> 5) & 31ULL);
+    unsigned long long v = mmer_at(r.x, r.y, mp, m);
+    if (canonical) {
+        unsigned long long rc = bl::pairrev64(v) >> (64 - 2 * m);
+        rc ^= m == 32 ? ~0ULL : ((1ULL << (2 * m)) - 1);
+        v = rc < v ? rc : v;
+    }
+    const unsigned long long h = bl::murmur64(v, seed);
+    ids[g] = bits ? (uint32_t)((h * 0x9E3779B97F4A7C15ULL) >> (64 - bits)) : 0u;
+}
+
+// starts[b] = first position of the sorted ids holding a value >= b, for b = 0 .. n_buckets
+__global__ __launch_bounds__(256) void bucket_starts_kernel(const uint32_t* __restrict__ ids, uint32_t n, uint32_t n_buckets, uint32_t* __restrict__ starts)
+{
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b > n_buckets) return;
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) {
+        const uint32_t mid = lo + (hi - lo) / 2;
+        if (ids[mid] < b) lo = mid + 1;
+        else hi = mid;
+    }
+    starts[b] = lo;
+}
+
+struct WaveTable {
+    unsigned long long keys[CT_SLOTS];
+    unsigned int cnt[CT_SLOTS];
+    ulonglong2 recs[CT_RECS];
+    unsigned int prefix[CT_RECS + 1];  // exclusive prefix of the records' sizes; [n_rec] = k-mers of the bucket
+};
+
+// LDS traffic of one wave is served in issue order, so lanes of a wave see each other's LDS writes as soon as the compiler
+// keeps the program order: a wavefront-scope fence does that (no s_barrier, no other wave involved)
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ void table_insert(WaveTable& t, unsigned long long key)
+{
+    uint32_t h = (uint32_t)((key * 0xD6E8FEB86659FD93ULL) >> (64 - 10));
+    for (;;) {
+        const unsigned long long old = atomicCAS(&t.keys[h], CT_EMPTY, key);
+        if (old == CT_EMPTY || old == key) {
+            atomicAdd(&t.cnt[h], 1u);
+            return;
+        }
+        h = (h + 1) & (CT_SLOTS - 1);  // the table never fills: at most CT_CAP of its CT_SLOTS slots are taken
+    }
+}
+
+__device__ __forceinline__ unsigned int wave_incl_scan(unsigned int v, int lane)
+{
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned int o = __shfl_up(v, d, 64);
+        if (lane >= d) v += o;
+    }
+    return v;
+}
+
+__device__ __forceinline__ void list_overflow(int lane, uint32_t lo, uint32_t hi, unsigned long long* cursor, uint2* overflow, uint32_t max_overflow)
+{
+    if (lane == 0) {
+        const unsigned long long slot = atomicAdd(&cursor[1], 1ULL);
+        if (slot < max_overflow) overflow[slot] = make_uint2(lo, hi);
+    }
+}
+
+// one bucket, one wave: records [lo, hi) of the sorted order; `rec` = this lane's record of it (lane l holds record lo + l; lanes
+// beyond the bucket hold something else and do not use it)
+template <bool WRITE>
+__device__ __forceinline__ void count_one_bucket(WaveTable& t, int lane, uint32_t bucket, uint32_t lo, uint32_t hi, ulonglong2 rec, int k, int canonical,
+                                                 unsigned long long kmask, unsigned int* __restrict__ distinct, const unsigned long long* __restrict__ offsets,
+                                                 unsigned long long* __restrict__ out_keys, unsigned int* __restrict__ out_counts, unsigned long long* cursor,
+                                                 uint2* __restrict__ overflow, uint32_t max_overflow)
+{
+    const uint32_t n_rec = hi - lo;  // wave-uniform
+    if (n_rec == 0) {
+        if (!WRITE && lane == 0) distinct[bucket] = 0;
+        return;
+    }
+    if (n_rec > CT_RECS) {  // too many records for one wave's table: the fallback counts this bucket
+        if (!WRITE) {
+            list_overflow(lane, lo, hi, cursor, overflow, max_overflow);
+            if (lane == 0) distinct[bucket] = 0;
+        }
+        return;
+    }
+    wave_lds_sync();  // the previous bucket's table has been read out
+#pragma unroll
+    for (int i = 0; i < CT_SLOTS / 64; ++i) {
+        t.keys[i * 64 + lane] = CT_EMPTY;
+        t.cnt[i * 64 + lane] = 0;
+    }
+    unsigned int size = 0;
+    if ((uint32_t)lane < n_rec) {
+        t.recs[lane] = rec;
+        size = (unsigned int)(rec.y & 31ULL) + 1;
+    }
+    const unsigned int incl = wave_incl_scan(size, lane);
+    const unsigned int total = __shfl(incl, 63, 64);
+    t.prefix[lane] = incl - size;  // lanes beyond the bucket hold the total, so prefix[n_rec] = total
+    if (lane == 63) t.prefix[64] = total;
+    wave_lds_sync();
+    if (total > CT_CAP) {  // wave-uniform
+        if (!WRITE) {
+            list_overflow(lane, lo, hi, cursor, overflow, max_overflow);
+            if (lane == 0) distinct[bucket] = 0;
+        }
+        return;
+    }
+    // k-mer j of the bucket: its record by binary search over the size prefix, then bases [q, q + k) of that record
+    for (unsigned int j = lane; j < total; j += 64) {
+        uint32_t a = 0, b = n_rec;  // last record with prefix <= j
+        while (b - a > 1) {
+            const uint32_t mid = (a + b) / 2;
+            if (t.prefix[mid] <= j) a = mid;
+            else b = mid;
+        }
+        const ulonglong2 r = t.recs[a];
+        const int q = (int)(j - t.prefix[a]);
+        const unsigned long long lob = r.y & ~0x3ffULL;
+        const unsigned long long top = q == 0 ? r.x : (r.x << (2 * q)) | (lob >> (64 - 2 * q));  // q <= 31
+        const unsigned long long fwd = top >> (64 - 2 * k);
+        unsigned long long key = fwd;
+        if (canonical) {
+            const unsigned long long rc = (bl::pairrev64(fwd) >> (64 - 2 * k)) ^ kmask;
+            key = rc < fwd ? rc : fwd;  // kmer_view.hpp:196
+        }
+        table_insert(t, key);
+    }
+    wave_lds_sync();
+    // occupied slots (lane l owns slots 16 l .. 16 l + 15)
+    unsigned int occ = 0;
+#pragma unroll
+    for (int i = 0; i < CT_SLOTS / 64; ++i) occ += t.cnt[lane * (CT_SLOTS / 64) + i] != 0;
+    const unsigned int oincl = wave_incl_scan(occ, lane);
+    if (!WRITE) {
+        if (lane == 63) distinct[bucket] = oincl;
+        return;
+    }
+    unsigned long long at = offsets[bucket + (lane >> 6)] + oincl - occ;
+#pragma unroll
+    for (int i = 0; i < CT_SLOTS / 64; ++i) {
+        const int slot = lane * (CT_SLOTS / 64) + i;
+        const unsigned int c = t.cnt[slot];
+        if (c) {
+            out_keys[at] = t.keys[slot];
+            out_counts[at] = c;
+            ++at;
+        }
+    }
+}
+
+// Every WAVE walks its own buckets with its own LDS: 12 buckets in flight per CU.  Software pipeline on top: while a wave
+// counts bucket b it already holds the records of its next bucket in registers and has the range of the one after that on
+// its way.  Three things keep the LDS waits of the bucket being counted from also sitting out that prefetch's DRAM latency:
+//   * the ranges are NOT fetched with scalar loads (scalar memory shares the wait counter lgkmcnt with LDS): a zero the
+//     compiler cannot see through puts them on the vector memory path, readfirstlane makes them scalar when consumed;
+//   * the records are fetched through a global-address-space pointer (a flat load counts on lgkmcnt as well);
+//   * every load of the pipeline is unconditional, indices clamped instead of branched on: with loads inside branches the
+//     compiler cannot count what is in flight and waits for everything (vmcnt(0)) at the first use of anything.
+template <bool WRITE>
+__global__ __launch_bounds__(64 * CT_WAVES) void count_buckets_kernel(const ulonglong2* __restrict__ recs, uint32_t n, const uint32_t* __restrict__ starts,
+                                                                      uint32_t n_buckets, int k, int canonical, unsigned int* __restrict__ distinct,
+                                                                      const unsigned long long* __restrict__ offsets, unsigned long long* __restrict__ out_keys,
+                                                                      unsigned int* __restrict__ out_counts, unsigned long long* cursor, uint2* __restrict__ overflow,
+                                                                      uint32_t max_overflow)
+{
+    __shared__ WaveTable tables[CT_WAVES];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    WaveTable& t = tables[wv];
+    const unsigned long long kmask = k == 32 ? ~0ULL : ((1ULL << (2 * k)) - 1);
+    typedef const __attribute__((address_space(1))) unsigned long long* gptr_t;
+    typedef const __attribute__((address_space(1))) uint32_t* gptr32_t;
+    gptr_t grecs = (gptr_t) reinterpret_cast<const unsigned long long*>(recs);
+    gptr32_t gstarts = (gptr32_t)starts;
+    uint32_t vz = 0;
+    asm volatile("" : "+v"(vz));
+    const uint32_t stride = gridDim.x * CT_WAVES, last_b = n_buckets - 1, last_r = n - 1;
+    auto range_of = [&](uint32_t bucket, uint32_t& vlo, uint32_t& vhi) {  // vector loads, always issued
+        const uint32_t c = (bucket < n_buckets ? bucket : last_b) + vz;
+        vlo = gstarts[c];
+        vhi = gstarts[c + 1];
+    };
+    auto record_of = [&](uint32_t pos) {  // always issued; lanes beyond the bucket get a record they will not use
+        const uint32_t c = pos < n ? pos : last_r;
+        ulonglong2 r;
+        r.x = grecs[2ull * c];
+        r.y = grecs[2ull * c + 1];
+        return r;
+    };
+    uint32_t b = blockIdx.x * CT_WAVES + wv, bn = b + stride;
+    if (b >= n_buckets) return;
+    uint32_t vlo, vhi, vnlo, vnhi;
+    range_of(b, vlo, vhi);
+    range_of(bn, vnlo, vnhi);
+    uint32_t lo = __builtin_amdgcn_readfirstlane(vlo), hi = __builtin_amdgcn_readfirstlane(vhi);
+    ulonglong2 rec = record_of(lo + lane);
+    while (b < n_buckets) {
+        const uint32_t nlo = __builtin_amdgcn_readfirstlane(vnlo), nhi = __builtin_amdgcn_readfirstlane(vnhi);
+        const ulonglong2 nrec = record_of(nlo + lane);  // the next bucket's records
+        const uint32_t b2 = bn + stride;
+        uint32_t v2lo, v2hi;
+        range_of(b2, v2lo, v2hi);                       // the range of the one after
+        count_one_bucket<WRITE>(t, lane, b, lo, hi, rec, k, canonical, kmask, distinct, offsets, out_keys, out_counts, cursor, overflow, max_overflow);
+        b = bn; bn = b2;
+        lo = nlo; hi = nhi; rec = nrec;
+        vnlo = v2lo; vnhi = v2hi;
+    }
+}
+
+// records of the listed ranges, one after the other: the fallback's input (one workgroup per range)
+__global__ __launch_bounds__(256) void gather_ranges_kernel(const ulonglong2* __restrict__ recs, const uint2* __restrict__ ranges,
+                                                            const unsigned long long* __restrict__ dst_off, ulonglong2* __restrict__ dst)
+{
+    const uint2 r = ranges[blockIdx.x];
+    ulonglong2* out = dst + dst_off[blockIdx.x];
+    for (uint32_t i = r.x + threadIdx.x; i < r.y; i += blockDim.x) out[i - r.x] = recs[i];
+}
+
+__global__ void append_counted_kernel(const unsigned long long* keys, const unsigned int* counts, unsigned long long n_runs, unsigned long long* out_keys,
+                                      unsigned int* out_counts, unsigned long long capacity, unsigned long long base)
+{
+    const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_runs && base + i < capacity) {
+        out_keys[base + i] = keys[i];
+        out_counts[base + i] = counts[i];
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -175,6 +447,144 @@ int bl_expand_super_kmers(bl_ctx* ctx, const uint64_t* d_records, uint64_t n_gro
     if (tmp) (void)hipFree(tmp);
     if (e != hipSuccess) return bl_set_error(e == hipErrorOutOfMemory ? BL_ERR_OOM : BL_ERR_HIP, hipGetErrorString(e));
     return rc;
+}
+
+int bl_count_super_kmers(bl_ctx* ctx, const uint64_t* d_records, uint64_t n_groups, uint32_t k, uint32_t m, uint64_t seed, uint32_t flags, uint64_t* d_kmers,
+                         uint32_t* d_counts, uint64_t capacity, uint64_t* n_distinct)
+{
+    if (!ctx || !n_distinct || (n_groups && !d_records)) return bl_set_error(BL_ERR_INVALID, "NULL argument");
+    if (k < 1 || k > 32 || m < 1 || m > k || 2 * k - m > MAX_BASES) return bl_set_error(BL_ERR_INVALID, "need 1 <= m <= k <= 32 and 2k - m <= 59 (bases per packed record)");
+    if (n_groups >= (1ull << 32)) return bl_set_error(BL_ERR_INVALID, "at most 2^32 - 1 records per call");
+    const int canonical = (flags & BL_FLAG_CANONICAL) ? 1 : 0;
+    if (k == 32 && !canonical) return bl_set_error(BL_ERR_INVALID, "k = 32 needs the canonical flag here (the all-T 32-mer is the table's empty mark); use bl_expand_super_kmers + bl_sort_u64");
+    *n_distinct = 0;
+    if (n_groups == 0) return BL_OK;
+    SK_HIP(hipSetDevice(bl_ctx_device(ctx)));
+    hipStream_t s = bl_ctx_stream(ctx);
+    const uint32_t n = (uint32_t)n_groups;
+    // buckets of ~20-40 records (170-340 k-mers at k = 31, m = 15), one wave each: a power of two, at most 2^26
+    int bits = 0;
+    while (bits < 26 && (n_groups >> bits) > 40) ++bits;
+    const uint32_t n_buckets = 1u << bits;
+    const uint32_t max_overflow = n_buckets < 65536u ? n_buckets : 65536u;
+    // scratch kept by the context between calls (hipMalloc / hipFree of gigabytes cost more than the kernels)
+    auto up16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
+    const size_t ids_bytes = up16(2ull * n * sizeof(uint32_t)), recs_bytes = (size_t)n * sizeof(ulonglong2), starts_bytes = up16(((size_t)n_buckets + 2) * sizeof(uint32_t));
+    const size_t over_bytes = up16((size_t)max_overflow * sizeof(uint2)), offs_bytes = up16(((size_t)n_buckets + 1) * sizeof(unsigned long long));
+    const size_t dist_bytes = up16(((size_t)n_buckets + 1) * sizeof(unsigned int));
+    unsigned char* arena = static_cast<unsigned char*>(bl_ctx_scratch(ctx, 0, ids_bytes + recs_bytes + starts_bytes + over_bytes + offs_bytes + dist_bytes + 64));
+    if (!arena) return bl_set_error(BL_ERR_OOM, "scratch allocation failed");
+    uint32_t* ids = reinterpret_cast<uint32_t*>(arena);
+    uint32_t* ids_sorted = ids + n;
+    ulonglong2* recs_sorted = reinterpret_cast<ulonglong2*>(arena + ids_bytes);
+    uint32_t* starts = reinterpret_cast<uint32_t*>(arena + ids_bytes + recs_bytes);
+    uint2* overflow = reinterpret_cast<uint2*>(arena + ids_bytes + recs_bytes + starts_bytes);
+    unsigned long long* offsets = reinterpret_cast<unsigned long long*>(arena + ids_bytes + recs_bytes + starts_bytes + over_bytes);
+    unsigned int* distinct = reinterpret_cast<unsigned int*>(arena + ids_bytes + recs_bytes + starts_bytes + over_bytes + offs_bytes);
+    unsigned long long* cursor = reinterpret_cast<unsigned long long*>(arena + ids_bytes + recs_bytes + starts_bytes + over_bytes + offs_bytes + dist_bytes);
+    const ulonglong2* recs = reinterpret_cast<const ulonglong2*>(d_records);
+    hipError_t e = hipMemsetAsync(cursor, 0, 2 * sizeof(unsigned long long), s);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(bucket_id_kernel, dim3((n + 255) / 256), dim3(256), 0, s, recs, (unsigned long long)n, (int)m, canonical, (uint32_t)seed, bits, ids);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess && bits > 0) {
+        size_t tmp_bytes = 0;
+        e = rocprim::radix_sort_pairs(nullptr, tmp_bytes, ids, ids_sorted, recs, recs_sorted, (size_t)n, 0, (unsigned)bits, s);
+        void* tmp = nullptr;
+        if (e == hipSuccess) {
+            tmp = bl_ctx_scratch(ctx, 1, tmp_bytes ? tmp_bytes : 16);
+            if (!tmp) e = hipErrorOutOfMemory;
+        }
+        if (e == hipSuccess) e = rocprim::radix_sort_pairs(tmp, tmp_bytes, ids, ids_sorted, recs, recs_sorted, (size_t)n, 0, (unsigned)bits, s);
+    } else if (e == hipSuccess) {
+        ids_sorted = ids;
+        recs_sorted = const_cast<ulonglong2*>(recs);
+    }
+    const uint32_t want = (n_buckets + CT_WAVES - 1) / CT_WAVES;
+    const uint32_t grid = want < 256u * 3u ? want : 256u * 3u;  // 3 workgroups of 4 waves per CU by LDS (13 KB per wave): all resident, grid-stride over the buckets
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(bucket_starts_kernel, dim3(n_buckets / 256 + 1), dim3(256), 0, s, ids_sorted, n, n_buckets, starts);
+        // pass 1: distinct k-mers per bucket; their exclusive scan = where each bucket writes in pass 2
+        hipLaunchKernelGGL((count_buckets_kernel<false>), dim3(grid), dim3(64 * CT_WAVES), 0, s, recs_sorted, n, starts, n_buckets, (int)k, canonical, distinct,
+                           static_cast<const unsigned long long*>(nullptr), static_cast<unsigned long long*>(nullptr), static_cast<unsigned int*>(nullptr), cursor,
+                           overflow, max_overflow);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemsetAsync(distinct + n_buckets, 0, sizeof(unsigned int), s);
+        size_t scan_bytes = 0;
+        if (e == hipSuccess) e = rocprim::exclusive_scan(nullptr, scan_bytes, distinct, offsets, 0ull, (size_t)n_buckets + 1, rocprim::plus<unsigned long long>(), s);
+        void* scan_tmp = nullptr;
+        if (e == hipSuccess) {
+            scan_tmp = bl_ctx_scratch(ctx, 2, scan_bytes ? scan_bytes : 16);
+            if (!scan_tmp) e = hipErrorOutOfMemory;
+        }
+        if (e == hipSuccess) e = rocprim::exclusive_scan(scan_tmp, scan_bytes, distinct, offsets, 0ull, (size_t)n_buckets + 1, rocprim::plus<unsigned long long>(), s);
+    }
+    unsigned long long cur[2] = {0, 0};
+    if (e == hipSuccess) e = hipMemcpyAsync(&cur[0], offsets + n_buckets, sizeof(unsigned long long), hipMemcpyDeviceToHost, s);  // distinct k-mers of the table buckets
+    if (e == hipSuccess) e = hipMemcpyAsync(&cur[1], cursor + 1, sizeof(unsigned long long), hipMemcpyDeviceToHost, s);          // buckets left to the fallback
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    const bool can_write = d_kmers && d_counts && cur[0] <= capacity;
+    if (e == hipSuccess && can_write && cur[0] > 0) {
+        hipLaunchKernelGGL((count_buckets_kernel<true>), dim3(grid), dim3(64 * CT_WAVES), 0, s, recs_sorted, n, starts, n_buckets, (int)k, canonical, distinct, offsets,
+                           reinterpret_cast<unsigned long long*>(d_kmers), d_counts, cursor, overflow, max_overflow);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+    }
+    unsigned long long total = cur[0];
+    int rc = BL_OK;
+    if (e == hipSuccess && cur[1] > max_overflow) rc = bl_set_error(BL_ERR_INTERNAL, "more oversized buckets than the fallback list holds");
+    if (e == hipSuccess && rc == BL_OK && cur[1] > 0) {
+        // fallback for the listed buckets: gather their records, expand, sort, run-length encode, append
+        const uint32_t n_over = (uint32_t)cur[1];
+        std::vector<uint2> ranges(n_over);
+        e = hipMemcpy(ranges.data(), overflow, n_over * sizeof(uint2), hipMemcpyDeviceToHost);
+        std::vector<unsigned long long> off(n_over + 1, 0);
+        for (uint32_t i = 0; i < n_over; ++i) off[i + 1] = off[i] + (ranges[i].y - ranges[i].x);
+        const unsigned long long n_over_recs = off[n_over];
+        ulonglong2* gathered = nullptr;
+        unsigned long long *d_off = nullptr, *kmers = nullptr, *uniq = nullptr;
+        unsigned int* cnts = nullptr;
+        uint64_t n_kmers = 0;
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&gathered), n_over_recs * sizeof(ulonglong2));
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_off), (n_over + 1) * sizeof(unsigned long long));
+        if (e == hipSuccess) e = hipMemcpy(d_off, off.data(), (n_over + 1) * sizeof(unsigned long long), hipMemcpyHostToDevice);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(gather_ranges_kernel, dim3(n_over), dim3(256), 0, s, recs_sorted, overflow, d_off, gathered);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) {
+            int r2 = bl_expand_super_kmers(ctx, reinterpret_cast<const uint64_t*>(gathered), n_over_recs, k, flags, nullptr, 0, &n_kmers);
+            if (r2 != BL_OK && r2 != BL_ERR_CAPACITY) rc = r2;
+        }
+        if (e == hipSuccess && rc == BL_OK) e = hipMalloc(reinterpret_cast<void**>(&kmers), 2 * n_kmers * sizeof(unsigned long long) + 8);
+        if (e == hipSuccess && rc == BL_OK) e = hipMalloc(reinterpret_cast<void**>(&cnts), n_kmers * sizeof(unsigned int) + 4);
+        if (e == hipSuccess && rc == BL_OK) {
+            uniq = kmers + n_kmers;
+            rc = bl_expand_super_kmers(ctx, reinterpret_cast<const uint64_t*>(gathered), n_over_recs, k, flags, reinterpret_cast<uint64_t*>(kmers), n_kmers, &n_kmers);
+            if (rc == BL_OK) rc = bl_sort_u64(ctx, reinterpret_cast<uint64_t*>(kmers), n_kmers);
+            uint64_t runs = 0;
+            if (rc == BL_OK) rc = bl_count_sorted_u64(ctx, reinterpret_cast<const uint64_t*>(kmers), n_kmers, reinterpret_cast<uint64_t*>(uniq), cnts, &runs);
+            if (rc == BL_OK && runs) {
+                if (d_kmers && d_counts) {
+                    hipLaunchKernelGGL(append_counted_kernel, dim3((unsigned)((runs + 255) / 256)), dim3(256), 0, s, uniq, cnts, (unsigned long long)runs,
+                                       reinterpret_cast<unsigned long long*>(d_kmers), d_counts, (unsigned long long)capacity, total);
+                    e = hipGetLastError();
+                    if (e == hipSuccess) e = hipStreamSynchronize(s);
+                }
+                total += runs;
+            }
+        }
+        if (gathered) (void)hipFree(gathered);
+        if (d_off) (void)hipFree(d_off);
+        if (kmers) (void)hipFree(kmers);
+        if (cnts) (void)hipFree(cnts);
+    }
+    if (e != hipSuccess) return bl_set_error(e == hipErrorOutOfMemory ? BL_ERR_OOM : BL_ERR_HIP, hipGetErrorString(e));
+    if (rc != BL_OK) return rc;
+    *n_distinct = total;
+    if (total > capacity || ((!d_kmers || !d_counts) && total)) return bl_set_error(BL_ERR_CAPACITY, "distinct k-mers exceed the capacity of the output arrays (n_distinct holds the need)");
+    return BL_OK;
 }
 
 }  // extern "C"
