@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256) void expand_kernel(const ulonglong2* __restric
 constexpr int CT_SLOTS = 1024;  // table slots of ONE WAVE
 constexpr int CT_CAP = 700;     // k-mers a bucket may hold to be counted in the table (load <= 0.68)
 constexpr int CT_RECS = 64;     // records a bucket may hold (one per lane)
-constexpr int CT_WAVES = 4;     // waves per workgroup
+constexpr int CT_WAVES = 2;     // waves per workgroup (14.4 KB of LDS per wave: 5 workgroups = 10 waves per CU)
 constexpr unsigned long long CT_EMPTY = ~0ULL;  // never a k-mer for k < 32, nor a canonical 32-mer (its reverse complement is 0)
 
 __device__ __forceinline__ unsigned long long mmer_at(unsigned long long hi, unsigned long long lo, int pos, int m)
@@ -165,11 +165,23 @@ __global__ __launch_bounds__(256) void bucket_starts_kernel(const uint32_t* __re
     starts[b] = lo;
 }
 
+// diagnostic build (-DBL_COUNT_STAMPS, tools/count_stamps.py): shader cycles per phase, accumulated per wave in registers
+#ifdef BL_COUNT_STAMPS
+__device__ unsigned long long bl_count_stamps[8];
+#define STAMP(i) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); acc[i] += now_ - stamp_t_; stamp_t_ = now_; } while (0)
+#define STAMP_ARGS , unsigned long long* acc, unsigned long long& stamp_t_
+#define STAMP_PASS , acc, stamp_t_
+#else
+#define STAMP(i) do {} while (0)
+#define STAMP_ARGS
+#define STAMP_PASS
+#endif
+
 struct WaveTable {
     unsigned long long keys[CT_SLOTS];
     unsigned int cnt[CT_SLOTS];
     ulonglong2 recs[CT_RECS];
-    unsigned int prefix[CT_RECS + 1];  // exclusive prefix of the records' sizes; [n_rec] = k-mers of the bucket
+    unsigned short work[CT_CAP + 4];  // k-mer j of the bucket = k-mer (entry & 31) of record (entry >> 5)
 };
 
 // LDS traffic of one wave is served in issue order, so lanes of a wave see each other's LDS writes as soon as the compiler
@@ -180,17 +192,44 @@ __device__ __forceinline__ void wave_lds_sync()
     __builtin_amdgcn_wave_barrier();
 }
 
-__device__ __forceinline__ void table_insert(WaveTable& t, unsigned long long key)
+__device__ __forceinline__ uint32_t table_slot(unsigned long long key) { return (uint32_t)((key * 0xD6E8FEB86659FD93ULL) >> (64 - 10)); }
+
+// one probe: true when the key sits in slot h now (it was empty, or held the same key already)
+__device__ __forceinline__ bool table_probe(WaveTable& t, uint32_t h, unsigned long long key)
 {
-    uint32_t h = (uint32_t)((key * 0xD6E8FEB86659FD93ULL) >> (64 - 10));
-    for (;;) {
-        const unsigned long long old = atomicCAS(&t.keys[h], CT_EMPTY, key);
-        if (old == CT_EMPTY || old == key) {
-            atomicAdd(&t.cnt[h], 1u);
-            return;
-        }
-        h = (h + 1) & (CT_SLOTS - 1);  // the table never fills: at most CT_CAP of its CT_SLOTS slots are taken
+    const unsigned long long old = atomicCAS(&t.keys[h], CT_EMPTY, key);
+    return old == CT_EMPTY || old == key;
+}
+
+// two keys at once (has2 = false: only the first): both first probes are issued before either result is looked at, so their LDS
+// round trips overlap; the few that collide (load <= 0.68) walk on one by one.  The table never fills.
+__device__ __forceinline__ void table_insert2(WaveTable& t, unsigned long long key1, unsigned long long key2, bool has2)
+{
+    uint32_t h1 = table_slot(key1), h2 = table_slot(key2);
+    const unsigned long long old1 = atomicCAS(&t.keys[h1], CT_EMPTY, key1);
+    const unsigned long long old2 = has2 ? atomicCAS(&t.keys[h2], CT_EMPTY, key2) : key2;
+    bool ok1 = old1 == CT_EMPTY || old1 == key1, ok2 = old2 == CT_EMPTY || old2 == key2;
+    while (!ok1) {
+        h1 = (h1 + 1) & (CT_SLOTS - 1);
+        ok1 = table_probe(t, h1, key1);
     }
+    while (!ok2) {
+        h2 = (h2 + 1) & (CT_SLOTS - 1);
+        ok2 = table_probe(t, h2, key2);
+    }
+    atomicAdd(&t.cnt[h1], 1u);
+    if (has2) atomicAdd(&t.cnt[h2], 1u);
+}
+
+__device__ __forceinline__ unsigned long long kmer_of(ulonglong2 r, int q, int k, int canonical, unsigned long long kmask)
+{
+    // bases [q, q + k) of the record (q <= 31): the top 2k bits of (hi:lo) << 2q
+    const unsigned long long lob = r.y & ~0x3ffULL;
+    const unsigned long long top = q == 0 ? r.x : (r.x << (2 * q)) | (lob >> (64 - 2 * q));
+    const unsigned long long fwd = top >> (64 - 2 * k);
+    if (!canonical) return fwd;
+    const unsigned long long rc = (bl::pairrev64(fwd) >> (64 - 2 * k)) ^ kmask;
+    return rc < fwd ? rc : fwd;  // kmer_view.hpp:196
 }
 
 __device__ __forceinline__ unsigned int wave_incl_scan(unsigned int v, int lane)
@@ -217,8 +256,9 @@ template <bool WRITE>
 __device__ __forceinline__ void count_one_bucket(WaveTable& t, int lane, uint32_t bucket, uint32_t lo, uint32_t hi, ulonglong2 rec, int k, int canonical,
                                                  unsigned long long kmask, unsigned int* __restrict__ distinct, const unsigned long long* __restrict__ offsets,
                                                  unsigned long long* __restrict__ out_keys, unsigned int* __restrict__ out_counts, unsigned long long* cursor,
-                                                 uint2* __restrict__ overflow, uint32_t max_overflow)
+                                                 uint2* __restrict__ overflow, uint32_t max_overflow STAMP_ARGS)
 {
+    STAMP(0);  // everything between two buckets: loop control, the waits for this bucket's records and range
     const uint32_t n_rec = hi - lo;  // wave-uniform
     if (n_rec == 0) {
         if (!WRITE && lane == 0) distinct[bucket] = 0;
@@ -242,11 +282,10 @@ __device__ __forceinline__ void count_one_bucket(WaveTable& t, int lane, uint32_
         t.recs[lane] = rec;
         size = (unsigned int)(rec.y & 31ULL) + 1;
     }
+    STAMP(1);  // table cleared, records staged
     const unsigned int incl = wave_incl_scan(size, lane);
     const unsigned int total = __shfl(incl, 63, 64);
-    t.prefix[lane] = incl - size;  // lanes beyond the bucket hold the total, so prefix[n_rec] = total
-    if (lane == 63) t.prefix[64] = total;
-    wave_lds_sync();
+    STAMP(2);  // size prefix
     if (total > CT_CAP) {  // wave-uniform
         if (!WRITE) {
             list_overflow(lane, lo, hi, cursor, overflow, max_overflow);
@@ -254,32 +293,28 @@ __device__ __forceinline__ void count_one_bucket(WaveTable& t, int lane, uint32_
         }
         return;
     }
-    // k-mer j of the bucket: its record by binary search over the size prefix, then bases [q, q + k) of that record
-    for (unsigned int j = lane; j < total; j += 64) {
-        uint32_t a = 0, b = n_rec;  // last record with prefix <= j
-        while (b - a > 1) {
-            const uint32_t mid = (a + b) / 2;
-            if (t.prefix[mid] <= j) a = mid;
-            else b = mid;
-        }
-        const ulonglong2 r = t.recs[a];
-        const int q = (int)(j - t.prefix[a]);
-        const unsigned long long lob = r.y & ~0x3ffULL;
-        const unsigned long long top = q == 0 ? r.x : (r.x << (2 * q)) | (lob >> (64 - 2 * q));  // q <= 31
-        const unsigned long long fwd = top >> (64 - 2 * k);
-        unsigned long long key = fwd;
-        if (canonical) {
-            const unsigned long long rc = (bl::pairrev64(fwd) >> (64 - 2 * k)) ^ kmask;
-            key = rc < fwd ? rc : fwd;  // kmer_view.hpp:196
-        }
-        table_insert(t, key);
+    // work list: k-mer j of the bucket -> (record, index inside it), written by the record's own lane at its prefix (fire and
+    // forget LDS stores, no search later)
+    {
+        const unsigned int first = incl - size;
+        for (unsigned int q = 0; q < size; ++q) t.work[first + q] = (unsigned short)((lane << 5) | q);
     }
     wave_lds_sync();
+    // two k-mers per lane and round, their table probes in flight together
+    for (unsigned int j = lane; j < total; j += 128) {
+        const bool has2 = j + 64 < total;
+        const unsigned int w1 = t.work[j], w2 = t.work[has2 ? j + 64 : j];
+        const ulonglong2 r1 = t.recs[w1 >> 5], r2 = t.recs[w2 >> 5];
+        table_insert2(t, kmer_of(r1, (int)(w1 & 31u), k, canonical, kmask), kmer_of(r2, (int)(w2 & 31u), k, canonical, kmask), has2);
+    }
+    wave_lds_sync();
+    STAMP(3);  // k-mers inserted
     // occupied slots (lane l owns slots 16 l .. 16 l + 15)
     unsigned int occ = 0;
 #pragma unroll
     for (int i = 0; i < CT_SLOTS / 64; ++i) occ += t.cnt[lane * (CT_SLOTS / 64) + i] != 0;
     const unsigned int oincl = wave_incl_scan(occ, lane);
+    STAMP(4);  // occupied slots counted
     if (!WRITE) {
         if (lane == 63) distinct[bucket] = oincl;
         return;
@@ -295,6 +330,7 @@ __device__ __forceinline__ void count_one_bucket(WaveTable& t, int lane, uint32_
             ++at;
         }
     }
+    STAMP(5);  // written out
 }
 
 // Every WAVE walks its own buckets with its own LDS: 12 buckets in flight per CU.  Software pipeline on top: while a wave
@@ -337,6 +373,10 @@ __global__ __launch_bounds__(64 * CT_WAVES) void count_buckets_kernel(const ulon
     };
     uint32_t b = blockIdx.x * CT_WAVES + wv, bn = b + stride;
     if (b >= n_buckets) return;
+#ifdef BL_COUNT_STAMPS
+    unsigned long long acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long stamp_t_ = __builtin_amdgcn_s_memtime();
+#endif
     uint32_t vlo, vhi, vnlo, vnhi;
     range_of(b, vlo, vhi);
     range_of(bn, vnlo, vnhi);
@@ -348,11 +388,18 @@ __global__ __launch_bounds__(64 * CT_WAVES) void count_buckets_kernel(const ulon
         const uint32_t b2 = bn + stride;
         uint32_t v2lo, v2hi;
         range_of(b2, v2lo, v2hi);                       // the range of the one after
-        count_one_bucket<WRITE>(t, lane, b, lo, hi, rec, k, canonical, kmask, distinct, offsets, out_keys, out_counts, cursor, overflow, max_overflow);
+        count_one_bucket<WRITE>(t, lane, b, lo, hi, rec, k, canonical, kmask, distinct, offsets, out_keys, out_counts, cursor, overflow, max_overflow STAMP_PASS);
+#ifdef BL_COUNT_STAMPS
+        acc[7] += 1;
+#endif
         b = bn; bn = b2;
         lo = nlo; hi = nhi; rec = nrec;
         vnlo = v2lo; vnhi = v2hi;
     }
+#ifdef BL_COUNT_STAMPS
+    if (lane == 0)
+        for (int i = 0; i < 8; ++i) atomicAdd(&bl_count_stamps[i], acc[i]);
+#endif
 }
 
 // records of the listed ranges, one after the other: the fallback's input (one workgroup per range)
@@ -375,6 +422,16 @@ __global__ void append_counted_kernel(const unsigned long long* keys, const unsi
 }
 
 }  // namespace
+
+#ifdef BL_COUNT_STAMPS
+extern "C" void bl_dbg_count_stamps(unsigned long long* out)
+{
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(bl_count_stamps), 8 * sizeof(unsigned long long));
+    unsigned long long z[8] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(bl_count_stamps), z, sizeof(z));
+}
+#endif
 
 extern "C" {
 
@@ -502,7 +559,7 @@ int bl_count_super_kmers(bl_ctx* ctx, const uint64_t* d_records, uint64_t n_grou
         recs_sorted = const_cast<ulonglong2*>(recs);
     }
     const uint32_t want = (n_buckets + CT_WAVES - 1) / CT_WAVES;
-    const uint32_t grid = want < 256u * 3u ? want : 256u * 3u;  // 3 workgroups of 4 waves per CU by LDS (13 KB per wave): all resident, grid-stride over the buckets
+    const uint32_t grid = want < 256u * 5u ? want : 256u * 5u;  // 5 workgroups of 2 waves per CU by LDS (14.4 KB per wave): all resident, grid-stride over the buckets
     if (e == hipSuccess) {
         hipLaunchKernelGGL(bucket_starts_kernel, dim3(n_buckets / 256 + 1), dim3(256), 0, s, ids_sorted, n, n_buckets, starts);
         // pass 1: distinct k-mers per bucket; their exclusive scan = where each bucket writes in pass 2

@@ -1,3 +1,4 @@
+"""Diagnostic: shader cycles per phase of count_buckets_kernel (library built with -DBL_COUNT_STAMPS as biolib_amd/lib/libbiolib_amd_stamps.so)."""
 import os, sys, ctypes as C
 ROOT=os.environ.get("GRAFT_REPO_ROOT","/root/repo")
 os.environ["BIOLIB_AMD_LIB"]=os.path.join(ROOT,"biolib_amd/lib/libbiolib_amd_stamps.so")
@@ -15,4 +16,8 @@ L.bl_dbg_count_stamps(out)
 u,c=ctx.count_super_kmers(recs,31,15,seed=42,canonical=True,out=(keys,cnts))
 L.bl_dbg_count_stamps(out)
 v=list(out)
-print("buckets(both passes)",v[5],"cycles/bucket: clear",v[0]/v[5],"load+scan",v[1]/v[5],"insert",v[2]/v[5],"occ-scan",v[3]/v[5],"whole",v[4]/v[5])
+nb=v[7]
+names=["between buckets (loop, waits for records/range)","clear+stage","size prefix","insert","occupied count","write out"]
+print("buckets (both passes):",nb)
+for i,nm in enumerate(names): print(f"  {nm:50s} {v[i]/nb:9.0f} cycles per bucket")
+print(f"  {'sum':50s} {sum(v[:6])/nb:9.0f}")
