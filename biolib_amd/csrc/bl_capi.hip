@@ -89,7 +89,7 @@ struct bl_ctx {
     Lane* cur = nullptr;               // lane of the scan being issued / issued last
     int next_lane = 0;
     int n_lanes = 1;                   // 2: consecutive async scans alternate lanes, staggered (bl_ctx_set_lanes, env BL_LANES)
-    uint32_t emit_lds_per_wg = 25600;  // two-lane mode: LDS footprint pass-2 workgroups are padded to (caps their residency per CU)
+    uint32_t emit_lds_per_wg = 16384;  // two-lane mode: LDS footprint pass-2 workgroups are padded to (caps their residency per CU; swept on MI355X: 0 -> 214, 16 K -> 449, 25 K -> 438 Gbp/s at C3)
     hipStream_t user_stream = nullptr; // borrowed (bl_ctx_set_stream); NULL while borrowed = the legacy default stream
     bool borrowed = false;             // scans run on user_stream instead of the lanes' own streams
     hipStream_t stream = nullptr;      // stream of `cur`

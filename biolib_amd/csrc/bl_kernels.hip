@@ -174,12 +174,16 @@ __device__ __forceinline__ void count_tile_frl(const ScanParams& p, TileShared<M
     }
 }
 
-// Pass 2 of one tile: reload the tile's 2-bit codes (spilled by pass 1), rebuild each record from its u16 list entry
-// (unit value, hash, position) and store it at the tile's global offset with coalesced stores.
-template <int MODE, int W>
-__device__ __forceinline__ void emit_tile(const ScanParams& p, TileShared<MODE, W>& sh, uint32_t tile, int tid, Digest& dg)
+// Pass 2 of one tile: reload the tile's 2-bit codes (spilled by pass 1) into LDS, rebuild each record from its u16 list entry
+// (unit value, hash, position) and store it at the tile's global offset with coalesced stores.  The list entries are read
+// straight from the tile's global slots — each exactly once, by the thread that builds the record — so the kernel's LDS
+// footprint is the 2 KB of codes and its residency is set by launch_scan_emit's padding alone (it used to stage up to
+// three 8 KB lists per tile, which, beside a hashing kernel that needs 12 KB per workgroup, decided who got the CU).
+template <int MODE>
+__device__ __forceinline__ void emit_tile(const ScanParams& p, uint32_t* codes, uint32_t tile, int tid, Digest& dg)
 {
-    // one memory round trip: every load of the tile is issued before the first one is consumed
+    // one memory round trip for the common case: every load of the tile — counts, offsets, codes, the first 2 * TPB list entries
+    // (speculatively: a tile of 150-bp reads holds ~600) — is issued before the first one is consumed
     const int64_t q0 = tile_q0(p, tile);
     const size_t slot = (size_t)tile * p.stride;
     const unsigned long long cnt = p.tile_counts[tile];
@@ -188,24 +192,38 @@ __device__ __forceinline__ void emit_tile(const ScanParams& p, TileShared<MODE, 
     const uint32_t* sc = p.slots_c + (size_t)tile * p.slot_chunks;
     const uint32_t c0 = tid < needed ? sc[tid] : 0;
     const uint32_t c1 = TPB + tid < needed ? sc[TPB + tid] : 0;
-    // the first 2*TPB list entries speculatively (a tile of 150-bp reads holds ~545)
-    const uint32_t* sa32 = reinterpret_cast<const uint32_t*>(p.slots_a + slot);
-    const uint32_t la = 2 * tid < p.stride ? sa32[tid] : 0;
+    const uint16_t* la = p.slots_a + slot;
+    const uint16_t* lj = MODE == MODE_SUPERKMER ? p.slots_j + slot : nullptr;
+    const uint16_t* le = MODE == MODE_SUPERKMER ? p.slots_e + slot : nullptr;
+    const bool in0 = tid < p.stride, in1 = TPB + tid < p.stride;  // inside the slot (its tail past n_s holds stale entries: never used)
+    const uint32_t a0 = in0 ? la[tid] : 0, a1 = in1 ? la[TPB + tid] : 0;
+    uint32_t j0 = 0, j1 = 0, e0 = 0, e1 = 0;
+    if (MODE == MODE_SUPERKMER) {
+        j0 = in0 ? lj[tid] : 0; j1 = in1 ? lj[TPB + tid] : 0;
+        e0 = in0 ? le[tid] : 0; e1 = in1 ? le[TPB + tid] : 0;
+    }
     const uint32_t n_s = (uint32_t)cnt, n_e = (uint32_t)(cnt >> 32);
     if (n_s == 0 && n_e == 0) return;  // uniform for the workgroup
     const uint64_t base_s = base & 0xffffffffull, base_e = base >> 32;
-
-    if (tid < needed) sh.codes[tid] = c0;
-    if (TPB + tid < needed) sh.codes[TPB + tid] = c1;
-    reinterpret_cast<uint32_t*>(sh.list_a)[tid] = la;
-#pragma unroll 1
-    for (uint32_t i = TPB + tid; i < (n_s + 1) / 2; i += TPB) reinterpret_cast<uint32_t*>(sh.list_a)[i] = sa32[i];  // rarely more than one round
-    if (MODE == MODE_SUPERKMER) {
-        fill_list(sh.list_j, p.slots_j + slot, n_s, tid);
-        fill_list(sh.list_e, p.slots_e + slot, n_e, tid);
-    }
+    if (tid < needed) codes[tid] = c0;
+    if (TPB + tid < needed) codes[TPB + tid] = c1;
     __syncthreads();
-    phase_emit<MODE, W>(p, sh, tid, q0, n_s, n_e, base_s, base_e, dg);
+    const bool fits = !BL_COLD(base_s + n_s > p.capacity);
+    auto one = [&](uint32_t r, uint32_t ent, uint32_t ent_j) {
+        const Record rec = emit_prepare<MODE>(p, codes, q0, ent, ent_j, dg);
+        if (fits) emit_store<MODE, false>(p, rec, base_s + r);
+        else emit_store<MODE, true>(p, rec, base_s + r);
+    };
+    if ((uint32_t)tid < n_s) one(tid, a0, j0);
+    if ((uint32_t)(TPB + tid) < n_s) one(TPB + tid, a1, j1);
+#pragma unroll 1
+    for (uint32_t r = 2 * TPB + tid; r < n_s; r += TPB) one(r, la[r], MODE == MODE_SUPERKMER ? lj[r] : 0u);  // rarely any
+    if (MODE == MODE_SUPERKMER) {
+        if ((uint32_t)tid < n_e) emit_end<MODE>(p, q0, e0, base_e + tid);
+        if ((uint32_t)(TPB + tid) < n_e) emit_end<MODE>(p, q0, e1, base_e + TPB + tid);
+#pragma unroll 1
+        for (uint32_t r = 2 * TPB + tid; r < n_e; r += TPB) emit_end<MODE>(p, q0, le[r], base_e + r);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -257,11 +275,11 @@ __global__ __launch_bounds__(TPB, (W <= 11 ? 5 : 4)) void scan_count_frl_kernel(
 template <int MODE>
 __global__ __launch_bounds__(TPB) void scan_emit_kernel(const ScanParams p, GroupRange g)
 {
-    __shared__ TileShared<MODE, 1> sh;  // W only sizes the fallback hash array: not used here
+    __shared__ uint32_t codes[NCHUNK];
     const int tid = threadIdx.x;
     if (blockIdx.x >= g.count) return;
     Digest dg{0, 0, 0};
-    emit_tile<MODE, 1>(p, sh, g.first + blockIdx.x, tid, dg);
+    emit_tile<MODE>(p, codes, g.first + blockIdx.x, tid, dg);
 
     // digest: wave reduce, then one set of atomics per WAVE into a shard line (an LDS stage in between would add two
     // barriers per tile to save 9 of 12 atomics that L2 absorbs anyway)
@@ -557,7 +575,7 @@ hipError_t launch_scan_count(int mode, const ScanParams& p, GroupRange g, hipStr
 template <int MODE>
 static void launch_emit_mode(const ScanParams& p, GroupRange g, hipStream_t stream, uint32_t lds_per_wg)
 {
-    const uint32_t have = (uint32_t)sizeof(TileShared<MODE, 1>);
+    const uint32_t have = (uint32_t)(NCHUNK * sizeof(uint32_t));
     const uint32_t pad = lds_per_wg > have ? lds_per_wg - have : 0;
     hipLaunchKernelGGL((scan_emit_kernel<MODE>), dim3(g.count), dim3(TPB), pad, stream, p, g);
 }

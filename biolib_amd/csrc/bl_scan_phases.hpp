@@ -685,24 +685,33 @@ struct Record {
     uint32_t mmpos;
 };
 
-// 5a: everything that does not need the global offset (runs while wave 0 is still in the look-back)
-template <int MODE, int W>
-BL_DEV Record emit_prepare(const ScanParams& p, const TileShared<MODE, W>& sh, int64_t q0, uint32_t r, Digest& dg)
+// The record lists of a tile as pass 2 sees them: plain pointers — into the tile's global slots on the GPU (every entry is
+// read exactly once, by the thread that builds its record: staging them in LDS would only cost residency), into the
+// emulated LDS lists in the harness.
+struct TileLists {
+    const uint32_t* codes;   // the tile's 2-bit codes (LDS: units are extracted at arbitrary offsets)
+    const uint16_t* list_a;  // [n_s]
+    const uint16_t* list_j;  // [n_s]  super-k-mer mode
+    const uint16_t* list_e;  // [n_e]  super-k-mer mode
+};
+
+// 5a: one record from its list entries.  Entries: (wave << 12) | wave-relative position, or — read-tiled scans — a flat
+// tile-relative position.
+template <int MODE>
+BL_DEV Record emit_prepare(const ScanParams& p, const uint32_t* codes, int64_t q0, uint32_t ent, uint32_t ent_j, Digest& dg)
 {
     Record rec{0, 0, 0, 0, 0};
-    // list entries: (wave << 12) | wave-relative position, or — read-tiled scans — a flat tile-relative position
-    const uint32_t ent = sh.list_a[r];
     const int wv = p.frl ? 0 : ent >> 12, ap = p.frl ? ent : ent & 0xfff;
     const int64_t wq0 = p.frl ? q0 : wave_origin(p, q0, wv);
     rec.pos = (uint64_t)(wq0 + ap);
     dg.xp ^= rec.pos;
     if (MODE != MODE_SYNCMER) {
-        rec.v = extract_unit(p.frl ? sh.codes : sh.codes + wave_chunk0(p, wv), ap, p.unit, p.canonical);
+        rec.v = extract_unit(p.frl ? codes : codes + wave_chunk0(p, wv), ap, p.unit, p.canonical);
         rec.h = murmur64(rec.v, p.seed);
         dg.xv ^= rec.v;
         dg.xh ^= rec.h;
         if (MODE == MODE_SUPERKMER) {
-            const int j = p.frl ? sh.list_j[r] : sh.list_j[r] & 0xfff;
+            const int j = p.frl ? ent_j : ent_j & 0xfff;
             rec.first = (uint64_t)(wq0 + j);
             rec.mmpos = (uint32_t)(ap - j);  // super_kmer_view.hpp:132
         }
@@ -740,36 +749,25 @@ BL_DEV void emit_store(const ScanParams& p, const Record& rec, uint64_t g)
     }
 }
 
-template <int MODE, int W>
-BL_DEV void emit_ends(const ScanParams& p, const TileShared<MODE, W>& sh, int tid, int64_t q0, uint32_t n_e, uint64_t base_e)
+template <int MODE>
+BL_DEV void emit_end(const ScanParams& p, int64_t q0, uint32_t ent, uint64_t g)
 {
-    if (MODE == MODE_SUPERKMER) {
-        for (uint32_t r = tid; r < n_e; r += TPB) {
-            const uint64_t g = base_e + r;
-            const uint32_t ent = sh.list_e[r];
-            const int64_t pos = p.frl ? q0 + ent : wave_origin(p, q0, ent >> 12) + (ent & 0xfff);
-            if (p.out_last && g < p.capacity) p.out_last[g] = (uint64_t)pos;
-        }
-    }
+    const int64_t pos = p.frl ? q0 + ent : wave_origin(p, q0, ent >> 12) + (ent & 0xfff);
+    if (p.out_last && g < p.capacity) p.out_last[g] = (uint64_t)pos;
 }
 
-// whole phase in one go (emulation harness; the kernel interleaves 5a with the look-back)
-template <int MODE, int W>
-BL_DEV void phase_emit(const ScanParams& p, const TileShared<MODE, W>& sh, int tid, int64_t q0, uint32_t n_s, uint32_t n_e,
-                       uint64_t base_s, uint64_t base_e, Digest& dg)
+// whole phase for one thread: records tid, tid + TPB, ...
+template <int MODE>
+BL_DEV void phase_emit(const ScanParams& p, const TileLists& L, int tid, int64_t q0, uint32_t n_s, uint32_t n_e, uint64_t base_s, uint64_t base_e, Digest& dg)
 {
-    if (!BL_COLD(base_s + n_s > p.capacity)) {  // the usual case, uniform for the workgroup: no per-record capacity test
-        for (uint32_t r = tid; r < n_s; r += TPB) {
-            const Record rec = emit_prepare<MODE, W>(p, sh, q0, r, dg);
-            emit_store<MODE, false>(p, rec, base_s + r);
-        }
-    } else {
-        for (uint32_t r = tid; r < n_s; r += TPB) {
-            const Record rec = emit_prepare<MODE, W>(p, sh, q0, r, dg);
-            emit_store<MODE, true>(p, rec, base_s + r);
-        }
+    const bool fits = !BL_COLD(base_s + n_s > p.capacity);  // the usual case, uniform for the workgroup: no per-record capacity test
+    for (uint32_t r = tid; r < n_s; r += TPB) {
+        const Record rec = emit_prepare<MODE>(p, L.codes, q0, L.list_a[r], MODE == MODE_SUPERKMER ? L.list_j[r] : 0u, dg);
+        if (fits) emit_store<MODE, false>(p, rec, base_s + r);
+        else emit_store<MODE, true>(p, rec, base_s + r);
     }
-    emit_ends<MODE, W>(p, sh, tid, q0, n_e, base_e);
+    if (MODE == MODE_SUPERKMER)
+        for (uint32_t r = tid; r < n_e; r += TPB) emit_end<MODE>(p, q0, L.list_e[r], base_e + r);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -801,29 +799,37 @@ BL_DEV void kmer_thread(const KmerParams& p, const uint32_t* codes, const uint32
     roller_start(r, codes[tid], codes[tid + 1], codes[tid + 2], p.unit);
     Bits128 good, start;
     gather_flags(flags, tid, good, start);
-    uint32_t valid = window_valid_mask(good, start, p.unit) & 0xffffu;
     const int64_t j0 = q0 + 16 * (int64_t)tid;
+    // which of the lane's 16 positions count, as ONE mask (no 64-bit compare per position): a k-mer starts there, the position
+    // lies in the requested range, and — reference idiom — it is not the k-mer that ends its sequence (quirk Q1)
+    const uint32_t inrange = range_mask(p.first - j0, p.end - j0) & 0xffffu;
+    uint32_t ok = window_valid_mask(good, start, p.unit) & inrange;
+    if (p.drop_last) {
+        uint32_t last = (uint32_t)b128_shr(start, p.unit).lo & 0xffffu;  // a sequence starts right after the k-mer at s
+        const int64_t s_end = p.n_bases - p.unit - j0;                   // ... or the batch ends there
+        if (s_end >= 0 && s_end < S) last |= 1u << s_end;
+        ok &= ~last;
+    }
+    const bool any_out = p.out_value || p.out_hash || p.out_valid;  // uniform: the digest-only scan (C2) stores nothing
     BL_UNROLL
     for (int s = 0; s < S; ++s) {
         roller_step(r, s);
         const uint64_t fw = roller_fwd(r), rv = roller_rc(r);
         const uint64_t v = (p.canonical && rv < fw) ? rv : fw;
         const uint64_t h = murmur64(v, p.seed);
-        const int64_t j = j0 + s;
-        bool ok = ((valid >> s) & 1) && j >= p.first && j < p.end;
-        if (ok && p.drop_last) {
-            const int nxt = s + p.unit;
-            const bool seq_end = (start.lo >> nxt) & 1;  // nxt <= 47
-            ok = !(seq_end || j + p.unit >= p.n_bases);
-        }
-        if (ok) { acc.cnt += 1; acc.xv ^= v; acc.xh ^= h; acc.sh += h; }
-        if (j >= p.first && j < p.end) {
-            const int64_t o = j - p.first;
-            if (p.out_value) p.out_value[o] = ok ? v : 0;
-            if (p.out_hash) p.out_hash[o] = ok ? h : 0;
-            if (p.out_valid) p.out_valid[o] = ok ? 1 : 0;
+        const bool take = (ok >> s) & 1;
+        const uint64_t vm = take ? v : 0, hm = take ? h : 0;
+        acc.xv ^= vm;
+        acc.xh ^= hm;
+        acc.sh += hm;
+        if (any_out && ((inrange >> s) & 1)) {
+            const int64_t o = j0 + s - p.first;
+            if (p.out_value) p.out_value[o] = vm;
+            if (p.out_hash) p.out_hash[o] = hm;
+            if (p.out_valid) p.out_valid[o] = take ? 1 : 0;
         }
     }
+    acc.cnt += (unsigned)__builtin_popcount(ok);
 }
 
 }  // namespace bl

@@ -98,8 +98,9 @@ void run_tiles(ScanParams p, unsigned long long* result)
             }
             if (MODE == MODE_SUPERKMER)
                 for (uint32_t r = 0; r < n_e; ++r) sh->list_e[r] = se[tile * p.stride + r];
+            const TileLists lists{sh->codes, sh->list_a, sh->list_j, sh->list_e};
             for (int tid = 0; tid < TPB; ++tid)
-                phase_emit<MODE, 1>(p, *sh, tid, q0, n_s, n_e, base[tile] & 0xffffffffull, base[tile] >> 32, dg);
+                phase_emit<MODE>(p, lists, tid, q0, n_s, n_e, base[tile] & 0xffffffffull, base[tile] >> 32, dg);
         }
         delete sh;
     }
@@ -168,8 +169,9 @@ void run_tiles_frl(ScanParams p, unsigned long long* result)
             }
             if (MODE == MODE_SUPERKMER)
                 for (uint32_t r = 0; r < n_e; ++r) sh->list_e[r] = se[tile * p.stride + r];
+            const TileLists lists{sh->codes, sh->list_a, sh->list_j, sh->list_e};
             for (int tid = 0; tid < TPB; ++tid)
-                phase_emit<MODE, 1>(p, *sh, tid, q0, n_s, n_e, base[tile] & 0xffffffffull, base[tile] >> 32, dg);
+                phase_emit<MODE>(p, lists, tid, q0, n_s, n_e, base[tile] & 0xffffffffull, base[tile] >> 32, dg);
         }
         delete sh;
     }
