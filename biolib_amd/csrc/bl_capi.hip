@@ -72,8 +72,6 @@ struct Lane {
     size_t tile_buf_bytes = 0;
     uint16_t* slot_buf = nullptr;  // per-tile u16 record lists
     size_t slot_buf_bytes = 0;
-    uint64_t* last_buf = nullptr;  // super-k-mer scratch
-    size_t last_cap = 0;
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     hipEvent_t ev_count_done = nullptr;  // two-lane mode: recorded after this lane's pass-1 kernel
     bool count_recorded = false;
@@ -443,7 +441,6 @@ int bl_ctx_destroy(bl_ctx* c)
         if (l.ws) (void)hipFree(l.ws);
         if (l.tile_buf) (void)hipFree(l.tile_buf);
         if (l.slot_buf) (void)hipFree(l.slot_buf);
-        if (l.last_buf) (void)hipFree(l.last_buf);
         if (l.ev_start) (void)hipEventDestroy(l.ev_start);
         if (l.ev_count_done) (void)hipEventDestroy(l.ev_count_done);
         if (l.ev_stop) (void)hipEventDestroy(l.ev_stop);
@@ -828,7 +825,6 @@ int bl_scan_super_kmers(bl_ctx* c, const bl_batch* b, uint64_t first, uint64_t n
                         uint64_t capacity, bl_result* result)
 {
     if (m < 1 || k < m) return fail(BL_ERR_INVALID, "need 1 <= m <= k");
-    if (d_sizes && !d_first_pos) return fail(BL_ERR_INVALID, "d_first_pos is required when d_sizes is requested");
     if (!c) return fail(BL_ERR_INVALID, "ctx is NULL");
     bl::ScanParams p{};
     p.out_value = d_minimizers;
@@ -836,29 +832,10 @@ int bl_scan_super_kmers(bl_ctx* c, const bl_batch* b, uint64_t first, uint64_t n
     p.out_mmpos = d_mm_pos;
     p.out_hash = d_hashes;
     const bool wants = d_minimizers || d_first_pos || d_mm_pos || d_sizes || d_hashes;
-    if (d_sizes && capacity) {
-        Lane* ln = c->borrowed ? &c->lanes[0] : &c->lanes[c->next_lane];  // the lane begin_scan() will pick
-        if (ln->last_cap < capacity) {
-            BL_HIP(hipSetDevice(c->device));
-            BL_HIP(hipStreamSynchronize(c->borrowed ? c->user_stream : ln->own));
-            if (ln->last_buf) BL_HIP(hipFree(ln->last_buf));
-            ln->last_buf = nullptr;
-            ln->last_cap = 0;
-            BL_HIP(hipMalloc(&ln->last_buf, capacity * sizeof(uint64_t)));
-            ln->last_cap = capacity;
-        }
-        p.out_last = ln->last_buf;
-    }
+    p.out_size = d_sizes;  // from the group's own end event, inside the record pass
     int rc = scan_windows(bl::MODE_SUPERKMER, c, b, first, n, m, k - m + 1, seed, flags, p, wants ? capacity : 0, result);
     if (rc != BL_OK || p.n_tiles == 0) return rc;
-    // fold first so that result[0] (the record count) is final on the device, then derive the sizes
-    hipError_t e = bl::launch_reduce_shards(c->shards(), c->result(), (1u << 0) | (1u << 4), c->stream);
-    if (e != hipSuccess) return fail(BL_ERR_HIP, std::string("reduce_shards: ") + hipGetErrorString(e));
-    if (d_sizes && capacity) {
-        e = bl::launch_superkmer_size(d_first_pos, c->cur->last_buf, d_sizes, c->result(), capacity, c->stream);
-        if (e != hipSuccess) return fail(BL_ERR_HIP, std::string("superkmer_size: ") + hipGetErrorString(e));
-    }
-    return end_scan(c, (1u << 0) | (1u << 4), result, wants, capacity, flags, /*already_folded=*/true);
+    return end_scan(c, (1u << 0) | (1u << 4), result, wants, capacity, flags);
 }
 
 int bl_scan_syncmers(bl_ctx* c, const bl_batch* b, uint64_t first, uint64_t n, uint32_t k, uint32_t s, uint32_t start_offset,

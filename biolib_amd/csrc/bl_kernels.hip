@@ -194,13 +194,12 @@ __device__ __forceinline__ void emit_tile(const ScanParams& p, uint32_t* codes, 
     const uint32_t c1 = TPB + tid < needed ? sc[TPB + tid] : 0;
     const uint16_t* la = p.slots_a + slot;
     const uint16_t* lj = MODE == MODE_SUPERKMER ? p.slots_j + slot : nullptr;
-    const uint16_t* le = MODE == MODE_SUPERKMER ? p.slots_e + slot : nullptr;
     const bool in0 = tid < p.stride, in1 = TPB + tid < p.stride;  // inside the slot (its tail past n_s holds stale entries: never used)
     const uint32_t a0 = in0 ? la[tid] : 0, a1 = in1 ? la[TPB + tid] : 0;
-    uint32_t j0 = 0, j1 = 0, e0 = 0, e1 = 0;
+    uint32_t j0 = 0, j1 = 0;
     if (MODE == MODE_SUPERKMER) {
-        j0 = in0 ? lj[tid] : 0; j1 = in1 ? lj[TPB + tid] : 0;
-        e0 = in0 ? le[tid] : 0; e1 = in1 ? le[TPB + tid] : 0;
+        j0 = in0 ? lj[tid] : 0;
+        j1 = in1 ? lj[TPB + tid] : 0;
     }
     const uint32_t n_s = (uint32_t)cnt, n_e = (uint32_t)(cnt >> 32);
     if (n_s == 0 && n_e == 0) return;  // uniform for the workgroup
@@ -209,21 +208,19 @@ __device__ __forceinline__ void emit_tile(const ScanParams& p, uint32_t* codes, 
     if (TPB + tid < needed) codes[TPB + tid] = c1;
     __syncthreads();
     const bool fits = !BL_COLD(base_s + n_s > p.capacity);
+    TileLists L{codes, la, lj, MODE == MODE_SUPERKMER ? p.slots_e + slot : nullptr, MODE == MODE_SUPERKMER ? p.slots_e + slot + p.stride : nullptr};
+    const uint32_t d = (uint32_t)(base_s - base_e);  // 0 or 1 (see end_position)
     auto one = [&](uint32_t r, uint32_t ent, uint32_t ent_j) {
         const Record rec = emit_prepare<MODE>(p, codes, q0, ent, ent_j, dg);
         if (fits) emit_store<MODE, false>(p, rec, base_s + r);
         else emit_store<MODE, true>(p, rec, base_s + r);
+        if (MODE == MODE_SUPERKMER && p.out_size && (fits || base_s + r < p.capacity))
+            p.out_size[base_s + r] = (uint8_t)(end_position(p, L, tile, q0, r + d, n_e) - (int64_t)rec.first + 1);
     };
     if ((uint32_t)tid < n_s) one(tid, a0, j0);
     if ((uint32_t)(TPB + tid) < n_s) one(TPB + tid, a1, j1);
 #pragma unroll 1
     for (uint32_t r = 2 * TPB + tid; r < n_s; r += TPB) one(r, la[r], MODE == MODE_SUPERKMER ? lj[r] : 0u);  // rarely any
-    if (MODE == MODE_SUPERKMER) {
-        if ((uint32_t)tid < n_e) emit_end<MODE>(p, q0, e0, base_e + tid);
-        if ((uint32_t)(TPB + tid) < n_e) emit_end<MODE>(p, q0, e1, base_e + TPB + tid);
-#pragma unroll 1
-        for (uint32_t r = 2 * TPB + tid; r < n_e; r += TPB) emit_end<MODE>(p, q0, le[r], base_e + r);
-    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -423,15 +420,6 @@ __global__ void reduce_shards_kernel(const unsigned long long* shards, unsigned 
     result[slot] = acc;
 }
 
-// super-k-mer size = last k-mer - first k-mer + 1 (super_kmer_view.hpp:133); n = min(*count, capacity)
-__global__ void superkmer_size_kernel(const uint64_t* first, const uint64_t* last, uint8_t* size,
-                                      const unsigned long long* count, uint64_t capacity)
-{
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint64_t n = *count < capacity ? *count : capacity;
-    if (i < n) size[i] = (uint8_t)(last[i] - first[i] + 1);
-}
-
 // SURVEY.md §8d generator: base[i] = "ACGT"[(splitmix64(seed + (i>>5)) >> (2*(i&31))) & 3]
 // one thread = one splitmix word = 32 bases = two 16-byte stores
 __global__ void synth_kernel(uint8_t* bases, uint64_t first, uint64_t n, uint64_t seed)
@@ -614,15 +602,6 @@ hipError_t launch_kmers(const KmerParams& p, int n_blocks, hipStream_t stream)
 hipError_t launch_reduce_shards(const unsigned long long* shards, unsigned long long* result, uint32_t add_mask, hipStream_t stream)
 {
     hipLaunchKernelGGL(reduce_shards_kernel, dim3(1), dim3(64), 0, stream, shards, result, add_mask);
-    return hipGetLastError();
-}
-
-hipError_t launch_superkmer_size(const uint64_t* first, const uint64_t* last, uint8_t* size, const unsigned long long* count,
-                                 uint64_t capacity, hipStream_t stream)
-{
-    if (capacity == 0) return hipSuccess;
-    hipLaunchKernelGGL(superkmer_size_kernel, dim3((unsigned)((capacity + 255) / 256)), dim3(256), 0, stream, first, last, size, count,
-                       capacity);
     return hipGetLastError();
 }
 

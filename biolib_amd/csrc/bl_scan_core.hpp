@@ -68,7 +68,7 @@ struct ScanParams {
     uint64_t* out_hash;
     uint64_t* out_first;         // super-k-mer: position of the first k-mer of the group
     uint8_t* out_mmpos;          // super-k-mer: minimizer offset inside the first k-mer
-    uint64_t* out_last;          // super-k-mer: position of the last k-mer of the group (scratch)
+    uint8_t* out_size;           // super-k-mer: number of k-mers of the group (last k-mer - first k-mer + 1, super_kmer_view.hpp:133)
     uint64_t capacity;           // records the output arrays can hold
     // two-pass ordered compaction (no inter-workgroup communication inside a kernel):
     //   pass 1 (scan_count_kernel) writes per tile its record counts and its compacted u16 lists,

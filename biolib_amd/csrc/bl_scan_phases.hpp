@@ -693,7 +693,20 @@ struct TileLists {
     const uint16_t* list_a;  // [n_s]
     const uint16_t* list_j;  // [n_s]  super-k-mer mode
     const uint16_t* list_e;  // [n_e]  super-k-mer mode
+    const uint16_t* next_e;  // super-k-mer mode: list_e of the NEXT tile (its first entry closes a group this tile leaves open)
 };
+
+// Where a group ends.  Starts and ends pair up in global order, and at any point of the scan at most one group is open
+// (a group is <= w windows long, far shorter than a tile), so the r-th start of a tile pairs with local end r + d, where
+// d = (starts before this tile) - (ends before this tile) is 0 or 1; the one start a tile may leave without an end finds it
+// as the first end of the next tile.  The group's size follows without a scratch array or a second kernel.
+BL_DEV int64_t end_position(const ScanParams& p, const TileLists& L, uint32_t tile, int64_t q0, uint32_t e, uint32_t n_e)
+{
+    const bool here = e < n_e;
+    const uint32_t ent = here ? L.list_e[e] : L.next_e[0];
+    const int64_t tq0 = here ? q0 : (p.frl ? ((p.origin + (int64_t)(tile + 1) * p.stride) & ~15LL) : p.origin + (int64_t)(tile + 1) * p.stride);
+    return p.frl ? tq0 + ent : wave_origin(p, tq0, ent >> 12) + (ent & 0xfff);
+}
 
 // 5a: one record from its list entries.  Entries: (wave << 12) | wave-relative position, or — read-tiled scans — a flat
 // tile-relative position.
@@ -749,25 +762,20 @@ BL_DEV void emit_store(const ScanParams& p, const Record& rec, uint64_t g)
     }
 }
 
-template <int MODE>
-BL_DEV void emit_end(const ScanParams& p, int64_t q0, uint32_t ent, uint64_t g)
-{
-    const int64_t pos = p.frl ? q0 + ent : wave_origin(p, q0, ent >> 12) + (ent & 0xfff);
-    if (p.out_last && g < p.capacity) p.out_last[g] = (uint64_t)pos;
-}
-
 // whole phase for one thread: records tid, tid + TPB, ...
 template <int MODE>
-BL_DEV void phase_emit(const ScanParams& p, const TileLists& L, int tid, int64_t q0, uint32_t n_s, uint32_t n_e, uint64_t base_s, uint64_t base_e, Digest& dg)
+BL_DEV void phase_emit(const ScanParams& p, const TileLists& L, uint32_t tile, int tid, int64_t q0, uint32_t n_s, uint32_t n_e, uint64_t base_s, uint64_t base_e,
+                       Digest& dg)
 {
     const bool fits = !BL_COLD(base_s + n_s > p.capacity);  // the usual case, uniform for the workgroup: no per-record capacity test
+    const uint32_t d = (uint32_t)(base_s - base_e);        // 0 or 1: a group left open by the tiles before this one
     for (uint32_t r = tid; r < n_s; r += TPB) {
         const Record rec = emit_prepare<MODE>(p, L.codes, q0, L.list_a[r], MODE == MODE_SUPERKMER ? L.list_j[r] : 0u, dg);
         if (fits) emit_store<MODE, false>(p, rec, base_s + r);
         else emit_store<MODE, true>(p, rec, base_s + r);
+        if (MODE == MODE_SUPERKMER && p.out_size && base_s + r < p.capacity)
+            p.out_size[base_s + r] = (uint8_t)(end_position(p, L, tile, q0, r + d, n_e) - (int64_t)rec.first + 1);
     }
-    if (MODE == MODE_SUPERKMER)
-        for (uint32_t r = tid; r < n_e; r += TPB) emit_end<MODE>(p, q0, L.list_e[r], base_e + r);
 }
 
 // ------------------------------------------------------------------------------------------------

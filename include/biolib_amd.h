@@ -149,7 +149,7 @@ int bl_scan_hash_sample(bl_ctx* ctx, const bl_batch* batch, uint64_t first, uint
  * (m-mer, w = k - m + 1):
  *   d_minimizers[r] m-mer value, d_first_pos[r] global position of the group's first k-mer,
  *   d_mm_pos[r] minimizer offset inside that k-mer, d_sizes[r] number of k-mers (<= w),
- *   d_hashes[r] hash of the minimizer.  d_first_pos is required when d_sizes is wanted. */
+ *   d_hashes[r] hash of the minimizer.  Any of the arrays may be NULL. */
 int bl_scan_super_kmers(bl_ctx* ctx, const bl_batch* batch, uint64_t first, uint64_t n, uint32_t k, uint32_t m, uint64_t seed,
                         uint32_t flags, uint64_t* d_minimizers, uint64_t* d_first_pos, uint8_t* d_mm_pos, uint8_t* d_sizes,
                         uint64_t* d_hashes, uint64_t capacity, bl_result* result);

@@ -98,9 +98,9 @@ void run_tiles(ScanParams p, unsigned long long* result)
             }
             if (MODE == MODE_SUPERKMER)
                 for (uint32_t r = 0; r < n_e; ++r) sh->list_e[r] = se[tile * p.stride + r];
-            const TileLists lists{sh->codes, sh->list_a, sh->list_j, sh->list_e};
+            const TileLists lists{sh->codes, sh->list_a, sh->list_j, sh->list_e, MODE == MODE_SUPERKMER && tile + 1 < nt ? &se[(tile + 1) * p.stride] : sh->list_e};
             for (int tid = 0; tid < TPB; ++tid)
-                phase_emit<MODE>(p, lists, tid, q0, n_s, n_e, base[tile] & 0xffffffffull, base[tile] >> 32, dg);
+                phase_emit<MODE>(p, lists, (uint32_t)tile, tid, q0, n_s, n_e, base[tile] & 0xffffffffull, base[tile] >> 32, dg);
         }
         delete sh;
     }
@@ -169,9 +169,9 @@ void run_tiles_frl(ScanParams p, unsigned long long* result)
             }
             if (MODE == MODE_SUPERKMER)
                 for (uint32_t r = 0; r < n_e; ++r) sh->list_e[r] = se[tile * p.stride + r];
-            const TileLists lists{sh->codes, sh->list_a, sh->list_j, sh->list_e};
+            const TileLists lists{sh->codes, sh->list_a, sh->list_j, sh->list_e, MODE == MODE_SUPERKMER && tile + 1 < nt ? &se[(tile + 1) * p.stride] : sh->list_e};
             for (int tid = 0; tid < TPB; ++tid)
-                phase_emit<MODE>(p, lists, tid, q0, n_s, n_e, base[tile] & 0xffffffffull, base[tile] >> 32, dg);
+                phase_emit<MODE>(p, lists, (uint32_t)tile, tid, q0, n_s, n_e, base[tile] & 0xffffffffull, base[tile] >> 32, dg);
         }
         delete sh;
     }
@@ -312,17 +312,14 @@ void emu_super_kmers(const EmuBatch* b, uint64_t first, uint64_t n, unsigned k, 
 {
     ScanParams p{};
     fill_common(p, b->bases, b->n_bases, b->single ? nullptr : b->bits.data(), MODE_SUPERKMER, first, n, m, k - m + 1, seed, flags, b->read_len);
-    std::vector<uint64_t> last(capacity ? capacity : 1);
     p.out_value = out_min;
     p.out_first = out_first;
     p.out_mmpos = out_mmpos;
     p.out_hash = out_hash;
-    p.out_last = last.data();
+    p.out_size = out_size;
     p.capacity = capacity;
     std::memset(result, 0, 8 * sizeof(unsigned long long));
     run_mode<MODE_SUPERKMER>(p, result);
-    const uint64_t cnt = result[0] < capacity ? result[0] : capacity;
-    for (uint64_t i = 0; i < cnt; ++i) out_size[i] = (uint8_t)(last[i] - out_first[i] + 1);  // superkmer_size_kernel
 }
 
 void emu_syncmers(const EmuBatch* b, uint64_t first, uint64_t n, unsigned k, unsigned s, unsigned soff, unsigned eoff, uint64_t seed,
