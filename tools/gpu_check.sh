@@ -12,5 +12,6 @@ python - <<PY
 import json
 d = json.loads(open("gpurun_out/r2/bench_$TAG.json").read().strip().splitlines()[-1])
 r = d["roofline"]
-print("value", d["value"], "ms/step", d["ms_per_step"], "kernel ms", r["avg_kernel_ms"], "frac", r["frac"], {k: v for k, v in d.items() if k in ("other_configs",)})
+print("value", d["value"], "ms/step", d["ms_per_step"], "kernel ms", r["avg_kernel_ms"], "frac", r["frac"], "valu", r.get("valu", {}).get("frac"),
+      {k: v["value"] for k, v in d.get("other_configs", {}).items() if isinstance(v, dict)}, {k: v for k, v in d.get("cpu_baseline", {}).items() if k in ("value", "cores", "single_thread_value", "gpu_result_bit_identical_on_sample")})
 PY
