@@ -278,7 +278,9 @@ __global__ __launch_bounds__(64) void clock_probe_kernel(unsigned long long* out
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     const unsigned long long c0 = __builtin_amdgcn_s_memtime();
     unsigned long long t = t0;
-    while (t - t0 < ticks) {  // wall-clock bound: the loop ends after `ticks` x 10 ns whatever else happens
+    // ends when the host raises out[2] (bl_clock_probe_finish) or, at the latest, after `ticks` x 10 ns: a wall-clock bound that
+    // holds whatever else happens
+    while (t - t0 < ticks && __hip_atomic_load(&out[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0) {
         __builtin_amdgcn_s_sleep(127);
         t = __builtin_amdgcn_s_memrealtime();
     }
@@ -294,7 +296,7 @@ __global__ __launch_bounds__(64) void clock_probe_kernel(unsigned long long* out
 struct bl_clock_probe {
     int device;
     hipStream_t stream;
-    unsigned long long* pinned;  // [2]
+    unsigned long long* pinned;  // [0] cycles, [1] 10-ns ticks, [2] stop request (host -> device)
 };
 
 extern "C" int bl_clock_probe_start(bl_ctx* ctx, uint32_t duration_ms, bl_clock_probe** out)
@@ -305,9 +307,9 @@ extern "C" int bl_clock_probe_start(bl_ctx* ctx, uint32_t duration_ms, bl_clock_
     bl_clock_probe* p = new (std::nothrow) bl_clock_probe{bl_ctx_device(ctx), nullptr, nullptr};
     if (!p) return bl_set_error(BL_ERR_OOM, "host allocation failed");
     hipError_t e = hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&p->pinned), 2 * sizeof(unsigned long long), hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&p->pinned), 4 * sizeof(unsigned long long), hipHostMallocDefault);
     if (e == hipSuccess) {
-        p->pinned[0] = p->pinned[1] = 0;
+        p->pinned[0] = p->pinned[1] = p->pinned[2] = 0;
         hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, p->stream, p->pinned, (unsigned long long)duration_ms * 100000ull);
         e = hipGetLastError();
     }
@@ -325,6 +327,8 @@ extern "C" int bl_clock_probe_finish(bl_clock_probe* p, double* shader_ghz)
 {
     if (!p) return bl_set_error(BL_ERR_INVALID, "probe is NULL");
     (void)hipSetDevice(p->device);
+    __atomic_store_n(&p->pinned[2], 1ull, __ATOMIC_RELEASE);  // stop now: the probe must never outlive what it measures (a device-wide
+                                                              // synchronise would otherwise wait for it)
     hipError_t e = hipStreamSynchronize(p->stream);
     const double cycles = (double)p->pinned[0], ticks = (double)p->pinned[1];
     (void)hipHostFree(p->pinned);

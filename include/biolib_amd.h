@@ -252,8 +252,8 @@ int bl_expand_super_kmers(bl_ctx* ctx, const uint64_t* d_records, uint64_t n_gro
 int bl_probe_hbm(bl_ctx* ctx, uint64_t n_bytes, int iters, double* read_gbps, double* copy_gbps);
 
 /* Shader clock held while other work runs: bl_clock_probe_start launches one sleeping wave on its own stream that stamps the
- * shader-cycle and the 100 MHz real-time counters duration_ms apart (1..5000); bl_clock_probe_finish waits for it, returns
- * cycles / time in GHz and releases the probe.  Used by bench.py to price the VALU ceiling at the clock of the run. */
+ * shader-cycle and the 100 MHz real-time counters until bl_clock_probe_finish stops it (at the latest duration_ms later, 1..5000);
+ * finish returns cycles / time in GHz and releases the probe.  Finish it BEFORE any device-wide synchronise.  Used by bench.py to price the VALU ceiling at the clock of the run. */
 typedef struct bl_clock_probe bl_clock_probe;
 int bl_clock_probe_start(bl_ctx* ctx, uint32_t duration_ms, bl_clock_probe** out);
 int bl_clock_probe_finish(bl_clock_probe* probe, double* shader_ghz);
