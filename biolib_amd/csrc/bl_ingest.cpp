@@ -32,6 +32,8 @@
 #include <thread>
 #include <vector>
 
+#include <hip/hip_runtime_api.h>
+
 #include "../../include/biolib_amd.h"
 
 extern int bl_set_error(int code, const char* msg);  // bl_capi.hip
@@ -44,6 +46,31 @@ constexpr int BGZF_GROUP = 48;            // BGZF members inflated per job (~3 M
 struct Chunk {
     std::vector<unsigned char> bytes;
     bool ok = true;  // false: the stream is damaged from here on
+};
+
+// Byte vectors that have been used once and keep their storage: a fresh multi-megabyte vector costs a page fault per 4 KiB on
+// its first use, which is more than filling it costs.
+class SpareBuffers {
+public:
+    std::vector<unsigned char> take()
+    {
+        std::lock_guard<std::mutex> lk(m_);
+        if (spare_.empty()) return {};
+        std::vector<unsigned char> v = std::move(spare_.back());
+        spare_.pop_back();
+        v.clear();
+        return v;
+    }
+    void give(std::vector<unsigned char>&& v)
+    {
+        if (v.capacity() == 0) return;
+        std::lock_guard<std::mutex> lk(m_);
+        if (spare_.size() < 64) spare_.push_back(std::move(v));
+    }
+
+private:
+    std::mutex m_;
+    std::vector<std::vector<unsigned char>> spare_;
 };
 
 // Results of jobs handed out in order, finished in any order, consumed in order.
@@ -77,8 +104,8 @@ public:
     bool pop(Chunk& out)
     {
         std::unique_lock<std::mutex> lk(m_);
-        ready_.wait(lk, [&] { return (!slots_.empty() && slots_.front().done) || (closed_ && slots_.empty()); });
-        if (slots_.empty()) return false;
+        ready_.wait(lk, [&] { return abandoned_ || (!slots_.empty() && slots_.front().done) || (closed_ && slots_.empty()); });
+        if (abandoned_ || slots_.empty()) return false;
         out = std::move(*slots_.front().chunk);
         slots_.pop_front();
         space_.notify_all();
@@ -89,6 +116,7 @@ public:
         std::lock_guard<std::mutex> lk(m_);
         abandoned_ = true;
         space_.notify_all();
+        ready_.notify_all();
     }
     bool abandoned()
     {
@@ -115,7 +143,7 @@ public:
         std::vector<unsigned char> packed;  // whole BGZF members, back to back
         std::shared_ptr<Chunk> out;
     };
-    InflatePool(int n, OrderedQueue& q) : q_(q)
+    InflatePool(int n, OrderedQueue& q, SpareBuffers& spare) : q_(q), spare_(spare)
     {
         for (int i = 0; i < n; ++i) workers_.emplace_back([this] { run(); });
     }
@@ -183,10 +211,12 @@ private:
                 }
                 at += bsize;
             }
+            spare_.give(std::move(j.packed));
             q_.finish(j.out);
         }
     }
     OrderedQueue& q_;
+    SpareBuffers& spare_;
     std::mutex m_;
     std::condition_variable cv_;
     std::deque<Job> jobs_;
@@ -206,7 +236,7 @@ public:
         const bool bgzf = gz && got == 18 && head[2] == 8 && (head[3] & 4) && head[12] == 'B' && head[13] == 'C' && head[14] == 2 && head[15] == 0;
         if (bgzf) {
             kind_ = "bgzf";
-            pool_.reset(new InflatePool(threads < 1 ? 1 : threads, queue_));
+            pool_.reset(new InflatePool(threads < 1 ? 1 : threads, queue_, spare_));
             feeder_ = std::thread([this] { cut_bgzf(); });
         } else if (gz) {
             kind_ = "gzip";
@@ -224,6 +254,8 @@ public:
         if (f_) std::fclose(f_);
     }
     bool next(Chunk& c) { return queue_.pop(c); }
+    void recycle(std::vector<unsigned char>&& v) { spare_.give(std::move(v)); }
+    void abandon() { queue_.abandon(); }  // the consumer is leaving: next() returns false from now on
     const char* kind() const { return kind_; }
 
 private:
@@ -232,6 +264,7 @@ private:
         for (;;) {
             auto c = queue_.reserve();
             if (!c) return;
+            c->bytes = spare_.take();
             c->bytes.resize(CHUNK_BYTES);
             const size_t n = std::fread(c->bytes.data(), 1, CHUNK_BYTES, f_);
             c->bytes.resize(n);
@@ -252,6 +285,7 @@ private:
         while (ok) {
             auto c = queue_.reserve();
             if (!c) break;
+            c->bytes = spare_.take();
             c->bytes.resize(CHUNK_BYTES);
             z.next_out = c->bytes.data();
             z.avail_out = (uInt)CHUNK_BYTES;
@@ -299,6 +333,8 @@ private:
             if (!c) break;
             InflatePool::Job job;
             job.out = c;
+            c->bytes = spare_.take();
+            job.packed = spare_.take();
             for (int b = 0; b < BGZF_GROUP; ++b) {
                 unsigned char head[18];
                 const size_t got = std::fread(head, 1, sizeof(head), f_);
@@ -325,6 +361,7 @@ private:
 
     FILE* f_;
     OrderedQueue queue_;
+    SpareBuffers spare_;
     std::unique_ptr<InflatePool> pool_;
     std::thread feeder_;
     const char* kind_ = "plain";
@@ -345,6 +382,7 @@ public:
             Chunk c;
             if (!src_.next(c)) { ended_ = true; return false; }
             if (!c.ok) broken_ = true;
+            src_.recycle(std::move(cur_.bytes));
             cur_ = std::move(c);
             pos_ = 0;
             if (broken_ && cur_.bytes.empty()) { ended_ = true; return false; }
@@ -355,6 +393,7 @@ public:
     const unsigned char* here() const { return cur_.bytes.data() + pos_; }
     size_t left() const { return cur_.bytes.size() - pos_; }
     void skip(size_t n) { pos_ += n; }
+    void abandon() { src_.abandon(); }
 
 private:
     ByteSource& src_;
@@ -479,98 +518,202 @@ private:
     bool header_seen_ = false;  // the marker of the next record has been consumed already
 };
 
-// Raw text cut at record boundaries, for the device-side parser.
+// Raw text cut at record boundaries, for the device-side parser.  A producer thread runs ahead of the caller and fills a ring
+// of three span buffers that live as long as the reader (their pages are touched once, not once per span: first touches cost
+// more than everything else here; page-locked when the spans go to a device, so that the copy is one DMA); the caller holds
+// one span while the next ones are being assembled.
+//
+// Where a span may end is decided from its own last bytes, not by counting from the start of the stream:
+//   FASTQ (the stream opens with '@'): in front of a line that begins with '@' and whose second-next line begins with '+'.
+//     In a 4-line record only the header satisfies that: for a quality line beginning with '@' the second-next line is a
+//     sequence line, which cannot begin with '+'.
+//   FASTA: in front of a line that begins with '>'.
+struct SpanMemory {  // where span buffers come from
+    void* (*get)(size_t bytes);
+    void (*put)(void* p);
+};
+
+struct SpanBuf {
+    char* p = nullptr;
+    size_t cap = 0;
+    size_t n = 0;     // bytes of the span handed to the caller; what follows them opens the next span
+    int state = 0;    // 0 free, 1 ready, 2 held by the caller
+    int verdict = 1;  // 1 span, 0 end of stream, -1 damaged stream
+};
+
 class TextCutter {
 public:
-    explicit TextCutter(ByteSource& s) : in_(s) {}
-    // next span of at most `limit` bytes (more if a single record is longer) that ends at a record boundary:
-    // FASTQ (first byte '@'): after every 4th line, counted from the start of the stream; FASTA: before a line-initial '>'
-    // 1 = span ready, 0 = end of stream, -1 = damaged stream
-    int next(size_t limit, std::string& span)
+    static constexpr int RING = 3;
+    static constexpr size_t LOOK = 64u << 10;  // read this far past the limit before looking for the cut
+    TextCutter(ByteSource& s, size_t limit, SpanMemory mem) : in_(s), limit_(limit), mem_(mem) { worker_ = std::thread([this] { produce(); }); }
+    ~TextCutter()
     {
-        std::string buf;
-        buf.swap(carry_);  // always starts at a record boundary
-        size_t scanned = 0, best = 0, cut = 0;
-        uint64_t lines = 0;
-        bool have_best = false;
-        for (;;) {
-            if (!buf.empty() && !fmt_) fmt_ = buf[0] == '@' ? 'q' : 'a';
-            bool decided = false;
-            if (fmt_ == 'q') {
-                // FASTQ: only the line COUNT matters (a record is 4 lines): count the newlines of what is new in one pass
-                // (the compiler vectorises the loop), then walk back from the last one to the last multiple of four
-                const size_t upto = buf.size() < limit ? buf.size() : limit;
-                if (scanned < upto) {
-                    const char* q = buf.data();
-                    uint64_t add = 0;
-                    for (size_t i = scanned; i < upto; ++i) add += q[i] == '\n';
-                    lines += add;
-                    scanned = upto;
-                    size_t back = (size_t)(lines % 4), at = upto;  // drop `back` newlines from the end, then cut after the one before them
-                    bool found = lines >= 4;
-                    for (size_t drop = 0; found && drop <= back; ++drop) {
-                        const void* nl = at ? memrchr(q, '\n', at) : nullptr;
-                        if (!nl) { found = false; break; }
-                        at = (size_t)(static_cast<const char*>(nl) - q);
-                        if (drop == back) { best = at + 1; have_best = true; }
-                    }
-                }
-                if (buf.size() > limit && !have_best) {  // a single record longer than the limit: the first boundary beyond it
-                    while (scanned < buf.size()) {
-                        const void* nl = std::memchr(buf.data() + scanned, '\n', buf.size() - scanned);
-                        if (!nl) { scanned = buf.size(); break; }
-                        scanned = (size_t)(static_cast<const char*>(nl) - buf.data()) + 1;
-                        if (++lines % 4 == 0) { cut = scanned; decided = true; break; }
-                    }
-                } else if (buf.size() > limit) {
-                    scanned = limit + 1;  // everything up to the limit has been counted: `best` stands
-                }
-            }
-            while (fmt_ != 'q' && scanned < buf.size()) {
-                const void* nl = std::memchr(buf.data() + scanned, '\n', buf.size() - scanned);
-                if (!nl) {
-                    scanned = buf.size();
-                    break;
-                }
-                const size_t p = (size_t)(static_cast<const char*>(nl) - buf.data()) + 1;  // first byte of the next line
-                if (p >= buf.size()) break;  // the byte that decides is not here yet: this newline is looked at again
-                const bool boundary = buf[p] == '>';
-                scanned = p;
-                if (!boundary) continue;
-                if (p <= limit) {
-                    best = p;
-                    have_best = true;
-                } else {
-                    cut = have_best ? best : p;
-                    decided = true;
-                    break;
-                }
-            }
-            if (decided) break;
-            if (have_best && scanned > limit) {
-                cut = best;
-                break;
-            }
-            if (!in_.more()) {
-                if (in_.broken()) return -1;
-                if (buf.empty()) return 0;
-                cut = buf.size();  // the tail of the file
-                break;
-            }
-            buf.append(reinterpret_cast<const char*>(in_.here()), in_.left());
-            in_.skip(in_.left());
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            quit_ = true;
         }
-        if (in_.broken()) return -1;
-        carry_.assign(buf, cut, std::string::npos);
-        buf.resize(cut);
-        span.swap(buf);
+        cv_.notify_all();
+        in_.abandon();  // a producer waiting for bytes wakes up with "end of stream"
+        if (worker_.joinable()) worker_.join();
+        for (auto& b : ring_)
+            if (b.p) mem_.put(b.p);
+    }
+    size_t limit() const { return limit_; }
+    // next span (valid until the following call): 1 = span ready, 0 = end of stream, -1 = damaged stream
+    int next(const char** text, size_t* n)
+    {
+        std::unique_lock<std::mutex> lk(m_);
+        if (held_ >= 0) {
+            ring_[held_].state = 0;
+            held_ = -1;
+            cv_.notify_all();
+        }
+        if (ended_) return ended_verdict_;
+        SpanBuf& b = ring_[take_];
+        cv_.wait(lk, [&] { return b.state == 1; });
+        if (b.verdict != 1) {
+            ended_ = true;
+            ended_verdict_ = b.verdict;
+            return b.verdict;
+        }
+        b.state = 2;
+        held_ = take_;
+        take_ = (take_ + 1) % RING;
+        *text = b.p;
+        *n = b.n;
         return 1;
     }
 
 private:
+    bool grow(SpanBuf& b, size_t keep, size_t need)
+    {
+        if (need <= b.cap) return true;
+        size_t want = b.cap ? b.cap : (size_t)1 << 20;
+        while (want < need) want *= 4;
+        const size_t full = limit_ + LOOK + CHUNK_BYTES;  // what a span of ordinary records needs at most
+        if (want > full && need <= full) want = full;
+        char* q = static_cast<char*>(mem_.get(want));
+        if (!q) return false;
+        if (keep) std::memcpy(q, b.p, keep);
+        if (b.p) mem_.put(b.p);
+        b.p = q;
+        b.cap = want;
+        return true;
+    }
+    // is `at` (the first byte of a line) where a record begins?  -1: the bytes that decide are not in the buffer yet
+    int record_opens_at(const char* p, size_t filled, size_t at) const
+    {
+        if (at >= filled) return -1;
+        if (fmt_ != 'q') return p[at] == '>';
+        if (p[at] != '@') return 0;
+        const char* nl = static_cast<const char*>(std::memchr(p + at, '\n', filled - at));
+        if (!nl || (size_t)(nl + 1 - p) >= filled) return -1;
+        nl = static_cast<const char*>(std::memchr(nl + 1, '\n', filled - (size_t)(nl + 1 - p)));
+        if (!nl || (size_t)(nl + 1 - p) >= filled) return -1;
+        return nl[1] == '+';
+    }
+    // the last record boundary in (0, limit], else the first one beyond it; 0: none in the buffer
+    size_t find_cut(const char* p, size_t filled, size_t limit) const
+    {
+        size_t upto = limit < filled ? limit : filled;  // a newline at a position < upto opens a line at <= limit
+        if (fmt_ == 'q') {
+            for (int lines = 0; upto > 0 && lines < 16; ++lines) {  // a header is among any four consecutive lines
+                const char* nl = static_cast<const char*>(memrchr(p, '\n', upto));
+                if (!nl) break;
+                const size_t at = (size_t)(nl - p) + 1;
+                if (record_opens_at(p, filled, at) == 1) return at;
+                upto = (size_t)(nl - p);
+            }
+        } else {
+            size_t last = filled ? (limit < filled - 1 ? limit : filled - 1) : 0;  // the last position a cut may take
+            while (last > 0) {  // the last '>' that follows a newline
+                const char* gt = static_cast<const char*>(memrchr(p + 1, '>', last));  // positions 1 .. last
+                if (!gt) break;
+                const size_t at = (size_t)(gt - p);
+                if (p[at - 1] == '\n') return at;
+                last = at - 1;
+            }
+        }
+        size_t from = limit < filled ? limit : filled;  // a record longer than the limit: the first boundary after it
+        while (from < filled) {
+            const char* nl = static_cast<const char*>(std::memchr(p + from, '\n', filled - from));
+            if (!nl) break;
+            const size_t at = (size_t)(nl - p) + 1;
+            const int v = record_opens_at(p, filled, at);
+            if (v == 1) return at;
+            if (v < 0) break;
+            from = at;
+        }
+        return 0;
+    }
+    void produce()
+    {
+        int put = 0;
+        const char* carry = nullptr;  // the bytes behind the previous span's cut (they stay in the previous buffer until copied)
+        size_t carry_n = 0;
+        bool eof = false;
+        for (;;) {
+            SpanBuf* b;
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                b = &ring_[put];
+                cv_.wait(lk, [&] { return quit_ || b->state == 0; });
+                if (quit_) return;
+            }
+            int verdict = 1;
+            size_t filled = 0, cut = 0, want = limit_ + LOOK;
+            if (!grow(*b, 0, carry_n + 1)) verdict = -1;
+            if (verdict == 1 && carry_n) std::memcpy(b->p, carry, carry_n);
+            if (verdict == 1) filled = carry_n;
+            while (verdict == 1) {
+                if (filled && !fmt_) fmt_ = b->p[0] == '@' ? 'q' : 'a';
+                if (eof && filled == 0) { verdict = 0; break; }
+                if (eof && filled <= limit_) { cut = filled; break; }
+                if (filled >= want || eof) {
+                    cut = find_cut(b->p, filled, limit_);
+                    if (cut == 0 && eof) cut = filled;  // the tail of the file, whatever it is
+                    if (cut) break;
+                    want = filled + LOOK;  // one record longer than all this: keep reading
+                }
+                if (!in_.more()) {
+                    if (in_.broken()) { verdict = -1; break; }
+                    eof = true;
+                    continue;
+                }
+                if (in_.broken()) { verdict = -1; break; }
+                size_t add = in_.left();
+                if (add > want - filled) add = want - filled;
+                if (!grow(*b, filled, filled + add)) { verdict = -1; break; }
+                std::memcpy(b->p + filled, in_.here(), add);
+                in_.skip(add);
+                filled += add;
+            }
+            if (verdict == 1 && in_.broken()) verdict = -1;
+            b->n = cut;
+            b->verdict = verdict;
+            carry = b->p + cut;
+            carry_n = verdict == 1 ? filled - cut : 0;
+            {
+                std::lock_guard<std::mutex> lk(m_);
+                b->state = 1;
+            }
+            cv_.notify_all();
+            if (verdict != 1) return;
+            put = (put + 1) % RING;
+        }
+    }
+
     Cursor in_;
-    std::string carry_;
+    const size_t limit_;
+    const SpanMemory mem_;
     char fmt_ = 0;
+    SpanBuf ring_[RING];
+    std::mutex m_;
+    std::condition_variable cv_;
+    std::thread worker_;
+    int take_ = 0, held_ = -1;
+    bool quit_ = false, ended_ = false;
+    int ended_verdict_ = 0;
 };
 
 }  // namespace
@@ -582,7 +725,7 @@ struct bl_reader {
     Record rec;
     bool have_pending = false;  // a record was parsed but did not fit the previous batch
     // last batch
-    std::string bases, span;
+    std::string bases;
     std::vector<uint64_t> offsets;
     std::vector<std::string> names;
 };
@@ -682,19 +825,38 @@ int bl_reader_next_batch(bl_ctx* ctx, bl_reader* r, uint64_t max_bases, bl_batch
     return bl_batch_upload(ctx, r->bases.data(), r->bases.size(), r->offsets.data(), r->names.size(), out);
 }
 
+namespace {
+
+const SpanMemory HOST_MEMORY = {[](size_t n) { return std::malloc(n); }, [](void* p) { std::free(p); }};
+// page-locked, visible to every device: the H2D copy of a span is then a single DMA transfer at link speed
+const SpanMemory PINNED_MEMORY = {[](size_t n) {
+                                      void* p = nullptr;
+                                      return hipHostMalloc(&p, n, hipHostMallocPortable) == hipSuccess ? p : nullptr;
+                                  },
+                                  [](void* p) { (void)hipHostFree(p); }};
+
+int next_span(bl_reader* r, uint64_t max_bytes, const SpanMemory& mem, const char** text, uint64_t* n_bytes)
+{
+    if (r->records) return bl_set_error(BL_ERR_INVALID, "this reader is delivering records: records and spans cannot be mixed");
+    const size_t limit = max_bytes ? (size_t)max_bytes : (size_t)64 << 20;
+    if (!r->text) r->text.reset(new TextCutter(*r->source, limit, mem));
+    if (r->text->limit() != limit) return bl_set_error(BL_ERR_INVALID, "the span size of a reader is fixed by its first span call");
+    *text = nullptr;
+    *n_bytes = 0;
+    size_t n = 0;
+    const int rc = r->text->next(text, &n);
+    if (rc < 0) return bl_set_error(BL_ERR_INVALID, "error reading the (compressed) stream");
+    if (rc == 0) return 1;  // end of file
+    *n_bytes = n;
+    return BL_OK;
+}
+
+}  // namespace
+
 int bl_reader_next_text(bl_reader* r, uint64_t max_bytes, const char** text, uint64_t* n_bytes)
 {
     if (!r || !text || !n_bytes) return bl_set_error(BL_ERR_INVALID, "NULL argument");
-    if (r->records) return bl_set_error(BL_ERR_INVALID, "this reader is delivering records: records and spans cannot be mixed");
-    if (!r->text) r->text.reset(new TextCutter(*r->source));
-    *text = nullptr;
-    *n_bytes = 0;
-    const int rc = r->text->next(max_bytes ? (size_t)max_bytes : (size_t)256 << 20, r->span);
-    if (rc < 0) return bl_set_error(BL_ERR_INVALID, "error reading the (compressed) stream");
-    if (rc == 0) return 1;  // end of file
-    *text = r->span.data();
-    *n_bytes = r->span.size();
-    return BL_OK;
+    return next_span(r, max_bytes, HOST_MEMORY, text, n_bytes);
 }
 
 int bl_reader_next_batch_device(bl_ctx* ctx, bl_reader* r, uint64_t max_text_bytes, bl_batch** out, uint64_t* n_seqs, uint64_t* n_bases)
@@ -705,7 +867,7 @@ int bl_reader_next_batch_device(bl_ctx* ctx, bl_reader* r, uint64_t max_text_byt
     if (n_bases) *n_bases = 0;
     const char* text = nullptr;
     uint64_t n = 0;
-    const int rc = bl_reader_next_text(r, max_text_bytes, &text, &n);
+    const int rc = next_span(r, max_text_bytes, PINNED_MEMORY, &text, &n);
     if (rc != BL_OK) return rc == 1 ? BL_OK : rc;  // end of file: *out stays NULL
     return bl_batch_from_text(ctx, text, n, out, n_seqs, n_bases);
 }

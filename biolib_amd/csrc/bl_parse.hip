@@ -14,6 +14,7 @@
 extern int bl_set_error(int code, const char* msg);
 extern hipStream_t bl_ctx_stream(bl_ctx* ctx);
 extern int bl_ctx_device(bl_ctx* ctx);
+extern void* bl_ctx_scratch(bl_ctx* ctx, int slot, size_t bytes);  // bl_capi.hip: grow-only device scratch that lives with the context
 extern int bl_batch_adopt_device(bl_ctx* ctx, void* d_bases, uint64_t n_bases, uint64_t* d_offsets, uint64_t n_seqs, bl_batch** out);  // bl_capi.hip
 
 namespace {
@@ -196,17 +197,17 @@ extern "C" int bl_batch_from_text(bl_ctx* ctx, const char* text, uint64_t n_byte
     const bool open_last_line = text[n_bytes - 1] != '\n';  // the last line has no terminator: a virtual one is added
 
     hipStream_t s = bl_ctx_stream(ctx);
+    // Temporary arrays come from the context's grow-only scratch (slot 0: text and block counts, slot 1: per-line arrays,
+    // slot 2: scan workspace): a file is parsed span after span, and a dozen hipMalloc / hipFree per span cost more than the
+    // kernels.  Only the two arrays the batch keeps are allocated here.
     uint8_t* d_text = nullptr;
     unsigned long long *d_blk = nullptr, *d_line_end = nullptr, *d_len = nullptr, *d_hdr = nullptr, *d_rec = nullptr, *d_dst = nullptr, *d_offsets = nullptr;
     unsigned int* d_err = nullptr;
     void* d_tmp = nullptr;
     uint8_t* d_bases = nullptr;
     bool handed_over = false;  // d_bases / d_offsets now belong to the batch
-    auto cleanup = [&]() {     // every exit path: the scratch always, the outputs unless the batch has adopted them
+    auto cleanup = [&]() {     // every exit path: nothing may still be running on the scratch; the outputs go unless adopted
         (void)hipStreamSynchronize(s);
-        for (void* p : {(void*)d_text, (void*)d_blk, (void*)d_line_end, (void*)d_len, (void*)d_hdr, (void*)d_rec, (void*)d_dst, (void*)d_err, d_tmp})
-            if (p) (void)hipFree(p);
-        d_text = nullptr; d_blk = d_line_end = d_len = d_hdr = d_rec = d_dst = nullptr; d_err = nullptr; d_tmp = nullptr;
         if (!handed_over) {
             if (d_bases) (void)hipFree(d_bases);
             if (d_offsets) (void)hipFree(d_offsets);
@@ -218,16 +219,20 @@ extern "C" int bl_batch_from_text(bl_ctx* ctx, const char* text, uint64_t n_byte
         cleanup();
         return bl_set_error(code, msg);
     };
+    auto up256 = [](size_t x) { return (x + 255) & ~(size_t)255; };
 
     P_HIP(hipSetDevice(bl_ctx_device(ctx)));
     const uint64_t n = n_bytes;
     const unsigned n_blocks = (unsigned)((n + BYTES_PER_BLOCK - 1) / BYTES_PER_BLOCK);
-    P_HIP(hipMalloc(&d_text, n + 64));
+    const size_t text_bytes = up256(n + 64), blk_bytes = up256(2 * ((size_t)n_blocks + 1) * sizeof(unsigned long long));
+    unsigned char* a0 = static_cast<unsigned char*>(bl_ctx_scratch(ctx, 0, text_bytes + blk_bytes + 256));
+    if (!a0) return fail_free(BL_ERR_OOM, "device allocation failed (text scratch)");
+    d_text = a0;
+    d_blk = reinterpret_cast<unsigned long long*>(a0 + text_bytes);  // counts, then their exclusive prefix
+    d_err = reinterpret_cast<unsigned int*>(a0 + text_bytes + blk_bytes);
     P_HIP(hipMemcpyAsync(d_text, text, n, hipMemcpyHostToDevice, s));
-    P_HIP(hipMalloc(&d_blk, 2 * ((size_t)n_blocks + 1) * sizeof(unsigned long long)));  // counts, then their exclusive prefix
     unsigned long long* d_blk_base = d_blk + n_blocks + 1;
     P_HIP(hipMemsetAsync(d_blk + n_blocks, 0, sizeof(unsigned long long), s));
-    P_HIP(hipMalloc(&d_err, sizeof(unsigned int)));
     P_HIP(hipMemsetAsync(d_err, 0, sizeof(unsigned int), s));
     hipLaunchKernelGGL(count_newlines_kernel, dim3(n_blocks), dim3(PB), 0, s, d_text, n, d_blk);
 
@@ -235,7 +240,9 @@ extern "C" int bl_batch_from_text(bl_ctx* ctx, const char* text, uint64_t n_byte
     size_t tmp_bytes = 0, need = 0;
     P_HIP(rocprim::exclusive_scan(nullptr, need, d_blk, d_blk_base, 0ull, (size_t)n_blocks + 1, rocprim::plus<unsigned long long>(), s));
     tmp_bytes = need;
-    P_HIP(hipMalloc(&d_tmp, tmp_bytes));
+    // the other two scans run over n_lines <= n_blocks * BYTES_PER_BLOCK items; their workspace is asked for again below
+    d_tmp = bl_ctx_scratch(ctx, 2, tmp_bytes ? tmp_bytes : 16);
+    if (!d_tmp) return fail_free(BL_ERR_OOM, "device allocation failed (scan scratch)");
     P_HIP(rocprim::exclusive_scan(d_tmp, tmp_bytes, d_blk, d_blk_base, 0ull, (size_t)n_blocks + 1, rocprim::plus<unsigned long long>(), s));
     unsigned long long n_newlines = 0;
     P_HIP(hipMemcpyAsync(&n_newlines, d_blk_base + n_blocks, sizeof(n_newlines), hipMemcpyDeviceToHost, s));
@@ -257,23 +264,38 @@ extern "C" int bl_batch_from_text(bl_ctx* ctx, const char* text, uint64_t n_byte
         n_lines -= excess;
     }
 
-    P_HIP(hipMalloc(&d_line_end, (n_lines_raw + 1) * sizeof(unsigned long long)));
+    {
+        const size_t per = up256((n_lines_raw + 2) * sizeof(unsigned long long));
+        unsigned char* a1 = static_cast<unsigned char*>(bl_ctx_scratch(ctx, 1, 5 * per));
+        if (!a1) return fail_free(BL_ERR_OOM, "device allocation failed (line scratch)");
+        d_line_end = reinterpret_cast<unsigned long long*>(a1);
+        d_len = reinterpret_cast<unsigned long long*>(a1 + per);
+        d_hdr = reinterpret_cast<unsigned long long*>(a1 + 2 * per);
+        d_rec = reinterpret_cast<unsigned long long*>(a1 + 3 * per);
+        d_dst = reinterpret_cast<unsigned long long*>(a1 + 4 * per);
+    }
     hipLaunchKernelGGL(newline_positions_kernel, dim3(n_blocks), dim3(PB), 0, s, d_text, n, d_blk_base, d_line_end);
     if (open_last_line) P_HIP(hipMemcpyAsync(d_line_end + n_newlines, &n, sizeof(unsigned long long), hipMemcpyHostToDevice, s));  // virtual '\n'
-    P_HIP(hipMalloc(&d_len, (n_lines + 1) * sizeof(unsigned long long)));
-    P_HIP(hipMalloc(&d_hdr, (n_lines + 1) * sizeof(unsigned long long)));
-    P_HIP(hipMalloc(&d_rec, (n_lines + 1) * sizeof(unsigned long long)));
-    P_HIP(hipMalloc(&d_dst, (n_lines + 1) * sizeof(unsigned long long)));
     P_HIP(hipMemsetAsync(d_len + n_lines, 0, sizeof(unsigned long long), s));
     const unsigned lb = (unsigned)((n_lines + 255) / 256);
     hipLaunchKernelGGL(classify_lines_kernel, dim3(lb), dim3(256), 0, s, d_text, d_line_end, n_lines, fastq ? 1 : 0, d_len, d_hdr, d_err);
 
     P_HIP(rocprim::inclusive_scan(nullptr, need, d_hdr, d_rec, (size_t)n_lines, rocprim::plus<unsigned long long>(), s));
-    if (need > tmp_bytes) { P_HIP(hipStreamSynchronize(s)); P_HIP(hipFree(d_tmp)); d_tmp = nullptr; tmp_bytes = need; P_HIP(hipMalloc(&d_tmp, tmp_bytes)); }
+    if (need > tmp_bytes) {
+        P_HIP(hipStreamSynchronize(s));
+        tmp_bytes = need;
+        d_tmp = bl_ctx_scratch(ctx, 2, tmp_bytes);
+        if (!d_tmp) return fail_free(BL_ERR_OOM, "device allocation failed (scan scratch)");
+    }
     P_HIP(rocprim::inclusive_scan(d_tmp, need, d_hdr, d_rec, (size_t)n_lines, rocprim::plus<unsigned long long>(), s));
     if (!fastq) hipLaunchKernelGGL(mask_leading_lines_kernel, dim3(lb), dim3(256), 0, s, d_rec, d_len, n_lines);
     P_HIP(rocprim::exclusive_scan(nullptr, need, d_len, d_dst, 0ull, (size_t)n_lines + 1, rocprim::plus<unsigned long long>(), s));
-    if (need > tmp_bytes) { P_HIP(hipStreamSynchronize(s)); P_HIP(hipFree(d_tmp)); d_tmp = nullptr; tmp_bytes = need; P_HIP(hipMalloc(&d_tmp, tmp_bytes)); }
+    if (need > tmp_bytes) {
+        P_HIP(hipStreamSynchronize(s));
+        tmp_bytes = need;
+        d_tmp = bl_ctx_scratch(ctx, 2, tmp_bytes);
+        if (!d_tmp) return fail_free(BL_ERR_OOM, "device allocation failed (scan scratch)");
+    }
     P_HIP(rocprim::exclusive_scan(d_tmp, need, d_len, d_dst, 0ull, (size_t)n_lines + 1, rocprim::plus<unsigned long long>(), s));
 
     unsigned long long total = 0, n_records = 0;

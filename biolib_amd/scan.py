@@ -539,8 +539,9 @@ class Reader:
                 return
             yield Batch(ctx, b)
 
-    def batches(self, ctx, max_bases=0):
-        """yield (Batch, names, offsets) of whole records holding at most max_bases bases each"""
+    def batches(self, ctx, max_bases=0, names=True):
+        """yield (Batch, names, offsets) of whole records holding at most max_bases bases each (names=False: the list stays
+        empty — one call per name is what a Python loop over millions of short reads spends its time on)"""
         while True:
             b, ns, nb = C.c_void_p(), C.c_uint64(), C.c_uint64()
             check(self._lib.bl_reader_next_batch(ctx._h, self._h, int(max_bases), C.byref(b), C.byref(ns), C.byref(nb)))
@@ -549,5 +550,5 @@ class Reader:
             offs_p, n2 = C.c_void_p(), C.c_uint64()
             check(self._lib.bl_reader_last_batch(self._h, None, C.byref(offs_p), C.byref(n2)))
             offs = np.ctypeslib.as_array(C.cast(offs_p, C.POINTER(C.c_uint64)), shape=(n2.value + 1,)).copy()
-            names = [self._lib.bl_reader_last_name(self._h, i).decode("latin1") for i in range(n2.value)]
-            yield Batch(ctx, b), names, offs
+            nm = [self._lib.bl_reader_last_name(self._h, i).decode("latin1") for i in range(n2.value)] if names else []
+            yield Batch(ctx, b), nm, offs

@@ -190,12 +190,14 @@ int bl_reader_next_record(bl_reader* reader, const char** name, const char** seq
 /* Next batch of whole records holding at most max_bases bases (0 = the rest of the file; always at least one
  * record), uploaded to the device.  At end of file *out is NULL and *n_seqs is 0. */
 int bl_reader_next_batch(bl_ctx* ctx, bl_reader* reader, uint64_t max_bases, bl_batch** out, uint64_t* n_seqs, uint64_t* n_bases);
-/* The high-throughput path for regular files: the decompressed TEXT, cut at record boundaries (FASTQ: every 4 lines; FASTA: before
- * a line-initial '>'), goes to the device-side parser (bl_batch_from_text) — parallel inflate, one H2D copy, parsing on the GPU.
- * bl_reader_next_text hands out the next span of at most max_bytes (0 = 256 MiB; a longer single record is not split), valid
- * until the next call, 1 at end of file; bl_reader_next_batch_device parses it on the device (names are not kept; *out NULL at
- * end of file; BL_ERR_INVALID for layouts the device parser refuses — reopen and use the record calls).  Records and spans
- * cannot be mixed on one reader. */
+/* The high-throughput path for regular files: the decompressed TEXT, cut at record boundaries (4-line FASTQ: in front of a header
+ * line, recognised by the '+' line two lines on; FASTA: before a line-initial '>'), goes to the device-side parser
+ * (bl_batch_from_text) — parallel inflate, one H2D copy, parsing on the GPU.  A thread of the reader assembles the next spans
+ * while the caller works on the current one, in buffers that live with the reader (page-locked for bl_reader_next_batch_device).
+ * bl_reader_next_text hands out the next span of at most max_bytes (0 = 64 MiB; a longer single record is not split), valid
+ * until the next call, 1 at end of file; max_bytes is fixed by the first call (BL_ERR_INVALID if a later call differs).
+ * bl_reader_next_batch_device parses the span on the device (names are not kept; *out NULL at end of file; BL_ERR_INVALID for
+ * layouts the device parser refuses — reopen and use the record calls).  Records and spans cannot be mixed on one reader. */
 int bl_reader_next_text(bl_reader* reader, uint64_t max_bytes, const char** text, uint64_t* n_bytes);
 int bl_reader_next_batch_device(bl_ctx* ctx, bl_reader* reader, uint64_t max_text_bytes, bl_batch** out, uint64_t* n_seqs, uint64_t* n_bases);
 /* Host copy of the batch produced last: concatenated bases, offsets[n_seqs+1], names. */

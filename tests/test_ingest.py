@@ -295,6 +295,38 @@ def test_text_spans_cut_at_record_boundaries(tmp_path, kind):
             assert max(len(s) for s in spans) <= limit and len(spans) >= len(text) // limit
 
 
+@pytest.mark.parametrize("kind", ["fastq", "fastq_crlf", "fasta"])
+def test_text_spans_cut_awkward_records(tmp_path, kind):
+    """the cut is found from the last bytes of a span: quality lines that open with '@' or '+', '>' inside FASTA headers and
+    sequence lines next to the limit, one record far longer than the limit, CRLF line ends; every span must open a record and
+    hold whole records only (the host record reader, pinned against the reference's, parses each span to the same sequences)"""
+    import biolib_amd
+
+    rng = np.random.default_rng(5)
+    seqs = [bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), int(n)).tobytes()) for n in rng.integers(1, 120, 4000)]
+    seqs[1500] = bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), 50_000).tobytes())  # longer than the limits below
+    nl = b"\r\n" if kind == "fastq_crlf" else b"\n"
+    if kind.startswith("fastq"):
+        first = [b"@", b"+", b"I", b"@", b">"]
+        text = b"".join(b"@r%d x@y +z" % i + nl + s + nl + b"+" + nl + (first[i % 5] + b"@" * (len(s) - 1))[:len(s)] + nl for i, s in enumerate(seqs))
+    else:
+        text = b"".join(b">c%d a>b >c" % i + nl + nl.join(s[j:j + 37] for j in range(0, len(s), 37)) + nl for i, s in enumerate(seqs))
+    path = tmp_path / "t.txt"
+    path.write_bytes(text)
+    for limit in (700, 4096, 1 << 16):
+        spans = list(biolib_amd.Reader(path).text_spans(limit))
+        assert b"".join(spans) == text
+        got = []
+        for i, sp in enumerate(spans):
+            assert sp[:1] == (b"@" if kind.startswith("fastq") else b">")
+            assert len(sp) <= limit or len(sp) < 110_000  # only the span of the long record may exceed the limit
+            q = tmp_path / "span.txt"
+            q.write_bytes(sp)
+            got += [s for _, s in biolib_amd.Reader(q).records()]
+        assert got == seqs
+        assert sum(len(sp) > limit for sp in spans) <= 1
+
+
 @pytest.mark.gpu
 def test_bgzf_to_device_parser_to_scan(tmp_path):
     """.gz -> parallel inflate -> text spans -> device-side parser -> scan, against the oracle on the same reads"""
