@@ -1,0 +1,501 @@
+// bl_inflate_core.hpp — DEFLATE (RFC 1951) decoder for ONE wavefront per BGZF member, written from the format.
+//
+// A BGZF file (bgzip, SAM spec §4.1) is a chain of gzip members of at most 64 KiB of text each, every one an independent deflate
+// stream: the members of a span are inflated side by side on the GPU, one wave each, so that compressed FASTA / FASTQ crosses
+// PCIe compressed and the host only reads the file and walks the member headers (bl_ingest.cpp).
+//
+// How one wave decodes a stream.  Decoding is sequential (a symbol's position depends on the lengths of all before it), so the
+// 64 lanes run the SAME decoder on the same bits: every lookup is an LDS broadcast and every branch is uniform.  The lanes
+// earn their keep where the format has width:
+//   * building a code's lookup table: one symbol per lane
+//   * a match (length, distance): up to 258 bytes copied 64 at a time inside the window
+//   * writing text to HBM: the window is flushed in 16 KiB halves, 16 bytes per lane per store
+//   * the input: each lane holds one dword of the current 256-byte chunk; the decoder takes the next dword with a readlane,
+//     and the following chunk is already on its way
+// The last 32 KiB of text (the deflate window) live in LDS as a ring addressed by the text position plus the low four bits of
+// the member's destination address, so that 16-byte pieces of ring and of HBM line up whatever the destination is.
+//
+// A damaged stream must end in an error, never in a fault or a hang: every output position is checked against the member's
+// stated size, every distance against the text produced so far, every code set against the Kraft sum (over-subscribed and
+// incomplete sets are refused the way zlib refuses them), and the symbol loop stops as soon as it has consumed more bits than
+// the member holds.
+//
+// The same source compiles for the host (BL_INFLATE_EMU: lane loops instead of lanes, arrays instead of LDS) so that the
+// decoder is tested on the CPU against zlib over fuzzed and damaged streams before it ever runs on a GPU (tests/emu/).
+#pragma once
+#include <cstdint>
+
+#ifdef BL_INFLATE_EMU
+#define BL_IDEV inline
+#define BL_LANES(l) for (int l = 0; l < 64; ++l)
+#define BL_WAVE_SYNC() ((void)0)
+#else
+#define BL_IDEV __device__ __forceinline__
+#define BL_LANES(l) for (int l = (int)(threadIdx.x & 63u), once_ = 1; once_; once_ = 0)
+// LDS operations of one wave complete in program order; the fence keeps the compiler from moving accesses across the point
+// where the lanes exchange roles (written by one lane, read by another)
+#define BL_WAVE_SYNC()                                              \
+    do {                                                            \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      \
+        __builtin_amdgcn_wave_barrier();                            \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");      \
+    } while (0)
+#endif
+
+namespace bl_inflate {
+
+constexpr int WINDOW = 32768;  // bytes of text kept in LDS: the furthest a match may reach back
+constexpr int FLUSH = 16384;   // the window goes to HBM in halves
+constexpr int LL_ROOT = 11;    // literal/length codes up to this many bits decode with one lookup
+constexpr int D_ROOT = 9;      // distance codes
+constexpr int CL_ROOT = 7;     // code-length codes are never longer
+constexpr int MAX_LL = 288, MAX_D = 32, MAX_CODES = MAX_LL + MAX_D;
+
+enum Status : uint32_t {
+    OK = 0,
+    ERR_BLOCK_TYPE = 1,    // reserved block type
+    ERR_STORED = 2,        // stored block: LEN / NLEN mismatch
+    ERR_HEADER = 3,        // dynamic block: too many codes, bad repeat, no end-of-block code
+    ERR_CODE_SET = 4,      // over-subscribed or incomplete code
+    ERR_SYMBOL = 5,        // bits that are no code, or a reserved symbol
+    ERR_DISTANCE = 6,      // match reaches in front of the member's text
+    ERR_OVERRUN = 7,       // more text than the member says it holds
+    ERR_INPUT = 8,         // ran past the end of the member's data
+    ERR_SIZE = 9,          // stream ended with less text than stated
+};
+
+struct CodeTable {  // canonical decoder for the codes longer than the root: symbols ordered by (length, symbol)
+    uint32_t count[16];
+};
+
+struct Shared {
+    uint8_t ring[WINDOW];
+    uint16_t ll_table[1 << LL_ROOT];  // (symbol << 4) | length, 0 = longer than the root (or no code)
+    uint16_t d_table[1 << D_ROOT];
+    uint16_t cl_table[1 << CL_ROOT];
+    uint8_t lens[MAX_CODES + 16];      // code lengths: literal/length codes, then distance codes
+    uint16_t code[MAX_CODES];          // canonical code of each symbol
+    uint16_t ll_sorted[MAX_LL], d_sorted[MAX_D], cl_sorted[32];
+    CodeTable ll, d, cl;
+    uint32_t next[16];                 // table building: next free slot of each length among the sorted symbols
+};
+
+// Input: dwords of the member's deflate data.  `word(i)` may be asked for any i >= 0 in increasing order; beyond the data it
+// returns zeros (the caller notices from the bit count).
+#ifdef BL_INFLATE_EMU
+struct Input {
+    const uint8_t* data;
+    uint32_t n_bytes;
+    uint32_t taken = 0;  // dwords handed out
+    Input(const uint8_t* d, uint32_t n) : data(d), n_bytes(n) {}
+    uint32_t next_word()
+    {
+        uint32_t w = 0;
+        for (int b = 0; b < 4; ++b) {
+            const uint32_t at = taken * 4 + b;
+            if (at < n_bytes) w |= (uint32_t)data[at] << (8 * b);
+        }
+        ++taken;
+        return w;
+    }
+    uint32_t lead_bits() const { return 0; }
+};
+#else
+struct Input {
+    const uint32_t* words;  // the data's first byte lies in words[0] (lead bytes in front of it are skipped by the bit reader)
+    uint32_t max_word;      // highest index that may be loaded (the buffer is padded accordingly)
+    uint32_t lead;          // bytes of words[0] in front of the data
+    uint32_t cur, nxt;      // this lane's dword of the current / next 64-dword chunk
+    uint32_t chunk = 0, idx = 0, taken = 0;
+    __device__ __forceinline__ uint32_t load(uint32_t c) const
+    {
+        uint32_t i = c * 64u + (threadIdx.x & 63u);
+        if (i > max_word) i = max_word;
+        return __builtin_nontemporal_load(words + i);
+    }
+    __device__ __forceinline__ Input(const uint8_t* data, uint32_t n_bytes, const uint8_t* buffer_end)
+    {
+        const uintptr_t a = reinterpret_cast<uintptr_t>(data);
+        lead = (uint32_t)(a & 3u);
+        words = reinterpret_cast<const uint32_t*>(a - lead);
+        const uintptr_t last = (reinterpret_cast<uintptr_t>(buffer_end) & ~(uintptr_t)3) - 4;  // last whole dword inside the buffer
+        max_word = last >= reinterpret_cast<uintptr_t>(words) ? (uint32_t)((last - reinterpret_cast<uintptr_t>(words)) >> 2) : 0u;
+        (void)n_bytes;
+        cur = load(0);
+        nxt = load(1);
+    }
+    __device__ __forceinline__ uint32_t next_word()
+    {
+        const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)cur, (int)idx);
+        ++taken;
+        if (++idx == 64u) {
+            idx = 0;
+            cur = nxt;
+            ++chunk;
+            nxt = load(chunk + 1);
+        }
+        return w;
+    }
+    __device__ __forceinline__ uint32_t lead_bits() const { return lead * 8u; }
+};
+#endif
+
+struct Bits {
+    uint64_t bb = 0;
+    int nb = 0;
+    template <class In>
+    BL_IDEV void start(In& in)
+    {
+        bb = in.next_word();
+        nb = 32;
+        const int skip = (int)in.lead_bits();
+        bb >>= skip;
+        nb -= skip;
+    }
+    template <class In>
+    BL_IDEV void need32(In& in)  // at least 33 bits afterwards
+    {
+        if (nb <= 32) {
+            bb |= (uint64_t)in.next_word() << nb;
+            nb += 32;
+        }
+    }
+    BL_IDEV uint32_t peek(int n) const { return (uint32_t)bb & ((1u << n) - 1u); }
+    BL_IDEV void drop(int n)
+    {
+        bb >>= n;
+        nb -= n;
+    }
+    BL_IDEV uint32_t take(int n)
+    {
+        const uint32_t v = peek(n);
+        drop(n);
+        return v;
+    }
+};
+
+BL_IDEV uint32_t reverse_bits(uint32_t v, int n)  // the low n bits of v, reversed
+{
+    v = ((v >> 1) & 0x55555555u) | ((v & 0x55555555u) << 1);
+    v = ((v >> 2) & 0x33333333u) | ((v & 0x33333333u) << 2);
+    v = ((v >> 4) & 0x0f0f0f0fu) | ((v & 0x0f0f0f0fu) << 4);
+    v = ((v >> 8) & 0x00ff00ffu) | ((v & 0x00ff00ffu) << 8);
+    v = (v >> 16) | (v << 16);
+    return v >> (32 - n);
+}
+
+// Build the decoder of one code from lens[0 .. n): `table` answers codes of at most `root` bits, `sorted` + `ct` the longer
+// ones.  Returns false for an over-subscribed set and for an incomplete one — except, when `lone_code_ok`, a set of one 1-bit
+// code or of no code at all (what zlib lets through for the literal/length and distance codes, not for the code-length code).
+BL_IDEV bool build_code(Shared& sh, const uint8_t* lens, int n, int root, uint16_t* table, uint16_t* sorted, CodeTable& ct, bool lone_code_ok)
+{
+    BL_LANES(lane)
+    {
+        if (lane < 16) ct.count[lane] = 0;
+        for (int i = lane; i < (1 << root); i += 64) table[i] = 0;
+    }
+    BL_WAVE_SYNC();
+    // how many codes of each length (every lane walks the same short list: a histogram by atomics would not be faster)
+    uint32_t cnt[16];
+#pragma unroll
+    for (int l = 0; l < 16; ++l) cnt[l] = 0;
+    for (int s = 0; s < n; ++s) {
+        const int l = lens[s] & 15;
+#pragma unroll
+        for (int k = 1; k < 16; ++k) cnt[k] += (l == k);
+    }
+    int left = 1, longest = 0;
+    uint32_t first = 0, at = 0;  // canonical code / slot among the sorted symbols where each length starts
+    uint32_t first_of[16], slot_of[16];
+#pragma unroll
+    for (int l = 1; l < 16; ++l) {
+        left = (left << 1) - (int)cnt[l];
+        if (left < 0) return false;  // over-subscribed
+        if (cnt[l]) longest = l;
+        first_of[l] = first;
+        slot_of[l] = at;
+        first = (first + cnt[l]) << 1;
+        at += cnt[l];
+    }
+    if (left > 0 && !(lone_code_ok && (at == 0 || (longest == 1 && at == 1)))) return false;  // incomplete
+    BL_LANES(lane)
+    {
+        if (lane >= 1 && lane < 16) {
+            uint32_t c = 0, f = 0;
+#pragma unroll
+            for (int l = 1; l < 16; ++l)
+                if (l == lane) { c = cnt[l]; f = slot_of[l]; }
+            ct.count[lane] = c;
+            sh.next[lane] = f;
+        }
+    }
+    BL_WAVE_SYNC();
+    // symbols in order: the k-th symbol of a length gets that length's k-th code and k-th sorted slot
+    for (int s = 0; s < n; ++s) {
+        const int l = lens[s] & 15;
+        if (l) {
+            uint32_t f = 0, base = 0;
+#pragma unroll
+            for (int k = 1; k < 16; ++k)
+                if (k == l) { f = first_of[k]; base = slot_of[k]; }
+            const uint32_t slot = sh.next[l];  // (every lane does the same here: no exchange between lanes)
+            sh.next[l] = slot + 1;
+            sorted[slot] = (uint16_t)s;
+            sh.code[s] = (uint16_t)(f + (slot - base));
+        }
+    }
+    BL_WAVE_SYNC();
+    // every symbol of at most `root` bits fills the table entries whose low bits are its (bit-reversed) code
+    BL_LANES(lane)
+    {
+        for (int s = lane; s < n; s += 64) {
+            const int l = lens[s] & 15;
+            if (l && l <= root) {
+                const uint32_t r = reverse_bits(sh.code[s], l);
+                const uint16_t e = (uint16_t)((s << 4) | l);
+                for (uint32_t j = r; j < (1u << root); j += (1u << l)) table[j] = e;
+            }
+        }
+    }
+    BL_WAVE_SYNC();
+    return true;
+}
+
+// One symbol of a code.  Returns the symbol, or -1 when the next bits are no code of the set.
+BL_IDEV int decode_symbol(Bits& b, int root, const uint16_t* table, const uint16_t* sorted, const CodeTable& ct)
+{
+    const uint32_t e = table[b.peek(root)];
+    if (e) {
+        b.drop((int)(e & 15u));
+        return (int)(e >> 4);
+    }
+    // longer than the root (or nothing): walk the canonical code one bit at a time
+    uint32_t code = 0, first = 0, index = 0;
+    uint64_t bits = b.bb;
+    for (int l = 1; l < 16; ++l) {
+        code |= (uint32_t)(bits & 1u);
+        bits >>= 1;
+        const uint32_t c = ct.count[l];
+        if (code < first + c) {
+            b.drop(l);
+            return (int)sorted[index + (code - first)];
+        }
+        index += c;
+        first = (first + c) << 1;
+        code <<= 1;
+    }
+    return -1;
+}
+
+BL_IDEV void copy16(uint8_t* dst, const uint8_t* src)  // both 16-byte aligned
+{
+#ifdef BL_INFLATE_EMU
+    for (int i = 0; i < 16; ++i) dst[i] = src[i];
+#else
+    *reinterpret_cast<uint4*>(__builtin_assume_aligned(dst, 16)) = *reinterpret_cast<const uint4*>(__builtin_assume_aligned(src, 16));
+#endif
+}
+
+// Text written so far goes out to HBM: ring positions [a, b) (b - a <= WINDOW), `g + q` being the address of ring position q.
+BL_IDEV void flush_range(const Shared& sh, uint8_t* g, uint32_t a, uint32_t b)
+{
+    uint32_t a16 = (a + 15u) & ~15u, b16 = b & ~15u;
+    if (a16 > b16) a16 = b16 = b;  // less than one aligned piece: bytes only
+    BL_LANES(lane)
+    {
+        for (uint32_t i = a + lane; i < a16 && i < b; i += 64) g[i] = sh.ring[i & (WINDOW - 1)];
+        for (uint32_t c = a16 + 16u * lane; c < b16; c += 16u * 64u) {
+            copy16(g + c, sh.ring + (c & (WINDOW - 1)));
+        }
+        for (uint32_t i = (b16 > a ? b16 : a) + lane; i < b; i += 64)
+            if (i >= a16) g[i] = sh.ring[i & (WINDOW - 1)];
+    }
+}
+
+// Inflate one member: `in` delivers its deflate data (n_in bytes), the text (exactly `isize` bytes if the stream is sound)
+// goes to out[0 .. isize).  Nothing outside out[0 .. isize) is written.  Returns a Status.
+template <class In>
+BL_IDEV uint32_t inflate_member(Shared& sh, In& in, uint32_t n_in, uint8_t* out, uint32_t isize)
+{
+    const uint32_t shift = (uint32_t)(reinterpret_cast<uintptr_t>(out) & 15u);
+    uint8_t* const g = out - shift;  // g + q: where ring position q = text position + shift goes
+    uint32_t q = shift, flushed = shift, next_flush = FLUSH;
+    const uint32_t q_end = shift + isize;
+    const uint32_t words_in = (n_in + in.lead_bits() / 8u + 3u) / 4u;  // dwords that hold data
+    Bits b;
+    b.start(in);
+    uint32_t status = OK;
+    for (;;) {
+        b.need32(in);
+        const uint32_t last = b.take(1), type = b.take(2);
+        if (type == 0) {
+            // stored: skip to the byte boundary, LEN, ~LEN, LEN bytes
+            b.drop(b.nb & 7);
+            b.need32(in);
+            const uint32_t len = b.take(16);
+            b.need32(in);
+            const uint32_t nlen = b.take(16);
+            if ((len ^ nlen) != 0xffffu) { status = ERR_STORED; break; }
+            if (q + len > q_end) { status = ERR_OVERRUN; break; }
+            for (uint32_t i = 0; i < len; ++i) {
+                b.need32(in);
+                sh.ring[q & (WINDOW - 1)] = (uint8_t)b.take(8);
+                ++q;
+                if (q >= next_flush) {
+                    BL_WAVE_SYNC();
+                    flush_range(sh, g, flushed, next_flush);
+                    flushed = next_flush;
+                    next_flush += FLUSH;
+                }
+                if ((i & 1023u) == 0 && in.taken > words_in + 2u) break;
+            }
+            if (in.taken > words_in + 2u) { status = ERR_INPUT; break; }
+        } else if (type == 3) {
+            status = ERR_BLOCK_TYPE;
+            break;
+        } else {
+            int n_ll, n_d;
+            if (type == 1) {
+                n_ll = 288;
+                n_d = 32;  // (the two last of each are never used in a sound stream; they take part in the code all the same)
+                BL_LANES(lane)
+                {
+                    for (int s = lane; s < 288 + 32; s += 64) sh.lens[s] = (uint8_t)(s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : s < 288 ? 8 : 5);
+                }
+                BL_WAVE_SYNC();
+            } else {
+                n_ll = (int)b.take(5) + 257;
+                n_d = (int)b.take(5) + 1;
+                const int n_cl = (int)b.take(4) + 4;
+                if (n_ll > 286 || n_d > 30) { status = ERR_HEADER; break; }
+                BL_LANES(lane)
+                {
+                    if (lane < 19) sh.lens[lane] = 0;
+                }
+                BL_WAVE_SYNC();
+                for (int i = 0; i < n_cl; ++i) {
+                    b.need32(in);
+                    const uint8_t v = (uint8_t)b.take(3);
+                    // the order in which the lengths of the code-length code are sent: 16 17 18 0 8 7 9 6 10 5 11 4 12 3 13 2 14 1 15
+                    const int at = i < 3 ? 16 + i : i == 3 ? 0 : (i & 1) ? (19 - i) >> 1 : 6 + (i >> 1);
+                    sh.lens[at] = v;  // (every lane stores the same byte)
+                }
+                BL_WAVE_SYNC();
+                if (!build_code(sh, sh.lens, 19, CL_ROOT, sh.cl_table, sh.cl_sorted, sh.cl, false)) { status = ERR_CODE_SET; break; }
+                // the lengths of the two codes, run-length coded with the code just built (whose decoder no longer reads sh.lens:
+                // the array is free for them)
+                const int total = n_ll + n_d;
+                int have = 0;
+                uint8_t prev = 0;
+                uint8_t* const lens = sh.lens;
+                while (have < total) {
+                    b.need32(in);
+                    const int s = decode_symbol(b, CL_ROOT, sh.cl_table, sh.cl_sorted, sh.cl);
+                    if (s < 0) { status = ERR_SYMBOL; break; }
+                    int rep;
+                    uint8_t v;
+                    if (s < 16) {
+                        rep = 1;
+                        v = (uint8_t)s;
+                        prev = v;
+                    } else if (s == 16) {
+                        if (have == 0) { status = ERR_HEADER; break; }
+                        rep = 3 + (int)b.take(2);
+                        v = prev;
+                    } else if (s == 17) {
+                        rep = 3 + (int)b.take(3);
+                        v = 0;
+                        prev = 0;
+                    } else {
+                        rep = 11 + (int)b.take(7);
+                        v = 0;
+                        prev = 0;
+                    }
+                    if (have + rep > total) { status = ERR_HEADER; break; }
+                    BL_LANES(lane)
+                    {
+                        for (int j = lane; j < rep; j += 64) {
+                            const int i = have + j;
+                            lens[i < n_ll ? i : MAX_LL + (i - n_ll)] = v;  // distance lengths start at slot MAX_LL
+                        }
+                    }
+                    have += rep;
+                    if (in.taken > words_in + 2u) { status = ERR_INPUT; break; }
+                }
+                if (status != OK) break;
+                BL_WAVE_SYNC();
+                if (sh.lens[256] == 0) { status = ERR_HEADER; break; }  // no end-of-block code
+            }
+            if (!build_code(sh, sh.lens, n_ll, LL_ROOT, sh.ll_table, sh.ll_sorted, sh.ll, true)) { status = ERR_CODE_SET; break; }
+            if (!build_code(sh, sh.lens + MAX_LL, n_d, D_ROOT, sh.d_table, sh.d_sorted, sh.d, true)) { status = ERR_CODE_SET; break; }
+            // the symbols of the block
+            for (;;) {
+                b.need32(in);
+                const int s = decode_symbol(b, LL_ROOT, sh.ll_table, sh.ll_sorted, sh.ll);
+                if (s < 256) {
+                    if (s < 0) { status = ERR_SYMBOL; break; }
+                    if (q >= q_end) { status = ERR_OVERRUN; break; }
+                    sh.ring[q & (WINDOW - 1)] = (uint8_t)s;  // (the same store from every lane)
+                    ++q;
+                } else {
+                    if (s == 256) break;
+                    if (s > 285) { status = ERR_SYMBOL; break; }
+                    const int c = s - 257;
+                    uint32_t len;
+                    if (c < 8) len = (uint32_t)c + 3u;
+                    else if (c == 28) len = 258u;
+                    else {
+                        const int eb = (c >> 2) - 1;
+                        len = ((4u + (uint32_t)(c & 3)) << eb) + 3u + b.take(eb);
+                    }
+                    b.need32(in);
+                    const int ds = decode_symbol(b, D_ROOT, sh.d_table, sh.d_sorted, sh.d);
+                    if (ds < 0 || ds > 29) { status = ERR_SYMBOL; break; }
+                    uint32_t dist;
+                    if (ds < 4) dist = (uint32_t)ds + 1u;
+                    else {
+                        const int eb = (ds >> 1) - 1;
+                        dist = ((2u + (uint32_t)(ds & 1)) << eb) + 1u + b.take(eb);
+                    }
+                    if (dist > q - shift) { status = ERR_DISTANCE; break; }
+                    if (q + len > q_end) { status = ERR_OVERRUN; break; }
+                    BL_WAVE_SYNC();  // the literals written since the last match are in the ring
+                    const uint32_t from = q - dist;
+                    if (dist >= len) {
+                        BL_LANES(lane)
+                        {
+                            for (uint32_t i = (uint32_t)lane; i < len; i += 64) sh.ring[(q + i) & (WINDOW - 1)] = sh.ring[(from + i) & (WINDOW - 1)];
+                        }
+                    } else {  // the match runs into itself: its first `dist` bytes repeat
+                        BL_LANES(lane)
+                        {
+                            for (uint32_t i = (uint32_t)lane; i < len; i += 64) sh.ring[(q + i) & (WINDOW - 1)] = sh.ring[(from + i % dist) & (WINDOW - 1)];
+                        }
+                    }
+                    BL_WAVE_SYNC();
+                    q += len;
+                }
+                if (q >= next_flush) {
+                    BL_WAVE_SYNC();
+                    flush_range(sh, g, flushed, next_flush);
+                    flushed = next_flush;
+                    next_flush += FLUSH;
+                }
+                if (in.taken > words_in + 2u) { status = ERR_INPUT; break; }
+            }
+            if (status != OK) break;
+        }
+        if (last) break;
+        if (in.taken > words_in + 2u) { status = ERR_INPUT; break; }
+    }
+    BL_WAVE_SYNC();
+    if (q > flushed) flush_range(sh, g, flushed, q);  // what a damaged stream produced before it failed is within [0, isize) too
+    if (status == OK) {
+        const uint32_t bits_used = in.taken * 32u - (uint32_t)b.nb - in.lead_bits();
+        if (bits_used > n_in * 8u) status = ERR_INPUT;
+        else if (q != q_end) status = ERR_SIZE;
+    }
+    return status;
+}
+
+}  // namespace bl_inflate

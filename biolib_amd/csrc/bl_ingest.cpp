@@ -23,6 +23,7 @@
 #include <atomic>
 #include <condition_variable>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <memory>
@@ -37,6 +38,10 @@
 #include "../../include/biolib_amd.h"
 
 extern int bl_set_error(int code, const char* msg);  // bl_capi.hip
+extern hipStream_t bl_ctx_stream(bl_ctx* ctx);
+extern int bl_ctx_device(bl_ctx* ctx);
+extern int bl_parse_device_text(bl_ctx* ctx, const uint8_t* d_text, uint64_t n_bytes, char first_byte, const char* ends, uint64_t ends_n, bl_batch** out,
+                                uint64_t* n_seqs, uint64_t* n_bases);  // bl_parse.hip
 
 namespace {
 
@@ -227,22 +232,26 @@ private:
 // The decompressed bytes of one file.
 class ByteSource {
 public:
-    ByteSource(FILE* f, int threads) : f_(f), queue_(16)
+    ByteSource(FILE* f, int threads) : f_(f), queue_(16), threads_(threads < 1 ? 1 : threads)
     {
         unsigned char head[18];
         const size_t got = std::fread(head, 1, sizeof(head), f_);
         std::rewind(f_);
         const bool gz = got >= 2 && head[0] == 0x1f && head[1] == 0x8b;
         const bool bgzf = gz && got == 18 && head[2] == 8 && (head[3] & 4) && head[12] == 'B' && head[13] == 'C' && head[14] == 2 && head[15] == 0;
-        if (bgzf) {
-            kind_ = "bgzf";
-            pool_.reset(new InflatePool(threads < 1 ? 1 : threads, queue_, spare_));
+        kind_ = bgzf ? "bgzf" : gz ? "gzip" : "plain";
+    }
+    // the threads start with the first request for bytes: a BGZF file that goes to the device compressed never needs them
+    void start()
+    {
+        if (started_) return;
+        started_ = true;
+        if (kind_[0] == 'b') {
+            pool_.reset(new InflatePool(threads_, queue_, spare_));
             feeder_ = std::thread([this] { cut_bgzf(); });
-        } else if (gz) {
-            kind_ = "gzip";
+        } else if (kind_[0] == 'g') {
             feeder_ = std::thread([this] { inflate_stream(); });
         } else {
-            kind_ = "plain";
             feeder_ = std::thread([this] { read_plain(); });
         }
     }
@@ -253,7 +262,11 @@ public:
         pool_.reset();  // joins the workers
         if (f_) std::fclose(f_);
     }
-    bool next(Chunk& c) { return queue_.pop(c); }
+    bool next(Chunk& c)
+    {
+        start();
+        return queue_.pop(c);
+    }
     void recycle(std::vector<unsigned char>&& v) { spare_.give(std::move(v)); }
     void abandon() { queue_.abandon(); }  // the consumer is leaving: next() returns false from now on
     const char* kind() const { return kind_; }
@@ -365,6 +378,8 @@ private:
     std::unique_ptr<InflatePool> pool_;
     std::thread feeder_;
     const char* kind_ = "plain";
+    int threads_;
+    bool started_ = false;
 };
 
 inline bool is_blank(int c) { return c == ' ' || (c >= '\t' && c <= '\r'); }  // isspace() of the C locale
@@ -528,6 +543,53 @@ private:
 //     In a 4-line record only the header satisfies that: for a quality line beginning with '@' the second-next line is a
 //     sequence line, which cannot begin with '+'.
 //   FASTA: in front of a line that begins with '>'.
+// is `at` (the first byte of a line) where a record begins (fmt_ 'q': 4-line FASTQ, else FASTA)?  -1: the bytes that decide are not in the buffer yet
+int record_opens_at(const char* p, size_t filled, size_t at, char fmt_)
+{
+    if (at >= filled) return -1;
+    if (fmt_ != 'q') return p[at] == '>';
+    if (p[at] != '@') return 0;
+    const char* nl = static_cast<const char*>(std::memchr(p + at, '\n', filled - at));
+    if (!nl || (size_t)(nl + 1 - p) >= filled) return -1;
+    nl = static_cast<const char*>(std::memchr(nl + 1, '\n', filled - (size_t)(nl + 1 - p)));
+    if (!nl || (size_t)(nl + 1 - p) >= filled) return -1;
+    return nl[1] == '+';
+}
+// the last record boundary in (0, limit], else the first one beyond it; 0: none in the buffer
+size_t find_record_cut(const char* p, size_t filled, size_t limit, char fmt_)
+{
+    size_t upto = limit < filled ? limit : filled;  // a newline at a position < upto opens a line at <= limit
+    if (fmt_ == 'q') {
+        for (int lines = 0; upto > 0 && lines < 16; ++lines) {  // a header is among any four consecutive lines
+            const char* nl = static_cast<const char*>(memrchr(p, '\n', upto));
+            if (!nl) break;
+            const size_t at = (size_t)(nl - p) + 1;
+            if (record_opens_at(p, filled, at, fmt_) == 1) return at;
+            upto = (size_t)(nl - p);
+        }
+    } else {
+        size_t last = filled ? (limit < filled - 1 ? limit : filled - 1) : 0;  // the last position a cut may take
+        while (last > 0) {  // the last '>' that follows a newline
+            const char* gt = static_cast<const char*>(memrchr(p + 1, '>', last));  // positions 1 .. last
+            if (!gt) break;
+            const size_t at = (size_t)(gt - p);
+            if (p[at - 1] == '\n') return at;
+            last = at - 1;
+        }
+    }
+    size_t from = limit < filled ? limit : filled;  // a record longer than the limit: the first boundary after it
+    while (from < filled) {
+        const char* nl = static_cast<const char*>(std::memchr(p + from, '\n', filled - from));
+        if (!nl) break;
+        const size_t at = (size_t)(nl - p) + 1;
+        const int v = record_opens_at(p, filled, at, fmt_);
+        if (v == 1) return at;
+        if (v < 0) break;
+        from = at;
+    }
+    return 0;
+}
+
 struct SpanMemory {  // where span buffers come from
     void* (*get)(size_t bytes);
     void (*put)(void* p);
@@ -600,52 +662,6 @@ private:
         b.cap = want;
         return true;
     }
-    // is `at` (the first byte of a line) where a record begins?  -1: the bytes that decide are not in the buffer yet
-    int record_opens_at(const char* p, size_t filled, size_t at) const
-    {
-        if (at >= filled) return -1;
-        if (fmt_ != 'q') return p[at] == '>';
-        if (p[at] != '@') return 0;
-        const char* nl = static_cast<const char*>(std::memchr(p + at, '\n', filled - at));
-        if (!nl || (size_t)(nl + 1 - p) >= filled) return -1;
-        nl = static_cast<const char*>(std::memchr(nl + 1, '\n', filled - (size_t)(nl + 1 - p)));
-        if (!nl || (size_t)(nl + 1 - p) >= filled) return -1;
-        return nl[1] == '+';
-    }
-    // the last record boundary in (0, limit], else the first one beyond it; 0: none in the buffer
-    size_t find_cut(const char* p, size_t filled, size_t limit) const
-    {
-        size_t upto = limit < filled ? limit : filled;  // a newline at a position < upto opens a line at <= limit
-        if (fmt_ == 'q') {
-            for (int lines = 0; upto > 0 && lines < 16; ++lines) {  // a header is among any four consecutive lines
-                const char* nl = static_cast<const char*>(memrchr(p, '\n', upto));
-                if (!nl) break;
-                const size_t at = (size_t)(nl - p) + 1;
-                if (record_opens_at(p, filled, at) == 1) return at;
-                upto = (size_t)(nl - p);
-            }
-        } else {
-            size_t last = filled ? (limit < filled - 1 ? limit : filled - 1) : 0;  // the last position a cut may take
-            while (last > 0) {  // the last '>' that follows a newline
-                const char* gt = static_cast<const char*>(memrchr(p + 1, '>', last));  // positions 1 .. last
-                if (!gt) break;
-                const size_t at = (size_t)(gt - p);
-                if (p[at - 1] == '\n') return at;
-                last = at - 1;
-            }
-        }
-        size_t from = limit < filled ? limit : filled;  // a record longer than the limit: the first boundary after it
-        while (from < filled) {
-            const char* nl = static_cast<const char*>(std::memchr(p + from, '\n', filled - from));
-            if (!nl) break;
-            const size_t at = (size_t)(nl - p) + 1;
-            const int v = record_opens_at(p, filled, at);
-            if (v == 1) return at;
-            if (v < 0) break;
-            from = at;
-        }
-        return 0;
-    }
     void produce()
     {
         int put = 0;
@@ -670,7 +686,7 @@ private:
                 if (eof && filled == 0) { verdict = 0; break; }
                 if (eof && filled <= limit_) { cut = filled; break; }
                 if (filled >= want || eof) {
-                    cut = find_cut(b->p, filled, limit_);
+                    cut = find_record_cut(b->p, filled, limit_, fmt_);
                     if (cut == 0 && eof) cut = filled;  // the tail of the file, whatever it is
                     if (cut) break;
                     want = filled + LOOK;  // one record longer than all this: keep reading
@@ -716,9 +732,172 @@ private:
     int ended_verdict_ = 0;
 };
 
+// BGZF that goes to the device compressed: a thread reads the file into a ring of page-locked buffers and walks the member
+// headers (that is all the host does: bl_inflate.hip inflates on the GPU); a span holds whole members with at most `limit`
+// bytes of text between them.
+struct PackedSpan {
+    char* p = nullptr;
+    size_t cap = 0;
+    size_t n = 0;  // bytes of whole members; what follows them opens the next span
+    std::vector<bl_bgzf_member> members;
+    uint64_t text_bytes = 0;
+    int state = 0;    // 0 free, 1 ready, 2 held by the caller
+    int verdict = 1;  // 1 span, 0 end of file, -1 damaged file
+};
+
+class PackedSpans {
+public:
+    static constexpr int RING = 3;
+    static constexpr size_t READ = 4u << 20;
+    PackedSpans(FILE* f, size_t limit, SpanMemory mem) : f_(f), limit_(limit), mem_(mem) { worker_ = std::thread([this] { produce(); }); }
+    ~PackedSpans()
+    {
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            quit_ = true;
+        }
+        cv_.notify_all();
+        if (worker_.joinable()) worker_.join();
+        for (auto& b : ring_)
+            if (b.p) mem_.put(b.p);
+        if (f_) std::fclose(f_);
+    }
+    int next(PackedSpan** out)  // the span stays valid until the following call
+    {
+        std::unique_lock<std::mutex> lk(m_);
+        if (held_ >= 0) {
+            ring_[held_].state = 0;
+            held_ = -1;
+            cv_.notify_all();
+        }
+        if (ended_) return ended_verdict_;
+        PackedSpan& b = ring_[take_];
+        cv_.wait(lk, [&] { return b.state == 1; });
+        if (b.verdict != 1) {
+            ended_ = true;
+            ended_verdict_ = b.verdict;
+            return b.verdict;
+        }
+        b.state = 2;
+        held_ = take_;
+        take_ = (take_ + 1) % RING;
+        *out = &b;
+        return 1;
+    }
+
+private:
+    bool grow(PackedSpan& b, size_t keep, size_t need)
+    {
+        if (need <= b.cap) return true;
+        size_t want = b.cap ? b.cap : 2 * READ;
+        while (want < need) want *= 2;
+        char* q = static_cast<char*>(mem_.get(want));
+        if (!q) return false;
+        if (keep) std::memcpy(q, b.p, keep);
+        if (b.p) mem_.put(b.p);
+        b.p = q;
+        b.cap = want;
+        return true;
+    }
+    void produce()
+    {
+        int put = 0;
+        const char* carry = nullptr;
+        size_t carry_n = 0;
+        bool eof = false;
+        for (;;) {
+            PackedSpan* b;
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                b = &ring_[put];
+                cv_.wait(lk, [&] { return quit_ || b->state == 0; });
+                if (quit_) return;
+            }
+            int verdict = 1;
+            size_t filled = 0, walked = 0;
+            uint64_t text = 0;
+            b->members.clear();
+            if (!grow(*b, 0, carry_n + READ)) verdict = -1;
+            if (verdict == 1 && carry_n) std::memcpy(b->p, carry, carry_n);
+            if (verdict == 1) filled = carry_n;
+            bool full = false;
+            while (verdict == 1 && !full) {
+                for (;;) {  // the whole members that are here
+                    bl_bgzf_member m;
+                    uint64_t got = 0, used = 0, tb = 0;
+                    if (bl_bgzf_walk(b->p + walked, filled - walked, walked, text, &m, 1, &got, &used, &tb) != BL_OK) { verdict = -1; break; }
+                    if (got == 0) break;
+                    if (!b->members.empty() && text + m.isize > limit_) { full = true; break; }
+                    b->members.push_back(m);
+                    walked += used;
+                    text += m.isize;
+                }
+                if (verdict != 1 || full || eof) break;
+                if (!grow(*b, filled, filled + READ)) { verdict = -1; break; }
+                const size_t n = std::fread(b->p + filled, 1, READ, f_);
+                if (n < READ) {
+                    if (std::ferror(f_)) { verdict = -1; break; }
+                    eof = true;
+                }
+                filled += n;
+            }
+            if (verdict == 1 && b->members.empty()) verdict = filled > walked ? -1 : 0;  // a member cut short by the end of the file / the end
+            b->n = walked;
+            b->text_bytes = text;
+            b->verdict = verdict;
+            carry = b->p + walked;
+            carry_n = verdict == 1 ? filled - walked : 0;
+            {
+                std::lock_guard<std::mutex> lk(m_);
+                b->state = 1;
+            }
+            cv_.notify_all();
+            if (verdict != 1) return;
+            put = (put + 1) % RING;
+        }
+    }
+
+    FILE* f_;
+    const size_t limit_;
+    const SpanMemory mem_;
+    PackedSpan ring_[RING];
+    std::mutex m_;
+    std::condition_variable cv_;
+    std::thread worker_;
+    int take_ = 0, held_ = -1;
+    bool quit_ = false, ended_ = false;
+    int ended_verdict_ = 0;
+};
+
 }  // namespace
 
+// Device side of the compressed path: the members of a span are inflated into `text[cur]` behind the bytes the previous span
+// left over (the part of its last record that was not complete yet), the text is cut at its last record boundary, parsed there,
+// and what lies behind the cut moves to the front of the other buffer.
+struct DeviceBgzf {
+    std::unique_ptr<PackedSpans> spans;
+    bl_ctx* ctx = nullptr;
+    void *d_packed = nullptr, *d_members = nullptr;
+    uint32_t* d_status = nullptr;
+    uint8_t* d_text[2] = {nullptr, nullptr};
+    size_t packed_cap = 0, members_cap = 0, text_cap[2] = {0, 0};
+    int cur = 0;
+    size_t carry_n = 0;
+    bool eof = false;
+    char first_byte = 0;
+    std::vector<char> window;
+    std::vector<uint32_t> status;
+    ~DeviceBgzf()
+    {
+        spans.reset();
+        for (void* p : {d_packed, d_members, (void*)d_text[0], (void*)d_text[1]})  // (d_status lies inside d_members)
+            if (p) (void)hipFree(p);
+    }
+};
+
 struct bl_reader {
+    std::string path;
+    std::unique_ptr<DeviceBgzf> packed;
     std::unique_ptr<ByteSource> source;
     std::unique_ptr<RecordParser> records;
     std::unique_ptr<TextCutter> text;
@@ -757,6 +936,7 @@ int bl_reader_open_threads(const char* path, int threads, bl_reader** out)
         std::fclose(f);
         return bl_set_error(BL_ERR_OOM, "host allocation failed");
     }
+    r->path = path;
     r->source.reset(new ByteSource(f, threads));
     *out = r;
     return BL_OK;
@@ -769,6 +949,7 @@ int bl_reader_close(bl_reader* r)
     if (!r) return BL_OK;
     r->records.reset();
     r->text.reset();
+    r->packed.reset();
     r->source.reset();
     delete r;
     return BL_OK;
@@ -779,7 +960,7 @@ const char* bl_reader_kind(bl_reader* r) { return r && r->source ? r->source->ki
 int bl_reader_next_record(bl_reader* r, const char** name, const char** seq, uint64_t* seq_len)
 {
     if (!r || !seq_len) return bl_set_error(BL_ERR_INVALID, "NULL argument");
-    if (r->text) return bl_set_error(BL_ERR_INVALID, "this reader is delivering text spans: records and spans cannot be mixed");
+    if (r->text || r->packed) return bl_set_error(BL_ERR_INVALID, "this reader is delivering text spans: records and spans cannot be mixed");
     if (!r->records) r->records.reset(new RecordParser(*r->source));
     const Step s = r->records->next(r->rec);
     if (s == Step::End) {
@@ -799,7 +980,7 @@ int bl_reader_next_batch(bl_ctx* ctx, bl_reader* r, uint64_t max_bases, bl_batch
 {
     if (!ctx || !r || !out) return bl_set_error(BL_ERR_INVALID, "NULL argument");
     *out = nullptr;
-    if (r->text) return bl_set_error(BL_ERR_INVALID, "this reader is delivering text spans: records and spans cannot be mixed");
+    if (r->text || r->packed) return bl_set_error(BL_ERR_INVALID, "this reader is delivering text spans: records and spans cannot be mixed");
     if (!r->records) r->records.reset(new RecordParser(*r->source));
     r->bases.clear();
     r->offsets.assign(1, 0);
@@ -837,7 +1018,7 @@ const SpanMemory PINNED_MEMORY = {[](size_t n) {
 
 int next_span(bl_reader* r, uint64_t max_bytes, const SpanMemory& mem, const char** text, uint64_t* n_bytes)
 {
-    if (r->records) return bl_set_error(BL_ERR_INVALID, "this reader is delivering records: records and spans cannot be mixed");
+    if (r->records || r->packed) return bl_set_error(BL_ERR_INVALID, "this reader is delivering records: records and spans cannot be mixed");
     const size_t limit = max_bytes ? (size_t)max_bytes : (size_t)64 << 20;
     if (!r->text) r->text.reset(new TextCutter(*r->source, limit, mem));
     if (r->text->limit() != limit) return bl_set_error(BL_ERR_INVALID, "the span size of a reader is fixed by its first span call");
@@ -859,12 +1040,130 @@ int bl_reader_next_text(bl_reader* r, uint64_t max_bytes, const char** text, uin
     return next_span(r, max_bytes, HOST_MEMORY, text, n_bytes);
 }
 
+namespace {
+
+#define R_HIP(call)                                                                                        \
+    do {                                                                                                   \
+        const hipError_t e_ = (call);                                                                      \
+        if (e_ != hipSuccess) return bl_set_error(e_ == hipErrorOutOfMemory ? BL_ERR_OOM : BL_ERR_HIP, hipGetErrorString(e_)); \
+    } while (0)
+
+// a device buffer of at least `need` bytes that keeps its first `keep` bytes
+int device_reserve(void** p, size_t* cap, size_t need, size_t keep, hipStream_t s)
+{
+    if (need <= *cap) return BL_OK;
+    size_t want = *cap ? *cap : (size_t)1 << 20;
+    while (want < need) want *= 2;
+    void* q = nullptr;
+    R_HIP(hipMalloc(&q, want));
+    if (keep) {
+        const hipError_t e = hipMemcpyAsync(q, *p, keep, hipMemcpyDeviceToDevice, s);
+        if (e != hipSuccess) { (void)hipFree(q); return bl_set_error(BL_ERR_HIP, hipGetErrorString(e)); }
+    }
+    R_HIP(hipStreamSynchronize(s));  // nothing queued may still use the old buffer
+    if (*p) R_HIP(hipFree(*p));
+    *p = q;
+    *cap = want;
+    return BL_OK;
+}
+
+// One batch from the compressed path (*out NULL at the end of the file).
+int next_batch_packed(bl_ctx* ctx, bl_reader* r, size_t limit, bl_batch** out, uint64_t* n_seqs, uint64_t* n_bases)
+{
+    DeviceBgzf& d = *r->packed;
+    if (d.ctx != ctx) return bl_set_error(BL_ERR_INVALID, "a reader's device batches must all go to the same context");
+    R_HIP(hipSetDevice(bl_ctx_device(ctx)));
+    hipStream_t s = bl_ctx_stream(ctx);
+    for (;;) {
+        PackedSpan* sp = nullptr;
+        if (!d.eof) {
+            const int rc = d.spans->next(&sp);
+            if (rc < 0) return bl_set_error(BL_ERR_INVALID, "error reading the (compressed) stream");
+            if (rc == 0) d.eof = true;
+        }
+        if (d.eof && d.carry_n == 0) return BL_OK;  // end of file
+        const size_t add = sp ? (size_t)sp->text_bytes : 0, filled = d.carry_n + add;
+        {
+            void* p = d.d_text[d.cur];
+            const int rc = device_reserve(&p, &d.text_cap[d.cur], filled + 64, d.carry_n, s);
+            d.d_text[d.cur] = static_cast<uint8_t*>(p);
+            if (rc != BL_OK) return rc;
+        }
+        uint8_t* const text = d.d_text[d.cur];
+        const size_t n_members = sp ? sp->members.size() : 0;
+        if (n_members) {
+            int rc = device_reserve(&d.d_packed, &d.packed_cap, sp->n + 8, 0, s);
+            if (rc == BL_OK) rc = device_reserve(&d.d_members, &d.members_cap, n_members * (sizeof(bl_bgzf_member) + sizeof(uint32_t)), 0, s);
+            if (rc != BL_OK) return rc;
+            d.d_status = reinterpret_cast<uint32_t*>(static_cast<char*>(d.d_members) + n_members * sizeof(bl_bgzf_member));
+            R_HIP(hipMemcpyAsync(d.d_packed, sp->p, sp->n, hipMemcpyHostToDevice, s));
+            R_HIP(hipMemcpyAsync(d.d_members, sp->members.data(), n_members * sizeof(bl_bgzf_member), hipMemcpyHostToDevice, s));
+            rc = bl_bgzf_inflate(ctx, d.d_packed, sp->n, static_cast<const bl_bgzf_member*>(d.d_members), n_members, text + d.carry_n, add, d.d_status);
+            if (rc != BL_OK) return rc;
+            d.status.resize(n_members);
+            R_HIP(hipMemcpyAsync(d.status.data(), d.d_status, n_members * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        }
+        if (filled == 0) {  // members without text (the end-of-file marker)
+            R_HIP(hipStreamSynchronize(s));  // the span's buffer is released by the next call to next()
+            continue;
+        }
+        // the end of the text comes back to the host: the cut is decided there
+        size_t win = filled < ((size_t)256 << 10) ? filled : (size_t)256 << 10;
+        size_t cut = 0;
+        for (;;) {
+            d.window.resize(win + 1);
+            R_HIP(hipMemcpyAsync(d.window.data(), text + (filled - win), win, hipMemcpyDeviceToHost, s));
+            if (!d.first_byte) R_HIP(hipMemcpyAsync(&d.first_byte, text, 1, hipMemcpyDeviceToHost, s));
+            R_HIP(hipStreamSynchronize(s));
+            for (size_t i = 0; i < n_members; ++i)
+                if (d.status[i] != 0) return bl_set_error(BL_ERR_INVALID, "error reading the (compressed) stream");
+            if (d.eof) { cut = filled; break; }
+            const size_t at = find_record_cut(d.window.data(), win, win, d.first_byte == '@' ? 'q' : 'a');
+            if (at >= 64 || (at > 0 && win == filled)) { cut = (filled - win) + at; break; }  // (64: the parser wants to see the bytes in front of the cut)
+            if (win == filled) break;  // no boundary in all of it: one record longer than the span
+            win = win * 8 < filled ? win * 8 : filled;
+        }
+        if (cut == 0) {  // keep everything and read on
+            d.carry_n = filled;
+            continue;
+        }
+        const size_t rest = filled - cut;
+        const int other = d.cur ^ 1;
+        if (rest) {
+            void* p = d.d_text[other];
+            const int rc = device_reserve(&p, &d.text_cap[other], rest + 64, 0, s);
+            d.d_text[other] = static_cast<uint8_t*>(p);
+            if (rc != BL_OK) return rc;
+            R_HIP(hipMemcpyAsync(d.d_text[other], text + cut, rest, hipMemcpyDeviceToDevice, s));
+        }
+        d.cur = other;
+        d.carry_n = rest;
+        const size_t ends_n = cut < 64 ? cut : 64;
+        const char* ends = d.window.data() + (cut - (filled - win)) - ends_n;
+        return bl_parse_device_text(ctx, text, cut, d.first_byte, ends, ends_n, out, n_seqs, n_bases);
+    }
+}
+
+}  // namespace
+
 int bl_reader_next_batch_device(bl_ctx* ctx, bl_reader* r, uint64_t max_text_bytes, bl_batch** out, uint64_t* n_seqs, uint64_t* n_bases)
 {
     if (!ctx || !r || !out) return bl_set_error(BL_ERR_INVALID, "NULL argument");
     *out = nullptr;
     if (n_seqs) *n_seqs = 0;
     if (n_bases) *n_bases = 0;
+    // BGZF goes to the device compressed (BL_HOST_INFLATE=1: through the host's inflate pool instead — for comparisons)
+    if (!r->packed && !r->text && !r->records && r->source->kind()[0] == 'b' && !std::getenv("BL_HOST_INFLATE")) {
+        FILE* f = std::fopen(r->path.c_str(), "rb");
+        if (!f) return bl_set_error(BL_ERR_INVALID, (std::string("cannot open ") + r->path).c_str());
+        r->packed.reset(new DeviceBgzf());
+        r->packed->ctx = ctx;
+        r->packed->spans.reset(new PackedSpans(f, max_text_bytes ? (size_t)max_text_bytes : (size_t)64 << 20, PINNED_MEMORY));
+    }
+    if (r->packed) {
+        if (r->records || r->text) return bl_set_error(BL_ERR_INVALID, "records, spans and device batches cannot be mixed on one reader");
+        return next_batch_packed(ctx, r, max_text_bytes ? (size_t)max_text_bytes : (size_t)64 << 20, out, n_seqs, n_bases);
+    }
     const char* text = nullptr;
     uint64_t n = 0;
     const int rc = next_span(r, max_text_bytes, PINNED_MEMORY, &text, &n);

@@ -178,29 +178,54 @@ __global__ void gather_bases_kernel(const uint8_t* text, const unsigned long lon
 
 }  // namespace
 
+// The parser proper, over text that is in device memory already.  `ends` is the host's copy of the text's last `ends_n` bytes
+// (all of it when the text is shorter than 64): the few decisions taken on the host look at the first byte and at the end only.
+int bl_parse_device_text(bl_ctx* ctx, const uint8_t* d_text_in, uint64_t n_bytes, char first_byte, const char* ends, uint64_t ends_n, bl_batch** out,
+                         uint64_t* n_seqs, uint64_t* n_bases);
+
 extern "C" int bl_batch_from_text(bl_ctx* ctx, const char* text, uint64_t n_bytes, bl_batch** out, uint64_t* n_seqs, uint64_t* n_bases)
 {
     if (!ctx || !out || (n_bytes && !text)) return bl_set_error(BL_ERR_INVALID, "NULL argument");
     *out = nullptr;
     if (n_seqs) *n_seqs = 0;
     if (n_bases) *n_bases = 0;
-    // the format is decided by the first character
     if (n_bytes == 0) return bl_batch_upload(ctx, "", 0, nullptr, 0, out);
-    const bool fastq = text[0] == '@';
-    if (!fastq && text[0] != '>') return bl_set_error(BL_ERR_INVALID, "text starts with neither '>' nor '@': use bl_reader_* for irregular files");
+    if (hipSetDevice(bl_ctx_device(ctx)) != hipSuccess) return bl_set_error(BL_ERR_HIP, "hipSetDevice failed");
+    uint8_t* d_text = static_cast<uint8_t*>(bl_ctx_scratch(ctx, 3, n_bytes + 64));
+    if (!d_text) return bl_set_error(BL_ERR_OOM, "device allocation failed (text)");
+    const hipError_t e = hipMemcpyAsync(d_text, text, n_bytes, hipMemcpyHostToDevice, bl_ctx_stream(ctx));
+    if (e != hipSuccess) return bl_set_error(BL_ERR_HIP, hipGetErrorString(e));
+    const uint64_t ends_n = n_bytes < 64 ? n_bytes : 64;
+    const int rc = bl_parse_device_text(ctx, d_text, n_bytes, text[0], text + (n_bytes - ends_n), ends_n, out, n_seqs, n_bases);
+    if (rc != BL_OK) (void)hipStreamSynchronize(bl_ctx_stream(ctx));  // the copy out of the caller's buffer is over when we return
+    return rc;
+}
+
+int bl_parse_device_text(bl_ctx* ctx, const uint8_t* d_text_in, uint64_t n_bytes, char first_byte, const char* ends, uint64_t ends_n, bl_batch** out,
+                         uint64_t* n_seqs, uint64_t* n_bases)
+{
+    if (!ctx || !out || !d_text_in || !ends || ends_n == 0 || ends_n > n_bytes) return bl_set_error(BL_ERR_INVALID, "NULL argument");
+    *out = nullptr;
+    if (n_seqs) *n_seqs = 0;
+    if (n_bases) *n_bases = 0;
+    auto last = [&](uint64_t back) { return ends[ends_n - 1 - back]; };  // the text's byte `back` places in front of its last one
+    // the format is decided by the first character
+    const bool fastq = first_byte == '@';
+    if (!fastq && first_byte != '>') return bl_set_error(BL_ERR_INVALID, "text starts with neither '>' nor '@': use bl_reader_* for irregular files");
     // a '>' that is the very last byte of the file and alone on its line opens no record in the reference reader (kseq meets
     // end of file while looking for the name and reports end of input): drop it
-    if (!fastq && text[n_bytes - 1] == '>' && (n_bytes == 1 || text[n_bytes - 2] == '\n')) {
+    if (!fastq && last(0) == '>' && (n_bytes == 1 || last(1) == '\n')) {
         --n_bytes;
+        --ends_n;
         if (n_bytes == 0) return bl_batch_upload(ctx, "", 0, nullptr, 0, out);
     }
-    const bool open_last_line = text[n_bytes - 1] != '\n';  // the last line has no terminator: a virtual one is added
+    const bool open_last_line = last(0) != '\n';  // the last line has no terminator: a virtual one is added
 
     hipStream_t s = bl_ctx_stream(ctx);
-    // Temporary arrays come from the context's grow-only scratch (slot 0: text and block counts, slot 1: per-line arrays,
-    // slot 2: scan workspace): a file is parsed span after span, and a dozen hipMalloc / hipFree per span cost more than the
-    // kernels.  Only the two arrays the batch keeps are allocated here.
-    uint8_t* d_text = nullptr;
+    // Temporary arrays come from the context's grow-only scratch (slot 0: block counts, slot 1: per-line arrays, slot 2: scan
+    // workspace; slot 3 holds the text when it came from the host): a file is parsed span after span, and a dozen hipMalloc /
+    // hipFree per span cost more than the kernels.  Only the two arrays the batch keeps are allocated here.
+    const uint8_t* d_text = nullptr;
     unsigned long long *d_blk = nullptr, *d_line_end = nullptr, *d_len = nullptr, *d_hdr = nullptr, *d_rec = nullptr, *d_dst = nullptr, *d_offsets = nullptr;
     unsigned int* d_err = nullptr;
     void* d_tmp = nullptr;
@@ -224,13 +249,12 @@ extern "C" int bl_batch_from_text(bl_ctx* ctx, const char* text, uint64_t n_byte
     P_HIP(hipSetDevice(bl_ctx_device(ctx)));
     const uint64_t n = n_bytes;
     const unsigned n_blocks = (unsigned)((n + BYTES_PER_BLOCK - 1) / BYTES_PER_BLOCK);
-    const size_t text_bytes = up256(n + 64), blk_bytes = up256(2 * ((size_t)n_blocks + 1) * sizeof(unsigned long long));
-    unsigned char* a0 = static_cast<unsigned char*>(bl_ctx_scratch(ctx, 0, text_bytes + blk_bytes + 256));
-    if (!a0) return fail_free(BL_ERR_OOM, "device allocation failed (text scratch)");
-    d_text = a0;
-    d_blk = reinterpret_cast<unsigned long long*>(a0 + text_bytes);  // counts, then their exclusive prefix
-    d_err = reinterpret_cast<unsigned int*>(a0 + text_bytes + blk_bytes);
-    P_HIP(hipMemcpyAsync(d_text, text, n, hipMemcpyHostToDevice, s));
+    const size_t blk_bytes = up256(2 * ((size_t)n_blocks + 1) * sizeof(unsigned long long));
+    unsigned char* a0 = static_cast<unsigned char*>(bl_ctx_scratch(ctx, 0, blk_bytes + 256));
+    if (!a0) return fail_free(BL_ERR_OOM, "device allocation failed (block scratch)");
+    d_text = d_text_in;
+    d_blk = reinterpret_cast<unsigned long long*>(a0);  // counts, then their exclusive prefix
+    d_err = reinterpret_cast<unsigned int*>(a0 + blk_bytes);
     unsigned long long* d_blk_base = d_blk + n_blocks + 1;
     P_HIP(hipMemsetAsync(d_blk + n_blocks, 0, sizeof(unsigned long long), s));
     P_HIP(hipMemsetAsync(d_err, 0, sizeof(unsigned int), s));
@@ -250,13 +274,14 @@ extern "C" int bl_batch_from_text(bl_ctx* ctx, const char* text, uint64_t n_byte
     const uint64_t n_lines_raw = n_newlines + (open_last_line ? 1 : 0);
     uint64_t n_lines = n_lines_raw;
     if (fastq && (n_lines & 3)) {  // blank lines after the last record are tolerated, anything else is not 4-line FASTQ
-        uint64_t excess = n_lines & 3, blank = 0, pos = n_bytes;
+        uint64_t excess = n_lines & 3, blank = 0, pos = ends_n;  // positions inside `ends`; running out of it means "not blank"
         while (blank < excess && pos > 0) {  // walk back over empty lines ("\n" or "\r\n")
             if (open_last_line && blank == 0) break;  // the last line is not empty
-            if (text[pos - 1] != '\n') break;
+            if (ends[pos - 1] != '\n') break;
             uint64_t q = pos - 1;
-            if (q > 0 && text[q - 1] == '\r') --q;
-            if (q > 0 && text[q - 1] != '\n') break;  // the line ending here has content
+            if (q > 0 && ends[q - 1] == '\r') --q;
+            if (q == 0 && ends_n < n_bytes) break;     // cannot see the byte in front
+            if (q > 0 && ends[q - 1] != '\n') break;  // the line ending here has content
             ++blank;
             pos = q;
         }

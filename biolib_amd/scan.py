@@ -254,6 +254,40 @@ class Context:
         check(self._lib.bl_probe_hbm(self._h, int(n_bytes), int(iters), C.byref(r), C.byref(c)))
         return r.value, c.value
 
+    def bgzf_inflate(self, data):
+        """inflate a buffer of whole BGZF members on the device (bl_bgzf_walk + bl_bgzf_inflate): (text as a numpy uint8 array,
+        per-member status codes — 0 = sound)"""
+        data = bytes(data)
+        cap = len(data) // 26 + 1
+        members = np.zeros(cap * 4, np.uint64)  # 32 bytes per member
+        n, used, text = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        check(self._lib.bl_bgzf_walk(data, len(data), 0, 0, members.ctypes.data, cap, C.byref(n), C.byref(used), C.byref(text)))
+        if used.value != len(data):
+            raise BiolibError(capi.BL_ERR_INVALID, "the buffer ends inside a BGZF member")
+        n, text = n.value, text.value
+        ptrs = []
+        try:
+            for size in (len(data) + 8, 32 * max(n, 1), text + 16, 4 * max(n, 1)):
+                p = C.c_void_p()
+                check(self._lib.bl_device_alloc(self._h, size, C.byref(p)))
+                ptrs.append(p)
+            d_packed, d_members, d_text, d_status = ptrs
+            check(self._lib.bl_copy_to_device(self._h, d_packed, data, len(data)))
+            if n:
+                check(self._lib.bl_copy_to_device(self._h, d_members, members.ctypes.data, 32 * n))
+            check(self._lib.bl_bgzf_inflate(self._h, d_packed, len(data), d_members, n, d_text, text, d_status))
+            self.sync()
+            out = np.zeros(text, np.uint8)
+            st = np.zeros(max(n, 1), np.uint32)
+            if text:
+                check(self._lib.bl_copy_to_host(self._h, out.ctypes.data, d_text, text))
+            if n:
+                check(self._lib.bl_copy_to_host(self._h, st.ctypes.data, d_status, 4 * n))
+            return out, st[:n]
+        finally:
+            for p in ptrs:
+                self._lib.bl_device_free(self._h, p)
+
     def clock_probe_start(self, duration_ms):
         """start measuring the shader clock the chip holds over the next duration_ms (beside whatever else runs)"""
         h = C.c_void_p()

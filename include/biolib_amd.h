@@ -249,6 +249,32 @@ int bl_partition_records(bl_ctx* ctx, const uint64_t* d_hashes, const uint64_t* 
 int bl_expand_super_kmers(bl_ctx* ctx, const uint64_t* d_records, uint64_t n_groups, uint32_t k, uint32_t flags, uint64_t* d_kmers, uint64_t capacity,
                           uint64_t* n_kmers);
 
+/* ---- BGZF on the device (ingest) -----------------------------------------------------------------------
+ * A bgzip'ed file is a chain of gzip members of at most 64 KiB of text each, every one an independent deflate stream: the
+ * device inflates a span's members side by side (one wavefront each) and checks their CRC-32, so that the file crosses PCIe
+ * compressed.  bl_reader_next_batch_device does this for BGZF input by itself; the two calls below are its building blocks.
+ * The reference reads .gz through zlib's gzread (tests/kseq.h:41-42 KSEQ_INIT(gzFile, gzread), tests/test_kmer_view.cpp:23-27):
+ * same text, produced here. */
+typedef struct {
+    uint64_t src_off;  /* the member's deflate data inside the packed buffer */
+    uint64_t dst_off;  /* where its text goes inside the text buffer */
+    uint32_t src_len;  /* bytes of deflate data */
+    uint32_t isize;    /* bytes of text (gzip ISIZE), <= 65536 */
+    uint32_t crc;      /* CRC-32 of the text (gzip trailer) */
+    uint32_t reserved;
+} bl_bgzf_member;
+/* Host: walk the member headers in bytes[0 .. n_bytes) and fill members[] (at most `capacity`) with offsets src_base + ... /
+ * dst_base + ...; stops in front of a member that is not completely inside the bytes.  *consumed = bytes walked, *text_bytes =
+ * the sum of the members' text sizes.  BL_ERR_INVALID for anything that is not a BGZF member header. */
+int bl_bgzf_walk(const void* bytes, uint64_t n_bytes, uint64_t src_base, uint64_t dst_base, bl_bgzf_member* members, uint64_t capacity, uint64_t* n_members,
+                 uint64_t* consumed, uint64_t* text_bytes);
+/* Device, asynchronous on the context's stream: inflate the members described by d_members[0 .. n_members) from d_packed
+ * (4-byte aligned, packed_bytes long, its allocation a whole number of dwords) into d_text (text_bytes long).  d_status[i] becomes 0 for a sound member, otherwise a
+ * non-zero code (damaged deflate data, text size or CRC-32 that differ from the trailer); a table entry that points outside the
+ * two buffers is refused, not followed, and nothing outside a member's own [dst_off, dst_off + isize) is ever written. */
+int bl_bgzf_inflate(bl_ctx* ctx, const void* d_packed, uint64_t packed_bytes, const bl_bgzf_member* d_members, uint64_t n_members, void* d_text,
+                    uint64_t text_bytes, uint32_t* d_status);
+
 /* Measurement helper: sustained HBM rates of THIS device — a read-only streaming kernel over n_bytes and a
  * device-to-device copy (read + write bytes counted), `iters` repetitions each; bench.py reports them next to the 8 TB/s spec. */
 int bl_probe_hbm(bl_ctx* ctx, uint64_t n_bytes, int iters, double* read_gbps, double* copy_gbps);

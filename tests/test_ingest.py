@@ -3,6 +3,7 @@
 make_ingest_golden.py), and — on the GPU — file -> batches -> scans against the oracle on the parsed sequences."""
 import json
 import os
+import struct
 
 import numpy as np
 import pytest
@@ -206,13 +207,13 @@ def test_fuzz_device_parser_vs_reference_reader(tmp_path):
 
 
 # ---- compressed inputs: stream gzip (one inflate thread running ahead), concatenated members, BGZF (parallel inflate) ----------
-def _bgzf(data, block=60000):
+def _bgzf(data, block=60000, eof=True):
     """BGZF (SAM spec §4.1): gzip members of <= 64 KiB with a 'BC' extra field that holds the member's size - 1, then the EOF marker"""
     import struct
     import zlib
 
     out = bytearray()
-    for a in list(range(0, len(data), block)) + [None]:
+    for a in list(range(0, len(data), block)) + ([None] if eof else []):
         chunk = b"" if a is None else data[a:a + block]
         z = zlib.compressobj(6, zlib.DEFLATED, -15)
         body = z.compress(chunk) + z.flush()
@@ -328,9 +329,14 @@ def test_text_spans_cut_awkward_records(tmp_path, kind):
 
 
 @pytest.mark.gpu
-def test_bgzf_to_device_parser_to_scan(tmp_path):
-    """.gz -> parallel inflate -> text spans -> device-side parser -> scan, against the oracle on the same reads"""
+@pytest.mark.parametrize("inflate", ["device", "host"])
+def test_bgzf_to_device_parser_to_scan(tmp_path, inflate, monkeypatch):
+    """.gz -> inflate (on the device, one wave per BGZF member; or by the host's pool) -> device-side parser -> scan, against
+    the oracle on the same reads"""
     import biolib_amd
+
+    if inflate == "host":
+        monkeypatch.setenv("BL_HOST_INFLATE", "1")
 
     rng = np.random.default_rng(8)
     n_reads, L = 200_000, 150
@@ -342,7 +348,9 @@ def test_bgzf_to_device_parser_to_scan(tmp_path):
     ctx = biolib_amd.Context(0)
     cnt = xh = xp = 0
     total = 0
+    n_batches = 0
     for b in biolib_amd.Reader(path, threads=8).device_batches(ctx, 8 << 20):
+        n_batches += 1
         g = b.minimizers_raw(31, 11, 42, biolib_amd.FLAG_CANONICAL | biolib_amd.FLAG_SYNC)
         assert b.n_bases % L == 0
         pos = b.minimizers(31, 11, seed=42, canonical=True)["positions"] + np.uint64(total)
@@ -351,4 +359,61 @@ def test_bgzf_to_device_parser_to_scan(tmp_path):
         b.close()
     d = O.minimizer_digest(seq, O.fixed_offsets(len(seq), L), 31, 11, 42, True, threads=8)
     assert total == len(seq) and (cnt, xh, xp) == (d["count"], d["xor_hash"], d["xor_pos"])
+    assert n_batches >= len(text) // (8 << 20)
+    ctx.close()
+
+
+@pytest.mark.gpu
+def test_bgzf_device_path_awkward_files(tmp_path):
+    """the compressed path (device inflate, cut decided from the end of the text on the device) on files that stress the cut:
+    wrapped FASTA with records longer than a span, FASTQ whose quality lines open with '@', CRLF, tiny spans, a file without the
+    end-of-file marker — same bases and sequence starts as the host record reader; damaged and truncated files are errors"""
+    import biolib_amd
+
+    ctx = biolib_amd.Context(0)
+    rng = np.random.default_rng(12)
+
+    def check(text, limit, eof=True, block=60000):
+        path = tmp_path / "t.gz"
+        path.write_bytes(_bgzf(text, block=block, eof=eof))
+        want = [s for _, s in biolib_amd.Reader(path).records()]
+        r = biolib_amd.Reader(path)
+        assert r.kind == "bgzf"
+        got, n_seqs = [], 0
+        for b in r.device_batches(ctx, limit):
+            got.append(bytes(b.download()))
+            n_seqs += b.n_seqs
+            b.close()
+        assert b"".join(got) == b"".join(want) and n_seqs == len(want)
+
+    # FASTA, 70-column lines, records from 1 base to 700 kbp; spans of 256 KiB: several records are longer than a span
+    lens = [1, 69, 70, 71, 5000, 700_000, 3, 300_000, 12]
+    fa = b"".join(b">c%d x>y\n" % i + b"\n".join(s[j:j + 70] for j in range(0, len(s), 70)) + b"\n"
+                  for i, s in enumerate(O.synth(30 + i, n).tobytes() for i, n in enumerate(lens)))
+    check(fa, 256 << 10)
+    check(fa, 0)
+    # FASTQ with quality lines that open with '@' and '+', CRLF line ends, spans of 64 KiB
+    seqs = [O.synth(100 + i, int(n)).tobytes() for i, n in enumerate(rng.integers(1, 400, 3000))]
+    first = [b"@", b"+", b"I", b"@", b">"]
+    for nl in (b"\n", b"\r\n"):
+        fq = b"".join(b"@r%d a@b" % i + nl + s + nl + b"+" + nl + (first[i % 5] + b"@" * (len(s) - 1))[:len(s)] + nl for i, s in enumerate(seqs))
+        check(fq, 64 << 10)
+        check(fq, 64 << 10, eof=False, block=9000)
+    # damaged / truncated
+    text = b"".join(b"@r%d\n" % i + s + b"\n+\n" + b"I" * len(s) + b"\n" for i, s in enumerate(seqs)) * 4
+    good = bytearray(_bgzf(text))
+    for how in ("flip", "truncate", "header"):
+        data = bytearray(good)
+        if how == "flip":
+            data[len(data) // 2] ^= 0x10
+        elif how == "truncate":
+            data = data[:len(data) // 2]
+        else:
+            second = struct.unpack_from("<H", data, 16)[0] + 1
+            data[second + 12] = ord("X")
+        path = tmp_path / "bad.gz"
+        path.write_bytes(bytes(data))
+        with pytest.raises(biolib_amd.BiolibError):
+            for b in biolib_amd.Reader(path).device_batches(ctx, 1 << 20):
+                b.close()
     ctx.close()
