@@ -15,6 +15,8 @@
 extern int bl_set_error(int code, const char* msg);  // bl_capi.hip
 extern hipStream_t bl_ctx_stream(bl_ctx* ctx);
 extern int bl_ctx_device(bl_ctx* ctx);
+int bl_bgzf_inflate_on(hipStream_t s, const void* d_packed, uint64_t packed_bytes, const bl_bgzf_member* d_members, uint64_t n_members, void* d_text,
+                       uint64_t text_bytes, uint32_t* d_status);
 
 namespace {
 
@@ -140,12 +142,21 @@ int bl_bgzf_walk(const void* bytes, uint64_t n_bytes, uint64_t src_base, uint64_
 int bl_bgzf_inflate(bl_ctx* ctx, const void* d_packed, uint64_t packed_bytes, const bl_bgzf_member* d_members, uint64_t n_members, void* d_text,
                     uint64_t text_bytes, uint32_t* d_status)
 {
-    if (!ctx || !d_packed || !d_members || !d_status || (!d_text && text_bytes)) return bl_set_error(BL_ERR_INVALID, "NULL argument");
+    if (!ctx) return bl_set_error(BL_ERR_INVALID, "NULL argument");
+    if (hipSetDevice(bl_ctx_device(ctx)) != hipSuccess) return bl_set_error(BL_ERR_HIP, "hipSetDevice failed");
+    return bl_bgzf_inflate_on(bl_ctx_stream(ctx), d_packed, packed_bytes, d_members, n_members, d_text, text_bytes, d_status);
+}
+
+}  // extern "C"
+
+// the same on a stream of the caller's (the reader inflates the next span on its own stream while the current one is parsed)
+int bl_bgzf_inflate_on(hipStream_t s, const void* d_packed, uint64_t packed_bytes, const bl_bgzf_member* d_members, uint64_t n_members, void* d_text,
+                       uint64_t text_bytes, uint32_t* d_status)
+{
+    if (!d_packed || !d_members || !d_status || (!d_text && text_bytes)) return bl_set_error(BL_ERR_INVALID, "NULL argument");
     if (reinterpret_cast<uintptr_t>(d_packed) & 3u) return bl_set_error(BL_ERR_INVALID, "d_packed must be 4-byte aligned");
     if (n_members == 0) return BL_OK;
     if (n_members > 0x7fffffffull) return bl_set_error(BL_ERR_INVALID, "too many members in one call");
-    if (hipSetDevice(bl_ctx_device(ctx)) != hipSuccess) return bl_set_error(BL_ERR_HIP, "hipSetDevice failed");
-    hipStream_t s = bl_ctx_stream(ctx);
     hipLaunchKernelGGL(inflate_members_kernel, dim3((unsigned)n_members), dim3(64), 0, s, static_cast<const uint8_t*>(d_packed), packed_bytes, d_members,
                        (uint32_t)n_members, static_cast<uint8_t*>(d_text), text_bytes, d_status);
     hipLaunchKernelGGL(crc_members_kernel, dim3((unsigned)n_members), dim3(64), 0, s, static_cast<const uint8_t*>(d_text), d_members, (uint32_t)n_members,
@@ -154,5 +165,3 @@ int bl_bgzf_inflate(bl_ctx* ctx, const void* d_packed, uint64_t packed_bytes, co
     if (e != hipSuccess) return bl_set_error(BL_ERR_HIP, hipGetErrorString(e));
     return BL_OK;
 }
-
-}  // extern "C"

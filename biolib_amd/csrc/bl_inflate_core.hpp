@@ -29,9 +29,14 @@
 #define BL_IDEV inline
 #define BL_LANES(l) for (int l = 0; l < 64; ++l)
 #define BL_WAVE_SYNC() ((void)0)
+#define BL_UNI(x) (x)
 #else
 #define BL_IDEV __device__ __forceinline__
 #define BL_LANES(l) for (int l = (int)(threadIdx.x & 63u), once_ = 1; once_; once_ = 0)
+// A value every lane has read from the same LDS address is the same in every lane, but the compiler cannot know: told so, it
+// keeps the decoder's state in scalar registers and its branches scalar.  (Left alone, one such value reaching the loop state
+// makes the whole symbol loop "divergent": masks instead of conditions, several extra jumps per symbol.)
+#define BL_UNI(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
 // LDS operations of one wave complete in program order; the fence keeps the compiler from moving accesses across the point
 // where the lanes exchange roles (written by one lane, read by another)
 #define BL_WAVE_SYNC()                                              \
@@ -88,14 +93,20 @@ struct Input {
     uint32_t n_bytes;
     uint32_t taken = 0;  // dwords handed out
     Input(const uint8_t* d, uint32_t n) : data(d), n_bytes(n) {}
-    uint32_t next_word()
+    uint32_t peek_word() const  // the next dword, not consumed yet
     {
         uint32_t w = 0;
         for (int b = 0; b < 4; ++b) {
             const uint32_t at = taken * 4 + b;
             if (at < n_bytes) w |= (uint32_t)data[at] << (8 * b);
         }
-        ++taken;
+        return w;
+    }
+    void advance(uint32_t n) { taken += n; }  // n = 0 or 1
+    uint32_t next_word()
+    {
+        const uint32_t w = peek_word();
+        advance(1);
         return w;
     }
     uint32_t lead_bits() const { return 0; }
@@ -124,21 +135,95 @@ struct Input {
         cur = load(0);
         nxt = load(1);
     }
-    __device__ __forceinline__ uint32_t next_word()
+    __device__ __forceinline__ uint32_t peek_word() const { return (uint32_t)__builtin_amdgcn_readlane((int)cur, (int)idx); }
+    __device__ __forceinline__ void advance(uint32_t n)  // n = 0 or 1
     {
-        const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)cur, (int)idx);
-        ++taken;
-        if (++idx == 64u) {
+        taken += n;
+        idx += n;
+        if (idx == 64u) {  // once per 256 bytes of input
             idx = 0;
             cur = nxt;
             ++chunk;
             nxt = load(chunk + 1);
         }
+    }
+    __device__ __forceinline__ uint32_t next_word()
+    {
+        const uint32_t w = peek_word();
+        advance(1);
         return w;
     }
     __device__ __forceinline__ uint32_t lead_bits() const { return lead * 8u; }
 };
 #endif
+
+// The two tables every symbol goes through leave LDS for registers once a block's codes are built, and grow on the way from
+// (symbol, code length) to everything the symbol loop needs, so that the loop neither computes nor looks up anything else:
+//   literal/length entry   bits 0-3 code length (0: longer than the root, or no code), 4-7 number of extra bits,
+//                          8-15 the literal, 16-24 the base length, bit 31 literal, bit 30 end of block, bit 29 reserved symbol
+//   distance entry         bits 0-3 code length, 4-7 number of extra bits, 8-22 the base distance, bit 29 reserved symbol
+// Entry i lives in lane i % 64 of register i / 64 (32 registers for 2048 literal/length entries, 8 for 512 distance entries);
+// a lookup is an indexed register move and a readlane.  One wave per SIMD is all the 32 KiB window leaves room for, and such a
+// wave issues one instruction every four cycles at best: what the loop costs is its instruction count, and memory latency on
+// top; both are what this layout removes.
+constexpr uint32_t E_LITERAL = 1u << 31, E_END = 1u << 30, E_RESERVED = 1u << 29;
+
+BL_IDEV uint32_t expand_ll(uint32_t sym, uint32_t code_len)
+{
+    if (sym < 256u) return E_LITERAL | (sym << 8) | code_len;
+    if (sym == 256u) return E_END | code_len;
+    if (sym > 285u) return E_RESERVED | code_len;
+    const uint32_t c = sym - 257u;
+    uint32_t base, extra;
+    if (c < 8u) { base = c + 3u; extra = 0; }
+    else if (c == 28u) { base = 258u; extra = 0; }
+    else { extra = (c >> 2) - 1u; base = ((4u + (c & 3u)) << extra) + 3u; }
+    return (base << 16) | (extra << 4) | code_len;
+}
+BL_IDEV uint32_t expand_d(uint32_t sym, uint32_t code_len)
+{
+    if (sym > 29u) return E_RESERVED | code_len;
+    uint32_t base, extra;
+    if (sym < 4u) { base = sym + 1u; extra = 0; }
+    else { extra = (sym >> 1) - 1u; base = ((2u + (sym & 1u)) << extra) + 1u; }
+    return (base << 8) | (extra << 4) | code_len;
+}
+
+#ifdef BL_INFLATE_EMU
+template <int NREG, bool DIST>
+struct RegTable {
+    uint32_t e[NREG * 64];
+    void load(const uint16_t* table)
+    {
+        for (int i = 0; i < NREG * 64; ++i) {
+            const uint32_t t = table[i];
+            e[i] = (t & 15u) ? (DIST ? expand_d(t >> 4, t & 15u) : expand_ll(t >> 4, t & 15u)) : 0u;
+        }
+    }
+    uint32_t lookup(uint32_t i) const { return e[i]; }
+};
+#else
+template <int NREG, bool DIST>
+struct RegTable {
+    typedef uint32_t regs_t __attribute__((ext_vector_type(NREG < 16 ? 16 : NREG)));  // (under 16 elements the compiler indexes a
+    regs_t regs;                                                                       // vector with a chain of selects, not a move)
+    __device__ __forceinline__ void load(const uint16_t* table)
+    {
+#pragma unroll
+        for (int r = 0; r < NREG; ++r) {
+            const uint32_t t = table[r * 64 + (int)(threadIdx.x & 63u)];
+            regs[r] = (t & 15u) ? (DIST ? expand_d(t >> 4, t & 15u) : expand_ll(t >> 4, t & 15u)) : 0u;
+        }
+    }
+    __device__ __forceinline__ uint32_t lookup(uint32_t i) const
+    {
+        const uint32_t r = (uint32_t)__builtin_amdgcn_readfirstlane((int)(i >> 6)), l = (uint32_t)__builtin_amdgcn_readfirstlane((int)(i & 63u));
+        return (uint32_t)__builtin_amdgcn_readlane((int)regs[r], (int)l);
+    }
+};
+#endif
+typedef RegTable<(1 << LL_ROOT) / 64, false> LLRegs;
+typedef RegTable<(1 << D_ROOT) / 64, true> DRegs;
 
 struct Bits {
     uint64_t bb = 0;
@@ -153,12 +238,23 @@ struct Bits {
         nb -= skip;
     }
     template <class In>
-    BL_IDEV void need32(In& in)  // at least 33 bits afterwards
+    BL_IDEV bool need32(In& in, uint32_t word_limit)  // at least 33 bits afterwards; false: the input is used up (and more)
     {
         if (nb <= 32) {
             bb |= (uint64_t)in.next_word() << nb;
             nb += 32;
+            if (in.taken > word_limit) return false;
         }
+        return true;
+    }
+    template <class In>
+    BL_IDEV void refill(In& in)  // at least 33 bits afterwards, without a branch: the symbol loop's form of need32
+    {
+        const uint32_t take = nb <= 32 ? 1u : 0u;
+        const uint64_t w = take ? (uint64_t)in.peek_word() : 0ull;
+        bb |= w << (nb & 63);
+        nb += (int)(take << 5);
+        in.advance(take);
     }
     BL_IDEV uint32_t peek(int n) const { return (uint32_t)bb & ((1u << n) - 1u); }
     BL_IDEV void drop(int n)
@@ -200,7 +296,7 @@ BL_IDEV bool build_code(Shared& sh, const uint8_t* lens, int n, int root, uint16
 #pragma unroll
     for (int l = 0; l < 16; ++l) cnt[l] = 0;
     for (int s = 0; s < n; ++s) {
-        const int l = lens[s] & 15;
+        const int l = (int)BL_UNI(lens[s] & 15);
 #pragma unroll
         for (int k = 1; k < 16; ++k) cnt[k] += (l == k);
     }
@@ -232,13 +328,13 @@ BL_IDEV bool build_code(Shared& sh, const uint8_t* lens, int n, int root, uint16
     BL_WAVE_SYNC();
     // symbols in order: the k-th symbol of a length gets that length's k-th code and k-th sorted slot
     for (int s = 0; s < n; ++s) {
-        const int l = lens[s] & 15;
+        const int l = (int)BL_UNI(lens[s] & 15);
         if (l) {
             uint32_t f = 0, base = 0;
 #pragma unroll
             for (int k = 1; k < 16; ++k)
                 if (k == l) { f = first_of[k]; base = slot_of[k]; }
-            const uint32_t slot = sh.next[l];  // (every lane does the same here: no exchange between lanes)
+            const uint32_t slot = BL_UNI(sh.next[l]);  // (every lane does the same here: no exchange between lanes)
             sh.next[l] = slot + 1;
             sorted[slot] = (uint16_t)s;
             sh.code[s] = (uint16_t)(f + (slot - base));
@@ -261,30 +357,38 @@ BL_IDEV bool build_code(Shared& sh, const uint8_t* lens, int n, int root, uint16
     return true;
 }
 
-// One symbol of a code.  Returns the symbol, or -1 when the next bits are no code of the set.
-BL_IDEV int decode_symbol(Bits& b, int root, const uint16_t* table, const uint16_t* sorted, const CodeTable& ct)
+// A code longer than its table's root (or bits that are no code at all): walk the canonical code one bit at a time.
+// Returns (symbol << 4) | code length without dropping the bits, or 0 when the bits are no code.  (One loop with one exit, not
+// unrolled: rare, and the symbol loop around it should stay small.)
+BL_IDEV uint32_t decode_long(const Bits& b, const uint16_t* sorted, const CodeTable& ct)
 {
-    const uint32_t e = table[b.peek(root)];
-    if (e) {
-        b.drop((int)(e & 15u));
-        return (int)(e >> 4);
-    }
-    // longer than the root (or nothing): walk the canonical code one bit at a time
-    uint32_t code = 0, first = 0, index = 0;
-    uint64_t bits = b.bb;
-    for (int l = 1; l < 16; ++l) {
-        code |= (uint32_t)(bits & 1u);
+    uint32_t code = 0, first = 0, index = 0, found = 0;
+    uint32_t bits = (uint32_t)b.bb;
+#pragma nounroll
+    for (uint32_t l = 1; l < 16 && !found; ++l) {
+        code |= bits & 1u;
         bits >>= 1;
-        const uint32_t c = ct.count[l];
-        if (code < first + c) {
-            b.drop(l);
-            return (int)sorted[index + (code - first)];
-        }
+        const uint32_t c = BL_UNI(ct.count[l]);
+        if (code < first + c) found = (BL_UNI(sorted[index + (code - first)]) << 4) | l;
         index += c;
         first = (first + c) << 1;
         code <<= 1;
     }
-    return -1;
+    return found;
+}
+
+// One symbol of the code-length code (used a few hundred times per block: its table stays in LDS).
+BL_IDEV int decode_cl(Bits& b, const Shared& sh)
+{
+    const uint32_t e = BL_UNI(sh.cl_table[b.peek(CL_ROOT)]);
+    if (e) {
+        b.drop((int)(e & 15u));
+        return (int)(e >> 4);
+    }
+    const uint32_t f = decode_long(b, sh.cl_sorted, sh.cl);
+    if (!f) return -1;
+    b.drop((int)(f & 15u));
+    return (int)(f >> 4);
 }
 
 BL_IDEV void copy16(uint8_t* dst, const uint8_t* src)  // both 16-byte aligned
@@ -321,24 +425,33 @@ BL_IDEV uint32_t inflate_member(Shared& sh, In& in, uint32_t n_in, uint8_t* out,
     uint8_t* const g = out - shift;  // g + q: where ring position q = text position + shift goes
     uint32_t q = shift, flushed = shift, next_flush = FLUSH;
     const uint32_t q_end = shift + isize;
-    const uint32_t words_in = (n_in + in.lead_bits() / 8u + 3u) / 4u;  // dwords that hold data
+    // the symbol loop looks at ONE bound after each symbol: the nearer of "time to flush" and "the member's text is complete"
+    uint32_t q_stop = next_flush < q_end ? next_flush : q_end;
+    const uint32_t word_limit = (n_in + in.lead_bits() / 8u + 3u) / 4u + 2u;  // dwords that hold data, and two to finish a symbol on
     Bits b;
     b.start(in);
     uint32_t status = OK;
+    LLRegs ll_regs;
+    DRegs d_regs;
+#define BL_NEED32()                                    \
+    if (!b.need32(in, word_limit)) {                   \
+        status = ERR_INPUT;                            \
+        break;                                         \
+    }
     for (;;) {
-        b.need32(in);
+        BL_NEED32();
         const uint32_t last = b.take(1), type = b.take(2);
         if (type == 0) {
             // stored: skip to the byte boundary, LEN, ~LEN, LEN bytes
             b.drop(b.nb & 7);
-            b.need32(in);
+            BL_NEED32();
             const uint32_t len = b.take(16);
-            b.need32(in);
+            BL_NEED32();
             const uint32_t nlen = b.take(16);
             if ((len ^ nlen) != 0xffffu) { status = ERR_STORED; break; }
             if (q + len > q_end) { status = ERR_OVERRUN; break; }
             for (uint32_t i = 0; i < len; ++i) {
-                b.need32(in);
+                BL_NEED32();
                 sh.ring[q & (WINDOW - 1)] = (uint8_t)b.take(8);
                 ++q;
                 if (q >= next_flush) {
@@ -347,9 +460,9 @@ BL_IDEV uint32_t inflate_member(Shared& sh, In& in, uint32_t n_in, uint8_t* out,
                     flushed = next_flush;
                     next_flush += FLUSH;
                 }
-                if ((i & 1023u) == 0 && in.taken > words_in + 2u) break;
             }
-            if (in.taken > words_in + 2u) { status = ERR_INPUT; break; }
+            if (status != OK) break;
+            q_stop = next_flush < q_end ? next_flush : q_end;
         } else if (type == 3) {
             status = ERR_BLOCK_TYPE;
             break;
@@ -373,13 +486,14 @@ BL_IDEV uint32_t inflate_member(Shared& sh, In& in, uint32_t n_in, uint8_t* out,
                     if (lane < 19) sh.lens[lane] = 0;
                 }
                 BL_WAVE_SYNC();
-                for (int i = 0; i < n_cl; ++i) {
-                    b.need32(in);
+                for (int i = 0; i < n_cl && status == OK; ++i) {
+                    if (!b.need32(in, word_limit)) status = ERR_INPUT;
                     const uint8_t v = (uint8_t)b.take(3);
                     // the order in which the lengths of the code-length code are sent: 16 17 18 0 8 7 9 6 10 5 11 4 12 3 13 2 14 1 15
                     const int at = i < 3 ? 16 + i : i == 3 ? 0 : (i & 1) ? (19 - i) >> 1 : 6 + (i >> 1);
                     sh.lens[at] = v;  // (every lane stores the same byte)
                 }
+                if (status != OK) break;
                 BL_WAVE_SYNC();
                 if (!build_code(sh, sh.lens, 19, CL_ROOT, sh.cl_table, sh.cl_sorted, sh.cl, false)) { status = ERR_CODE_SET; break; }
                 // the lengths of the two codes, run-length coded with the code just built (whose decoder no longer reads sh.lens:
@@ -389,8 +503,8 @@ BL_IDEV uint32_t inflate_member(Shared& sh, In& in, uint32_t n_in, uint8_t* out,
                 uint8_t prev = 0;
                 uint8_t* const lens = sh.lens;
                 while (have < total) {
-                    b.need32(in);
-                    const int s = decode_symbol(b, CL_ROOT, sh.cl_table, sh.cl_sorted, sh.cl);
+                    BL_NEED32();
+                    const int s = decode_cl(b, sh);
                     if (s < 0) { status = ERR_SYMBOL; break; }
                     int rep;
                     uint8_t v;
@@ -420,75 +534,88 @@ BL_IDEV uint32_t inflate_member(Shared& sh, In& in, uint32_t n_in, uint8_t* out,
                         }
                     }
                     have += rep;
-                    if (in.taken > words_in + 2u) { status = ERR_INPUT; break; }
                 }
                 if (status != OK) break;
                 BL_WAVE_SYNC();
-                if (sh.lens[256] == 0) { status = ERR_HEADER; break; }  // no end-of-block code
+                if (BL_UNI(sh.lens[256]) == 0) { status = ERR_HEADER; break; }  // no end-of-block code
             }
             if (!build_code(sh, sh.lens, n_ll, LL_ROOT, sh.ll_table, sh.ll_sorted, sh.ll, true)) { status = ERR_CODE_SET; break; }
             if (!build_code(sh, sh.lens + MAX_LL, n_d, D_ROOT, sh.d_table, sh.d_sorted, sh.d, true)) { status = ERR_CODE_SET; break; }
-            // the symbols of the block
-            for (;;) {
-                b.need32(in);
-                const int s = decode_symbol(b, LL_ROOT, sh.ll_table, sh.ll_sorted, sh.ll);
-                if (s < 256) {
-                    if (s < 0) { status = ERR_SYMBOL; break; }
-                    if (q >= q_end) { status = ERR_OVERRUN; break; }
-                    sh.ring[q & (WINDOW - 1)] = (uint8_t)s;  // (the same store from every lane)
-                    ++q;
-                } else {
-                    if (s == 256) break;
-                    if (s > 285) { status = ERR_SYMBOL; break; }
-                    const int c = s - 257;
-                    uint32_t len;
-                    if (c < 8) len = (uint32_t)c + 3u;
-                    else if (c == 28) len = 258u;
-                    else {
-                        const int eb = (c >> 2) - 1;
-                        len = ((4u + (uint32_t)(c & 3)) << eb) + 3u + b.take(eb);
+            ll_regs.load(sh.ll_table);
+            d_regs.load(sh.d_table);
+            // The symbols of the block.  The loop is written for the instruction count and for plain control flow (one exit, no
+            // jumps out of nested blocks: anything else costs this compiler several extra jumps per symbol): whatever can go
+            // wrong is gathered in `bad` and looked at together with the one bound on q, and a wrong path only ever touches
+            // the ring (whose index is masked) before it is noticed.
+            uint32_t bad = 0, stop = 0;
+            do {
+                b.refill(in);
+                uint32_t e = ll_regs.lookup(b.peek(LL_ROOT));
+                if ((e & 15u) == 0) {  // rare: a code longer than the root
+                    const uint32_t f = decode_long(b, sh.ll_sorted, sh.ll);
+                    e = f ? expand_ll(f >> 4, f & 15u) : (E_RESERVED | 1u);
+                }
+                b.drop((int)(e & 15u));
+                if (e & E_LITERAL) {
+                    sh.ring[q & (WINDOW - 1)] = (uint8_t)(e >> 8);  // (the same store from every lane; one byte past the text's end
+                    ++q;                                             // is caught below before anything leaves the ring)
+                } else if ((e & (E_END | E_RESERVED)) == 0) {
+                    const uint32_t len = (e >> 16) + b.take((int)((e >> 4) & 15u));
+                    b.refill(in);
+                    uint32_t de = d_regs.lookup(b.peek(D_ROOT));
+                    if ((de & 15u) == 0) {
+                        const uint32_t f = decode_long(b, sh.d_sorted, sh.d);
+                        de = f ? expand_d(f >> 4, f & 15u) : (E_RESERVED | 1u);
                     }
-                    b.need32(in);
-                    const int ds = decode_symbol(b, D_ROOT, sh.d_table, sh.d_sorted, sh.d);
-                    if (ds < 0 || ds > 29) { status = ERR_SYMBOL; break; }
-                    uint32_t dist;
-                    if (ds < 4) dist = (uint32_t)ds + 1u;
-                    else {
-                        const int eb = (ds >> 1) - 1;
-                        dist = ((2u + (uint32_t)(ds & 1)) << eb) + 1u + b.take(eb);
-                    }
-                    if (dist > q - shift) { status = ERR_DISTANCE; break; }
-                    if (q + len > q_end) { status = ERR_OVERRUN; break; }
+                    b.drop((int)(de & 15u));
+                    const uint32_t dist = ((de >> 8) & 0x7fffu) + b.take((int)((de >> 4) & 15u));
+                    bad |= (de & E_RESERVED) | (uint32_t)(dist > q - shift);
                     BL_WAVE_SYNC();  // the literals written since the last match are in the ring
                     const uint32_t from = q - dist;
+                    // (most matches are shorter than a wave is wide: one masked read and write, no loop)
                     if (dist >= len) {
                         BL_LANES(lane)
                         {
-                            for (uint32_t i = (uint32_t)lane; i < len; i += 64) sh.ring[(q + i) & (WINDOW - 1)] = sh.ring[(from + i) & (WINDOW - 1)];
+                            if ((uint32_t)lane < len) sh.ring[(q + lane) & (WINDOW - 1)] = sh.ring[(from + lane) & (WINDOW - 1)];
+                            for (uint32_t i = (uint32_t)lane + 64u; i < len; i += 64) sh.ring[(q + i) & (WINDOW - 1)] = sh.ring[(from + i) & (WINDOW - 1)];
                         }
-                    } else {  // the match runs into itself: its first `dist` bytes repeat
+                    } else {  // the match runs into itself: its first `dist` bytes repeat (dist < 258 here; 0 only on a wrong path)
+                        const uint32_t period = dist ? dist : 1u;
                         BL_LANES(lane)
                         {
-                            for (uint32_t i = (uint32_t)lane; i < len; i += 64) sh.ring[(q + i) & (WINDOW - 1)] = sh.ring[(from + i % dist) & (WINDOW - 1)];
+                            for (uint32_t i = (uint32_t)lane; i < len; i += 64) sh.ring[(q + i) & (WINDOW - 1)] = sh.ring[(from + i % period) & (WINDOW - 1)];
                         }
                     }
                     BL_WAVE_SYNC();
                     q += len;
+                } else {
+                    stop = e;  // end of block, or a reserved symbol
                 }
-                if (q >= next_flush) {
-                    BL_WAVE_SYNC();
-                    flush_range(sh, g, flushed, next_flush);
-                    flushed = next_flush;
-                    next_flush += FLUSH;
+                if ((q >= q_stop) | (bad != 0) | (in.taken > word_limit)) {
+                    if (in.taken > word_limit) status = ERR_INPUT;
+                    else if (bad) status = (bad & E_RESERVED) ? ERR_SYMBOL : ERR_DISTANCE;
+                    else if (q > q_end) status = ERR_OVERRUN;
+                    else {
+                        if (q >= next_flush) {
+                            BL_WAVE_SYNC();
+                            flush_range(sh, g, flushed, next_flush);
+                            flushed = next_flush;
+                            next_flush += FLUSH;
+                        }
+                        // at the text's end only the end-of-block code may follow: the bound then sits one past it
+                        q_stop = q == q_end ? q_end + 1u : (next_flush < q_end ? next_flush : q_end);
+                    }
+                    if (status != OK) stop = E_RESERVED;
                 }
-                if (in.taken > words_in + 2u) { status = ERR_INPUT; break; }
-            }
+            } while (!stop);
+            if (status == OK && (stop & E_RESERVED)) status = ERR_SYMBOL;
             if (status != OK) break;
         }
         if (last) break;
-        if (in.taken > words_in + 2u) { status = ERR_INPUT; break; }
     }
+#undef BL_NEED32
     BL_WAVE_SYNC();
+    if (q > q_end) q = q_end;  // (a literal one past the end was refused above; it stays in the ring)
     if (q > flushed) flush_range(sh, g, flushed, q);  // what a damaged stream produced before it failed is within [0, isize) too
     if (status == OK) {
         const uint32_t bits_used = in.taken * 32u - (uint32_t)b.nb - in.lead_bits();

@@ -21,6 +21,7 @@
 #include <zlib.h>
 
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
@@ -40,6 +41,8 @@
 extern int bl_set_error(int code, const char* msg);  // bl_capi.hip
 extern hipStream_t bl_ctx_stream(bl_ctx* ctx);
 extern int bl_ctx_device(bl_ctx* ctx);
+extern int bl_bgzf_inflate_on(hipStream_t s, const void* d_packed, uint64_t packed_bytes, const bl_bgzf_member* d_members, uint64_t n_members, void* d_text,
+                              uint64_t text_bytes, uint32_t* d_status);  // bl_inflate.hip
 extern int bl_parse_device_text(bl_ctx* ctx, const uint8_t* d_text, uint64_t n_bytes, char first_byte, const char* ends, uint64_t ends_n, bl_batch** out,
                                 uint64_t* n_seqs, uint64_t* n_bases);  // bl_parse.hip
 
@@ -885,13 +888,35 @@ struct DeviceBgzf {
     size_t carry_n = 0;
     bool eof = false;
     char first_byte = 0;
-    std::vector<char> window;
-    std::vector<uint32_t> status;
+    // what comes back from the device lands in page-locked memory: a copy into pageable memory would make the host wait for
+    // everything queued in front of it (the inflate kernel), and nothing would overlap
+    char* window = nullptr;
+    uint32_t* status = nullptr;
+    char* first_back = nullptr;
+    bl_bgzf_member* members_up = nullptr;  // (and the member table goes up from page-locked memory, for the same reason)
+    size_t window_cap = 0, status_cap = 0, members_up_cap = 0;
+    hipStream_t stream = nullptr;  // upload + inflate of the NEXT span run here while the current text is parsed on the context's stream
+    struct {
+        bool active = false;
+        size_t n_members = 0, filled = 0;
+        int buf = 0;
+    } pending;
+    double t_launch = 0, t_wait = 0, t_parse = 0;  // seconds spent starting spans, waiting for inflate, parsing (BL_INGEST_TRACE=1 prints them)
+    unsigned n_batches = 0;
     ~DeviceBgzf()
     {
+        if (std::getenv("BL_INGEST_TRACE"))
+            std::fprintf(stderr, "[bl ingest] compressed path: %u batches, launch %.1f ms, wait for inflate %.1f ms, parse %.1f ms\n", n_batches, t_launch * 1e3,
+                         t_wait * 1e3, t_parse * 1e3);
+        if (stream) {
+            (void)hipStreamSynchronize(stream);
+            (void)hipStreamDestroy(stream);
+        }
         spans.reset();
         for (void* p : {d_packed, d_members, (void*)d_text[0], (void*)d_text[1]})  // (d_status lies inside d_members)
             if (p) (void)hipFree(p);
+        for (void* p : {(void*)window, (void*)status, (void*)first_back, (void*)members_up})
+            if (p) (void)hipHostFree(p);
     }
 };
 
@@ -1048,6 +1073,23 @@ namespace {
         if (e_ != hipSuccess) return bl_set_error(e_ == hipErrorOutOfMemory ? BL_ERR_OOM : BL_ERR_HIP, hipGetErrorString(e_)); \
     } while (0)
 
+// page-locked host memory of at least `need` bytes (contents not kept)
+int pinned_reserve_raw(void** p, size_t* cap, size_t need)
+{
+    if (need <= *cap) return BL_OK;
+    size_t want = *cap ? *cap : 4096;
+    while (want < need) want *= 2;
+    if (*p) R_HIP(hipHostFree(*p));
+    *p = nullptr;
+    *cap = 0;
+    void* q = nullptr;
+    R_HIP(hipHostMalloc(&q, want, hipHostMallocPortable));
+    *p = q;
+    *cap = want;
+    return BL_OK;
+}
+#define pinned_reserve(pp, cap, need) pinned_reserve_raw(reinterpret_cast<void**>(pp), cap, need)
+
 // a device buffer of at least `need` bytes that keeps its first `keep` bytes
 int device_reserve(void** p, size_t* cap, size_t need, size_t keep, hipStream_t s)
 {
@@ -1067,58 +1109,98 @@ int device_reserve(void** p, size_t* cap, size_t need, size_t keep, hipStream_t 
     return BL_OK;
 }
 
-// One batch from the compressed path (*out NULL at the end of the file).
-int next_batch_packed(bl_ctx* ctx, bl_reader* r, size_t limit, bl_batch** out, uint64_t* n_seqs, uint64_t* n_bases)
+// Take the next packed span and start inflating it into text[buf] behind the `offset` bytes that are there already.
+int launch_packed(DeviceBgzf& d, int buf, size_t offset)
+{
+    hipStream_t s = d.stream;
+    PackedSpan* sp = nullptr;
+    if (!d.eof) {
+        const int rc = d.spans->next(&sp);  // (releases the previous span's buffer: its upload was waited for)
+        if (rc < 0) return bl_set_error(BL_ERR_INVALID, "error reading the (compressed) stream");
+        if (rc == 0) d.eof = true;
+    }
+    const size_t add = sp ? (size_t)sp->text_bytes : 0, filled = offset + add;
+    {
+        void* p = d.d_text[buf];
+        const int rc = device_reserve(&p, &d.text_cap[buf], filled + 64, offset, s);
+        d.d_text[buf] = static_cast<uint8_t*>(p);
+        if (rc != BL_OK) return rc;
+    }
+    const size_t n_members = sp ? sp->members.size() : 0;
+    if (n_members) {
+        int rc = device_reserve(&d.d_packed, &d.packed_cap, sp->n + 8, 0, s);
+        if (rc == BL_OK) rc = device_reserve(&d.d_members, &d.members_cap, n_members * (sizeof(bl_bgzf_member) + sizeof(uint32_t)), 0, s);
+        if (rc != BL_OK) return rc;
+        d.d_status = reinterpret_cast<uint32_t*>(static_cast<char*>(d.d_members) + n_members * sizeof(bl_bgzf_member));
+        R_HIP(hipMemcpyAsync(d.d_packed, sp->p, sp->n, hipMemcpyHostToDevice, s));
+        rc = pinned_reserve(&d.members_up, &d.members_up_cap, n_members * sizeof(bl_bgzf_member));
+        if (rc != BL_OK) return rc;
+        std::memcpy(d.members_up, sp->members.data(), n_members * sizeof(bl_bgzf_member));  // (the previous table's copy was waited for)
+        R_HIP(hipMemcpyAsync(d.d_members, d.members_up, n_members * sizeof(bl_bgzf_member), hipMemcpyHostToDevice, s));
+        rc = bl_bgzf_inflate_on(s, d.d_packed, sp->n, static_cast<const bl_bgzf_member*>(d.d_members), n_members, d.d_text[buf] + offset, add, d.d_status);
+        if (rc != BL_OK) return rc;
+        rc = pinned_reserve(&d.status, &d.status_cap, n_members * sizeof(uint32_t));
+        if (rc != BL_OK) return rc;
+        R_HIP(hipMemcpyAsync(d.status, d.d_status, n_members * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    }
+    d.pending.active = true;
+    d.pending.n_members = n_members;
+    d.pending.filled = filled;
+    d.pending.buf = buf;
+    return BL_OK;
+}
+
+// One batch from the compressed path (*out NULL at the end of the file).  The span after the one returned is uploaded and
+// inflated on the reader's own stream before this call parses its text, so that it overlaps the parse and whatever the caller
+// does with the batch (the inflate kernel leaves most of every CU's issue slots free: one wave per SIMD).
+int next_batch_packed(bl_ctx* ctx, bl_reader* r, bl_batch** out, uint64_t* n_seqs, uint64_t* n_bases)
 {
     DeviceBgzf& d = *r->packed;
     if (d.ctx != ctx) return bl_set_error(BL_ERR_INVALID, "a reader's device batches must all go to the same context");
     R_HIP(hipSetDevice(bl_ctx_device(ctx)));
-    hipStream_t s = bl_ctx_stream(ctx);
+    if (!d.stream) R_HIP(hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking));
+    hipStream_t s = d.stream;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     for (;;) {
-        PackedSpan* sp = nullptr;
-        if (!d.eof) {
-            const int rc = d.spans->next(&sp);
-            if (rc < 0) return bl_set_error(BL_ERR_INVALID, "error reading the (compressed) stream");
-            if (rc == 0) d.eof = true;
-        }
-        if (d.eof && d.carry_n == 0) return BL_OK;  // end of file
-        const size_t add = sp ? (size_t)sp->text_bytes : 0, filled = d.carry_n + add;
-        {
-            void* p = d.d_text[d.cur];
-            const int rc = device_reserve(&p, &d.text_cap[d.cur], filled + 64, d.carry_n, s);
-            d.d_text[d.cur] = static_cast<uint8_t*>(p);
+        if (!d.pending.active) {
+            const double t0 = now();
+            const int rc = launch_packed(d, d.cur, d.carry_n);
+            d.t_launch += now() - t0;
             if (rc != BL_OK) return rc;
         }
-        uint8_t* const text = d.d_text[d.cur];
-        const size_t n_members = sp ? sp->members.size() : 0;
-        if (n_members) {
-            int rc = device_reserve(&d.d_packed, &d.packed_cap, sp->n + 8, 0, s);
-            if (rc == BL_OK) rc = device_reserve(&d.d_members, &d.members_cap, n_members * (sizeof(bl_bgzf_member) + sizeof(uint32_t)), 0, s);
-            if (rc != BL_OK) return rc;
-            d.d_status = reinterpret_cast<uint32_t*>(static_cast<char*>(d.d_members) + n_members * sizeof(bl_bgzf_member));
-            R_HIP(hipMemcpyAsync(d.d_packed, sp->p, sp->n, hipMemcpyHostToDevice, s));
-            R_HIP(hipMemcpyAsync(d.d_members, sp->members.data(), n_members * sizeof(bl_bgzf_member), hipMemcpyHostToDevice, s));
-            rc = bl_bgzf_inflate(ctx, d.d_packed, sp->n, static_cast<const bl_bgzf_member*>(d.d_members), n_members, text + d.carry_n, add, d.d_status);
-            if (rc != BL_OK) return rc;
-            d.status.resize(n_members);
-            R_HIP(hipMemcpyAsync(d.status.data(), d.d_status, n_members * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-        }
-        if (filled == 0) {  // members without text (the end-of-file marker)
-            R_HIP(hipStreamSynchronize(s));  // the span's buffer is released by the next call to next()
+        d.pending.active = false;
+        const size_t filled = d.pending.filled, n_members = d.pending.n_members;
+        uint8_t* const text = d.d_text[d.pending.buf];
+        d.cur = d.pending.buf;
+        if (filled == 0) {
+            R_HIP(hipStreamSynchronize(s));  // (members without text: the end-of-file marker)
+            for (size_t i = 0; i < n_members; ++i)
+                if (d.status[i] != 0) return bl_set_error(BL_ERR_INVALID, "error reading the (compressed) stream");
+            if (d.eof) return BL_OK;  // end of file
             continue;
         }
         // the end of the text comes back to the host: the cut is decided there
         size_t win = filled < ((size_t)256 << 10) ? filled : (size_t)256 << 10;
         size_t cut = 0;
         for (;;) {
-            d.window.resize(win + 1);
-            R_HIP(hipMemcpyAsync(d.window.data(), text + (filled - win), win, hipMemcpyDeviceToHost, s));
-            if (!d.first_byte) R_HIP(hipMemcpyAsync(&d.first_byte, text, 1, hipMemcpyDeviceToHost, s));
+            {
+                int rc = pinned_reserve(&d.window, &d.window_cap, win + 1);
+                if (rc == BL_OK && !d.first_back) {
+                    size_t one = 0;
+                    rc = pinned_reserve(&d.first_back, &one, 64);
+                }
+                if (rc != BL_OK) return rc;
+            }
+            R_HIP(hipMemcpyAsync(d.window, text + (filled - win), win, hipMemcpyDeviceToHost, s));
+            if (!d.first_byte) R_HIP(hipMemcpyAsync(d.first_back, text, 1, hipMemcpyDeviceToHost, s));
+            const double t0 = now();
             R_HIP(hipStreamSynchronize(s));
+            d.t_wait += now() - t0;
+            if (!d.first_byte) d.first_byte = d.first_back[0];
             for (size_t i = 0; i < n_members; ++i)
                 if (d.status[i] != 0) return bl_set_error(BL_ERR_INVALID, "error reading the (compressed) stream");
             if (d.eof) { cut = filled; break; }
-            const size_t at = find_record_cut(d.window.data(), win, win, d.first_byte == '@' ? 'q' : 'a');
+            const size_t at = find_record_cut(d.window, win, win, d.first_byte == '@' ? 'q' : 'a');
             if (at >= 64 || (at > 0 && win == filled)) { cut = (filled - win) + at; break; }  // (64: the parser wants to see the bytes in front of the cut)
             if (win == filled) break;  // no boundary in all of it: one record longer than the span
             win = win * 8 < filled ? win * 8 : filled;
@@ -1138,9 +1220,19 @@ int next_batch_packed(bl_ctx* ctx, bl_reader* r, size_t limit, bl_batch** out, u
         }
         d.cur = other;
         d.carry_n = rest;
+        if (!d.eof) {  // the next span starts now, behind the bytes just moved
+            const double t0 = now();
+            const int rc = launch_packed(d, d.cur, d.carry_n);
+            d.t_launch += now() - t0;
+            if (rc != BL_OK) return rc;
+        }
         const size_t ends_n = cut < 64 ? cut : 64;
-        const char* ends = d.window.data() + (cut - (filled - win)) - ends_n;
-        return bl_parse_device_text(ctx, text, cut, d.first_byte, ends, ends_n, out, n_seqs, n_bases);
+        const char* ends = d.window + (cut - (filled - win)) - ends_n;
+        const double t0 = now();
+        const int rc = bl_parse_device_text(ctx, text, cut, d.first_byte, ends, ends_n, out, n_seqs, n_bases);
+        d.t_parse += now() - t0;
+        ++d.n_batches;
+        return rc;
     }
 }
 
@@ -1162,7 +1254,7 @@ int bl_reader_next_batch_device(bl_ctx* ctx, bl_reader* r, uint64_t max_text_byt
     }
     if (r->packed) {
         if (r->records || r->text) return bl_set_error(BL_ERR_INVALID, "records, spans and device batches cannot be mixed on one reader");
-        return next_batch_packed(ctx, r, max_text_bytes ? (size_t)max_text_bytes : (size_t)64 << 20, out, n_seqs, n_bases);
+        return next_batch_packed(ctx, r, out, n_seqs, n_bases);
     }
     const char* text = nullptr;
     uint64_t n = 0;

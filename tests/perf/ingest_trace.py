@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Where the time of the compressed (BGZF -> device inflate) ingest path goes: one pass over a synthetic bgzip'ed FASTQ with
+BL_INGEST_TRACE=1 (the reader prints its own phase times), with and without the scan behind each batch."""
+import os, struct, sys, tempfile, time, zlib
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+os.environ["BL_INGEST_TRACE"] = "1"
+import numpy as np
+import biolib_amd as B
+import oracle_lib as O
+
+
+def bgzf(data, level=1, block=65280):
+    out = bytearray()
+    for a in list(range(0, len(data), block)) + [None]:
+        chunk = b"" if a is None else data[a:a + block]
+        z = zlib.compressobj(level, zlib.DEFLATED, -15)
+        body = z.compress(chunk) + z.flush()
+        out += b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, 12 + 6 + len(body) + 8 - 1)
+        out += body + struct.pack("<II", zlib.crc32(chunk) & 0xFFFFFFFF, len(chunk))
+    return bytes(out)
+
+
+n_reads = int(sys.argv[1]) if len(sys.argv) > 1 else 4_000_000
+span = (int(sys.argv[2]) if len(sys.argv) > 2 else 64) << 20
+seq = O.synth(42, n_reads * 150).reshape(n_reads, 150)
+text = b"".join(b"@r%d\n" % i + seq[i].tobytes() + b"\n+\n" + b"I" * 150 + b"\n" for i in range(n_reads))
+with tempfile.TemporaryDirectory() as d:
+    path = os.path.join(d, "r.bgzf.gz")
+    open(path, "wb").write(bgzf(text))
+    ctx = B.Context(0)
+    for scan in (False, True, True):
+        t0 = time.perf_counter(); nb = 0
+        r = B.Reader(path)
+        for batch in r.device_batches(ctx, span):
+            nb += batch.n_bases
+            if scan:
+                batch.minimizers_raw(31, 11, 42, B.FLAG_CANONICAL | B.FLAG_SYNC)
+            batch.close()
+        r.close()
+        dt = time.perf_counter() - t0
+        print(f"scan={scan}: {nb / dt / 1e9:.2f} Gbp/s ({dt * 1e3:.0f} ms)", flush=True)
