@@ -18,6 +18,7 @@
 #include <rocprim/device/device_scan.hpp>
 #include <rocprim/device/device_radix_sort.hpp>
 
+#include <algorithm>
 #include <vector>
 
 #include "../../include/biolib_amd.h"
@@ -47,6 +48,28 @@ __device__ __forceinline__ unsigned base_at(unsigned long long hi, unsigned long
     return i < 32 ? (unsigned)(hi >> (62 - 2 * i)) & 3u : (unsigned)(lo >> (62 - 2 * (i - 32))) & 3u;
 }
 
+// 8 bases at `at` as 16 bits of 2-bit codes, the first base in the two most significant bits: one (unaligned) 8-byte load and
+// a dozen word operations instead of 8 byte loads (the records of neighbouring groups overlap by k - 1 bases: the loads hit in L1)
+struct __attribute__((packed)) Unaligned8 {
+    unsigned long long v;
+};
+__device__ __forceinline__ unsigned long long codes8(const unsigned char* __restrict__ bases, unsigned long long at, unsigned long long n_bases)
+{
+    unsigned long long w = 0;
+    if (at + 8 <= n_bases) {
+        w = reinterpret_cast<const Unaligned8*>(bases + at)->v;
+    } else {  // the last bytes of the batch (a borrowed buffer has nothing behind them that may be read)
+        for (int i = 0; i < 8; ++i)
+            if (at + i < n_bases) w |= (unsigned long long)bases[at + i] << (8 * i);
+    }
+    w = __builtin_bswap64(w);                                            // first base in the most significant byte
+    unsigned long long x = ((w >> 1) ^ (w >> 2)) & 0x0303030303030303ULL;  // code_of() of all eight bytes
+    x = (x | (x >> 6)) & 0x000f000f000f000fULL;
+    x = (x | (x >> 12)) & 0x000000ff000000ffULL;
+    x = (x | (x >> 24)) & 0xffffULL;
+    return x;
+}
+
 __global__ __launch_bounds__(256) void pack_kernel(const unsigned char* __restrict__ bases, unsigned long long n_bases,
                                                    const unsigned long long* __restrict__ first_pos, const unsigned char* __restrict__ sizes,
                                                    const unsigned char* __restrict__ mm_pos, unsigned long long n, int k, ulonglong2* __restrict__ out)
@@ -58,11 +81,16 @@ __global__ __launch_bounds__(256) void pack_kernel(const unsigned char* __restri
     int nb = size + k - 1;
     if (p + (unsigned long long)nb > n_bases) nb = p < n_bases ? (int)(n_bases - p) : 0;  // never read past the batch (a caller error; the record is then short)
     unsigned long long hi = 0, lo = 0;
-    const int n_hi = nb < 32 ? nb : 32;
-    for (int i = 0; i < n_hi; ++i) hi = (hi << 2) | code_of(bases[p + i]);
-    if (n_hi < 32) hi <<= 2 * (32 - n_hi);
-    for (int i = 32; i < nb; ++i) lo = (lo << 2) | code_of(bases[p + i]);
-    if (nb > 32) lo <<= 64 - 2 * (nb - 32);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (8 * j < nb) hi |= codes8(bases, p + 8 * j, n_bases) << (48 - 16 * j);
+#pragma unroll
+    for (int j = 4; j < 8; ++j)
+        if (8 * j < nb) lo |= codes8(bases, p + 8 * j, n_bases) << (48 - 16 * (j - 4));
+    // bases beyond the record's own are not part of it
+    if (nb < 32) hi &= nb ? ~0ULL << (64 - 2 * nb) : 0ULL;
+    if (nb > 32 && nb < 64) lo &= ~0ULL << (64 - 2 * (nb - 32));
+    if (nb <= 32) lo = 0;
     const unsigned long long mp = mm_pos ? (unsigned long long)(mm_pos[g] & 31u) : 0ULL;
     out[g] = make_ulonglong2(hi, (lo & ~0x3ffULL) | (mp << 5) | (unsigned long long)((size - 1) & 31));
 }
@@ -123,6 +151,7 @@ __global__ __launch_bounds__(256) void expand_kernel(const ulonglong2* __restric
 constexpr int CT_SLOTS = 1024;  // table slots of ONE WAVE
 constexpr int CT_CAP = 700;     // k-mers a bucket may hold to be counted in the table (load <= 0.68)
 constexpr int CT_RECS = 64;     // records a bucket may hold (one per lane)
+constexpr int CT_WIDE = 2;      // k-mers a lane inserts per round
 constexpr int CT_WAVES = 2;     // waves per workgroup (14.4 KB of LDS per wave: 5 workgroups = 10 waves per CU)
 constexpr unsigned long long CT_EMPTY = ~0ULL;  // never a k-mer for k < 32, nor a canonical 32-mer (its reverse complement is 0)
 
@@ -201,24 +230,28 @@ __device__ __forceinline__ bool table_probe(WaveTable& t, uint32_t h, unsigned l
     return old == CT_EMPTY || old == key;
 }
 
-// two keys at once (has2 = false: only the first): both first probes are issued before either result is looked at, so their LDS
-// round trips overlap; the few that collide (load <= 0.68) walk on one by one.  The table never fills.
-__device__ __forceinline__ void table_insert2(WaveTable& t, unsigned long long key1, unsigned long long key2, bool has2)
+// W keys at once (live[i] = false: key i is not there): all first probes are issued before any result is looked at, so their
+// LDS round trips overlap; the few that collide (load <= 0.68) walk on one by one.  The table never fills.
+template <int W>
+__device__ __forceinline__ void table_insert_many(WaveTable& t, const unsigned long long (&key)[W], const bool (&live)[W])
 {
-    uint32_t h1 = table_slot(key1), h2 = table_slot(key2);
-    const unsigned long long old1 = atomicCAS(&t.keys[h1], CT_EMPTY, key1);
-    const unsigned long long old2 = has2 ? atomicCAS(&t.keys[h2], CT_EMPTY, key2) : key2;
-    bool ok1 = old1 == CT_EMPTY || old1 == key1, ok2 = old2 == CT_EMPTY || old2 == key2;
-    while (!ok1) {
-        h1 = (h1 + 1) & (CT_SLOTS - 1);
-        ok1 = table_probe(t, h1, key1);
+    uint32_t h[W];
+    unsigned long long old[W];
+#pragma unroll
+    for (int i = 0; i < W; ++i) h[i] = table_slot(key[i]);
+#pragma unroll
+    for (int i = 0; i < W; ++i) old[i] = live[i] ? atomicCAS(&t.keys[h[i]], CT_EMPTY, key[i]) : key[i];
+#pragma unroll
+    for (int i = 0; i < W; ++i) {
+        bool ok = old[i] == CT_EMPTY || old[i] == key[i];
+        while (!ok) {
+            h[i] = (h[i] + 1) & (CT_SLOTS - 1);
+            ok = table_probe(t, h[i], key[i]);
+        }
     }
-    while (!ok2) {
-        h2 = (h2 + 1) & (CT_SLOTS - 1);
-        ok2 = table_probe(t, h2, key2);
-    }
-    atomicAdd(&t.cnt[h1], 1u);
-    if (has2) atomicAdd(&t.cnt[h2], 1u);
+#pragma unroll
+    for (int i = 0; i < W; ++i)
+        if (live[i]) atomicAdd(&t.cnt[h[i]], 1u);
 }
 
 __device__ __forceinline__ unsigned long long kmer_of(ulonglong2 r, int q, int k, int canonical, unsigned long long kmask)
@@ -250,13 +283,44 @@ __device__ __forceinline__ void list_overflow(int lane, uint32_t lo, uint32_t hi
     }
 }
 
+// Where the counted k-mers go when they are written in the same pass that counts them (no second pass over the buckets to learn
+// the offsets first): every wave fills chunks of CT_CHUNK output slots that it takes from one global cursor, a bucket's k-mers
+// going to the rest of the wave's current chunk and on into a fresh one, so that only each wave's LAST chunk is left partly
+// empty.  Those holes (one per wave, noted at the end of the kernel) are filled afterwards from the end of the array
+// (fill_holes_kernel).  Positions at or beyond the caller's capacity land in a side buffer of one chunk per wave: that is how far
+// the holes can push the end of the array beyond the number of distinct k-mers.
+constexpr unsigned int CT_CHUNK = 4096;
+struct CountedOut {
+    unsigned long long* keys;
+    unsigned int* counts;
+    unsigned long long capacity;
+    unsigned long long* ext_keys;
+    unsigned int* ext_counts;
+    unsigned long long ext_n;
+    unsigned long long* cursor;  // [0] next free chunk, [1] buckets listed for the fallback, [2] distinct k-mers counted
+    ulonglong2* holes;           // per wave: [first unused slot, end) of its last chunk
+};
+__device__ __forceinline__ void put_counted(const CountedOut& o, unsigned long long pos, unsigned long long key, unsigned int c)
+{
+    if (pos < o.capacity) {
+        o.keys[pos] = key;
+        o.counts[pos] = c;
+    } else if (pos - o.capacity < o.ext_n) {
+        o.ext_keys[pos - o.capacity] = key;
+        o.ext_counts[pos - o.capacity] = c;
+    }
+}
+struct WaveChunk {
+    unsigned long long at = 0, end = 0;  // wave-uniform
+    unsigned long long distinct = 0;
+};
+
 // one bucket, one wave: records [lo, hi) of the sorted order; `rec` = this lane's record of it (lane l holds record lo + l; lanes
 // beyond the bucket hold something else and do not use it)
 template <bool WRITE>
 __device__ __forceinline__ void count_one_bucket(WaveTable& t, int lane, uint32_t bucket, uint32_t lo, uint32_t hi, ulonglong2 rec, int k, int canonical,
-                                                 unsigned long long kmask, unsigned int* __restrict__ distinct, const unsigned long long* __restrict__ offsets,
-                                                 unsigned long long* __restrict__ out_keys, unsigned int* __restrict__ out_counts, unsigned long long* cursor,
-                                                 uint2* __restrict__ overflow, uint32_t max_overflow STAMP_ARGS)
+                                                 unsigned long long kmask, unsigned int* __restrict__ distinct, const CountedOut& out, WaveChunk& chunk,
+                                                 unsigned long long* cursor, uint2* __restrict__ overflow, uint32_t max_overflow STAMP_ARGS)
 {
     STAMP(0);  // everything between two buckets: loop control, the waits for this bucket's records and range
     const uint32_t n_rec = hi - lo;  // wave-uniform
@@ -265,10 +329,8 @@ __device__ __forceinline__ void count_one_bucket(WaveTable& t, int lane, uint32_
         return;
     }
     if (n_rec > CT_RECS) {  // too many records for one wave's table: the fallback counts this bucket
-        if (!WRITE) {
-            list_overflow(lane, lo, hi, cursor, overflow, max_overflow);
-            if (lane == 0) distinct[bucket] = 0;
-        }
+        list_overflow(lane, lo, hi, cursor, overflow, max_overflow);
+        if (!WRITE && lane == 0) distinct[bucket] = 0;
         return;
     }
     wave_lds_sync();  // the previous bucket's table has been read out
@@ -287,10 +349,8 @@ __device__ __forceinline__ void count_one_bucket(WaveTable& t, int lane, uint32_
     const unsigned int total = __shfl(incl, 63, 64);
     STAMP(2);  // size prefix
     if (total > CT_CAP) {  // wave-uniform
-        if (!WRITE) {
-            list_overflow(lane, lo, hi, cursor, overflow, max_overflow);
-            if (lane == 0) distinct[bucket] = 0;
-        }
+        list_overflow(lane, lo, hi, cursor, overflow, max_overflow);
+        if (!WRITE && lane == 0) distinct[bucket] = 0;
         return;
     }
     // work list: k-mer j of the bucket -> (record, index inside it), written by the record's own lane at its prefix (fire and
@@ -300,12 +360,20 @@ __device__ __forceinline__ void count_one_bucket(WaveTable& t, int lane, uint32_
         for (unsigned int q = 0; q < size; ++q) t.work[first + q] = (unsigned short)((lane << 5) | q);
     }
     wave_lds_sync();
-    // two k-mers per lane and round, their table probes in flight together
-    for (unsigned int j = lane; j < total; j += 128) {
-        const bool has2 = j + 64 < total;
-        const unsigned int w1 = t.work[j], w2 = t.work[has2 ? j + 64 : j];
-        const ulonglong2 r1 = t.recs[w1 >> 5], r2 = t.recs[w2 >> 5];
-        table_insert2(t, kmer_of(r1, (int)(w1 & 31u), k, canonical, kmask), kmer_of(r2, (int)(w2 & 31u), k, canonical, kmask), has2);
+    // CT_WIDE k-mers per lane and round, their table probes in flight together: the rounds are chains of LDS round trips (work
+    // list -> record -> probe -> count) with little to overlap them with, so fewer, wider rounds it is
+    for (unsigned int j = lane; j < total; j += 64 * CT_WIDE) {
+        unsigned long long key[CT_WIDE];
+        bool live[CT_WIDE];
+        unsigned int w[CT_WIDE];
+#pragma unroll
+        for (int i = 0; i < CT_WIDE; ++i) {
+            live[i] = j + 64 * i < total;
+            w[i] = t.work[live[i] ? j + 64 * i : j];
+        }
+#pragma unroll
+        for (int i = 0; i < CT_WIDE; ++i) key[i] = kmer_of(t.recs[w[i] >> 5], (int)(w[i] & 31u), k, canonical, kmask);
+        table_insert_many<CT_WIDE>(t, key, live);
     }
     wave_lds_sync();
     STAMP(3);  // k-mers inserted
@@ -319,17 +387,32 @@ __device__ __forceinline__ void count_one_bucket(WaveTable& t, int lane, uint32_
         if (lane == 63) distinct[bucket] = oincl;
         return;
     }
-    unsigned long long at = offsets[bucket + (lane >> 6)] + oincl - occ;
+    // the bucket's distinct k-mers go to the rest of this wave's chunk and, when they do not fit, on into a fresh one
+    const unsigned int d = (unsigned int)__shfl((int)oincl, 63, 64);
+    const unsigned long long room = chunk.end - chunk.at;
+    unsigned long long fresh = 0;
+    if (d > room) {
+        unsigned long long got = 0;
+        if (lane == 0) got = atomicAdd(&out.cursor[0], (unsigned long long)CT_CHUNK);
+        fresh = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(got >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)got);
+    }
+    unsigned int idx = oincl - occ;
 #pragma unroll
     for (int i = 0; i < CT_SLOTS / 64; ++i) {
         const int slot = lane * (CT_SLOTS / 64) + i;
         const unsigned int c = t.cnt[slot];
         if (c) {
-            out_keys[at] = t.keys[slot];
-            out_counts[at] = c;
-            ++at;
+            put_counted(out, idx < room ? chunk.at + idx : fresh + (idx - room), t.keys[slot], c);
+            ++idx;
         }
     }
+    if (d > room) {
+        chunk.at = fresh + (d - room);
+        chunk.end = fresh + CT_CHUNK;
+    } else {
+        chunk.at += d;
+    }
+    chunk.distinct += d;
     STAMP(5);  // written out
 }
 
@@ -344,9 +427,7 @@ __device__ __forceinline__ void count_one_bucket(WaveTable& t, int lane, uint32_
 template <bool WRITE>
 __global__ __launch_bounds__(64 * CT_WAVES) void count_buckets_kernel(const ulonglong2* __restrict__ recs, uint32_t n, const uint32_t* __restrict__ starts,
                                                                       uint32_t n_buckets, int k, int canonical, unsigned int* __restrict__ distinct,
-                                                                      const unsigned long long* __restrict__ offsets, unsigned long long* __restrict__ out_keys,
-                                                                      unsigned int* __restrict__ out_counts, unsigned long long* cursor, uint2* __restrict__ overflow,
-                                                                      uint32_t max_overflow)
+                                                                      CountedOut out, unsigned long long* cursor, uint2* __restrict__ overflow, uint32_t max_overflow)
 {
     __shared__ WaveTable tables[CT_WAVES];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -372,7 +453,11 @@ __global__ __launch_bounds__(64 * CT_WAVES) void count_buckets_kernel(const ulon
         return r;
     };
     uint32_t b = blockIdx.x * CT_WAVES + wv, bn = b + stride;
-    if (b >= n_buckets) return;
+    WaveChunk chunk;
+    if (b >= n_buckets) {
+        if (WRITE && lane == 0) out.holes[blockIdx.x * CT_WAVES + wv] = make_ulonglong2(0, 0);
+        return;
+    }
 #ifdef BL_COUNT_STAMPS
     unsigned long long acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long stamp_t_ = __builtin_amdgcn_s_memtime();
@@ -388,7 +473,7 @@ __global__ __launch_bounds__(64 * CT_WAVES) void count_buckets_kernel(const ulon
         const uint32_t b2 = bn + stride;
         uint32_t v2lo, v2hi;
         range_of(b2, v2lo, v2hi);                       // the range of the one after
-        count_one_bucket<WRITE>(t, lane, b, lo, hi, rec, k, canonical, kmask, distinct, offsets, out_keys, out_counts, cursor, overflow, max_overflow STAMP_PASS);
+        count_one_bucket<WRITE>(t, lane, b, lo, hi, rec, k, canonical, kmask, distinct, out, chunk, cursor, overflow, max_overflow STAMP_PASS);
 #ifdef BL_COUNT_STAMPS
         acc[7] += 1;
 #endif
@@ -396,10 +481,53 @@ __global__ __launch_bounds__(64 * CT_WAVES) void count_buckets_kernel(const ulon
         lo = nlo; hi = nhi; rec = nrec;
         vnlo = v2lo; vnhi = v2hi;
     }
+    if (WRITE && lane == 0) {
+        out.holes[blockIdx.x * CT_WAVES + wv] = make_ulonglong2(chunk.at, chunk.end);
+        atomicAdd(&out.cursor[2], chunk.distinct);
+    }
 #ifdef BL_COUNT_STAMPS
     if (lane == 0)
         for (int i = 0; i < 8; ++i) atomicAdd(&bl_count_stamps[i], acc[i]);
 #endif
+}
+
+// Fill the holes below `n_valid` (the number of counted k-mers) with the entries that sit at or beyond it: thread t moves the
+// t-th such entry into the t-th hole slot.  below_*: the holes' parts below n_valid (start, exclusive prefix of their lengths),
+// above_*: their parts at or beyond it (start, exclusive prefix), both in increasing position; the host prepares the four arrays
+// from the few thousand holes.
+__global__ __launch_bounds__(256) void fill_holes_kernel(CountedOut o, unsigned long long n_valid, unsigned long long n_moves, const unsigned long long* below_start,
+                                                         const unsigned long long* below_prefix, uint32_t n_below, const unsigned long long* above_start,
+                                                         const unsigned long long* above_prefix, uint32_t n_above)
+{
+    const unsigned long long t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_moves) return;
+    uint32_t lo = 0, hi = n_below;  // last hole part with prefix <= t
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (below_prefix[mid] <= t) lo = mid;
+        else hi = mid;
+    }
+    const unsigned long long dst = below_start[lo] + (t - below_prefix[lo]);
+    // the t-th entry at or beyond n_valid that is not in a hole: n_valid + t + (hole slots in front of it); j = number of hole
+    // parts in front of it = the first j for which that position lies in front of part j
+    uint32_t a = 0, b = n_above;
+    while (a < b) {
+        const uint32_t mid = (a + b) >> 1;
+        if (n_valid + t + above_prefix[mid] < above_start[mid]) b = mid;
+        else a = mid + 1;
+    }
+    const unsigned long long src = n_valid + t + above_prefix[a];  // (above_prefix has n_above + 1 entries)
+    unsigned long long key;
+    unsigned int c;
+    if (src < o.capacity) {
+        key = o.keys[src];
+        c = o.counts[src];
+    } else {
+        key = o.ext_keys[src - o.capacity];
+        c = o.ext_counts[src - o.capacity];
+    }
+    o.keys[dst] = key;
+    o.counts[dst] = c;
 }
 
 // records of the listed ranges, one after the other: the fallback's input (one workgroup per range)
@@ -540,7 +668,7 @@ int bl_count_super_kmers(bl_ctx* ctx, const uint64_t* d_records, uint64_t n_grou
     unsigned int* distinct = reinterpret_cast<unsigned int*>(arena + ids_bytes + recs_bytes + starts_bytes + over_bytes + offs_bytes);
     unsigned long long* cursor = reinterpret_cast<unsigned long long*>(arena + ids_bytes + recs_bytes + starts_bytes + over_bytes + offs_bytes + dist_bytes);
     const ulonglong2* recs = reinterpret_cast<const ulonglong2*>(d_records);
-    hipError_t e = hipMemsetAsync(cursor, 0, 2 * sizeof(unsigned long long), s);
+    hipError_t e = hipMemsetAsync(cursor, 0, 4 * sizeof(unsigned long long), s);
     if (e == hipSuccess) {
         hipLaunchKernelGGL(bucket_id_kernel, dim3((n + 255) / 256), dim3(256), 0, s, recs, (unsigned long long)n, (int)m, canonical, (uint32_t)seed, bits, ids);
         e = hipGetLastError();
@@ -560,12 +688,18 @@ int bl_count_super_kmers(bl_ctx* ctx, const uint64_t* d_records, uint64_t n_grou
     }
     const uint32_t want = (n_buckets + CT_WAVES - 1) / CT_WAVES;
     const uint32_t grid = want < 256u * 5u ? want : 256u * 5u;  // 5 workgroups of 2 waves per CU by LDS (14.4 KB per wave): all resident, grid-stride over the buckets
+    const uint32_t n_waves = grid * CT_WAVES;
+    const bool write = d_kmers && d_counts;
+    unsigned long long cur[3] = {0, 0, 0};  // [0] distinct k-mers of the table buckets, [1] buckets left to the fallback, [2] end of the chunks handed out
+    CountedOut out{};
     if (e == hipSuccess) {
         hipLaunchKernelGGL(bucket_starts_kernel, dim3(n_buckets / 256 + 1), dim3(256), 0, s, ids_sorted, n, n_buckets, starts);
-        // pass 1: distinct k-mers per bucket; their exclusive scan = where each bucket writes in pass 2
-        hipLaunchKernelGGL((count_buckets_kernel<false>), dim3(grid), dim3(64 * CT_WAVES), 0, s, recs_sorted, n, starts, n_buckets, (int)k, canonical, distinct,
-                           static_cast<const unsigned long long*>(nullptr), static_cast<unsigned long long*>(nullptr), static_cast<unsigned int*>(nullptr), cursor,
-                           overflow, max_overflow);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess && !write) {
+        // the caller only asks how many: distinct k-mers per bucket, summed
+        hipLaunchKernelGGL((count_buckets_kernel<false>), dim3(grid), dim3(64 * CT_WAVES), 0, s, recs_sorted, n, starts, n_buckets, (int)k, canonical, distinct, out,
+                           cursor, overflow, max_overflow);
         e = hipGetLastError();
         if (e == hipSuccess) e = hipMemsetAsync(distinct + n_buckets, 0, sizeof(unsigned int), s);
         size_t scan_bytes = 0;
@@ -576,21 +710,88 @@ int bl_count_super_kmers(bl_ctx* ctx, const uint64_t* d_records, uint64_t n_grou
             if (!scan_tmp) e = hipErrorOutOfMemory;
         }
         if (e == hipSuccess) e = rocprim::exclusive_scan(scan_tmp, scan_bytes, distinct, offsets, 0ull, (size_t)n_buckets + 1, rocprim::plus<unsigned long long>(), s);
-    }
-    unsigned long long cur[2] = {0, 0};
-    if (e == hipSuccess) e = hipMemcpyAsync(&cur[0], offsets + n_buckets, sizeof(unsigned long long), hipMemcpyDeviceToHost, s);  // distinct k-mers of the table buckets
-    if (e == hipSuccess) e = hipMemcpyAsync(&cur[1], cursor + 1, sizeof(unsigned long long), hipMemcpyDeviceToHost, s);          // buckets left to the fallback
-    if (e == hipSuccess) e = hipStreamSynchronize(s);
-    const bool can_write = d_kmers && d_counts && cur[0] <= capacity;
-    if (e == hipSuccess && can_write && cur[0] > 0) {
-        hipLaunchKernelGGL((count_buckets_kernel<true>), dim3(grid), dim3(64 * CT_WAVES), 0, s, recs_sorted, n, starts, n_buckets, (int)k, canonical, distinct, offsets,
-                           reinterpret_cast<unsigned long long*>(d_kmers), d_counts, cursor, overflow, max_overflow);
-        e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpyAsync(&cur[0], offsets + n_buckets, sizeof(unsigned long long), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipMemcpyAsync(&cur[1], cursor + 1, sizeof(unsigned long long), hipMemcpyDeviceToHost, s);
         if (e == hipSuccess) e = hipStreamSynchronize(s);
     }
-    unsigned long long total = cur[0];
     int rc = BL_OK;
-    if (e == hipSuccess && cur[1] > max_overflow) rc = bl_set_error(BL_ERR_INTERNAL, "more oversized buckets than the fallback list holds");
+    if (e == hipSuccess && write) {
+        // ONE pass: count and write (see CountedOut).  Side buffer and hole list come from the context's scratch.
+        const unsigned long long ext_n = (unsigned long long)n_waves * CT_CHUNK;
+        const size_t ext_keys_bytes = up16(ext_n * sizeof(unsigned long long)), ext_counts_bytes = up16(ext_n * sizeof(unsigned int));
+        const size_t holes_bytes = up16((size_t)n_waves * sizeof(ulonglong2)), lists_bytes = up16(((size_t)n_waves + 1) * sizeof(unsigned long long));
+        unsigned char* side = static_cast<unsigned char*>(bl_ctx_scratch(ctx, 3, ext_keys_bytes + ext_counts_bytes + holes_bytes + 4 * lists_bytes + 64));
+        if (!side) return bl_set_error(BL_ERR_OOM, "scratch allocation failed");
+        out.keys = reinterpret_cast<unsigned long long*>(d_kmers);
+        out.counts = d_counts;
+        out.capacity = capacity;
+        out.ext_keys = reinterpret_cast<unsigned long long*>(side);
+        out.ext_counts = reinterpret_cast<unsigned int*>(side + ext_keys_bytes);
+        out.ext_n = ext_n;
+        out.cursor = cursor;
+        out.holes = reinterpret_cast<ulonglong2*>(side + ext_keys_bytes + ext_counts_bytes);
+        unsigned long long* lists = reinterpret_cast<unsigned long long*>(side + ext_keys_bytes + ext_counts_bytes + holes_bytes);
+        hipLaunchKernelGGL((count_buckets_kernel<true>), dim3(grid), dim3(64 * CT_WAVES), 0, s, recs_sorted, n, starts, n_buckets, (int)k, canonical, distinct, out,
+                           cursor, overflow, max_overflow);
+        e = hipGetLastError();
+        std::vector<ulonglong2> holes(n_waves);
+        unsigned long long c3[3] = {0, 0, 0};
+        if (e == hipSuccess) e = hipMemcpyAsync(c3, cursor, sizeof(c3), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipMemcpyAsync(holes.data(), out.holes, (size_t)n_waves * sizeof(ulonglong2), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e == hipSuccess) {
+            cur[0] = c3[2];
+            cur[1] = c3[1];
+            cur[2] = c3[0];
+            // the holes, in increasing position; those below the number of k-mers are filled from the entries beyond it
+            std::vector<std::pair<unsigned long long, unsigned long long>> hs;
+            unsigned long long hole_slots = 0;
+            for (const ulonglong2& h : holes)
+                if (h.y > h.x) {
+                    hs.emplace_back(h.x, h.y);
+                    hole_slots += h.y - h.x;
+                }
+            std::sort(hs.begin(), hs.end());
+            const unsigned long long n_valid = cur[0];
+            if (cur[2] - hole_slots != n_valid) rc = bl_set_error(BL_ERR_INTERNAL, "chunk accounting of the k-mer counter does not add up");
+            if (rc == BL_OK && n_valid <= capacity && n_valid > 0) {
+                std::vector<unsigned long long> below_start, below_prefix, above_start, above_prefix;
+                unsigned long long n_moves = 0, above_total = 0;
+                for (const auto& h : hs) {
+                    if (h.first < n_valid) {
+                        const unsigned long long end = h.second < n_valid ? h.second : n_valid;
+                        below_start.push_back(h.first);
+                        below_prefix.push_back(n_moves);
+                        n_moves += end - h.first;
+                    }
+                    if (h.second > n_valid) {
+                        const unsigned long long start = h.first > n_valid ? h.first : n_valid;
+                        above_start.push_back(start);
+                        above_prefix.push_back(above_total);
+                        above_total += h.second - start;
+                    }
+                }
+                above_prefix.push_back(above_total);
+                above_start.push_back(~0ULL);
+                if (n_moves) {
+                    const size_t nb = below_start.size(), na = above_start.size() - 1;
+                    unsigned long long *d_bs = lists, *d_bp = lists + (n_waves + 1), *d_as = lists + 2 * (size_t)(n_waves + 1), *d_ap = lists + 3 * (size_t)(n_waves + 1);
+                    e = hipMemcpyAsync(d_bs, below_start.data(), nb * sizeof(unsigned long long), hipMemcpyHostToDevice, s);
+                    if (e == hipSuccess) e = hipMemcpyAsync(d_bp, below_prefix.data(), nb * sizeof(unsigned long long), hipMemcpyHostToDevice, s);
+                    if (e == hipSuccess) e = hipMemcpyAsync(d_as, above_start.data(), (na + 1) * sizeof(unsigned long long), hipMemcpyHostToDevice, s);
+                    if (e == hipSuccess) e = hipMemcpyAsync(d_ap, above_prefix.data(), (na + 1) * sizeof(unsigned long long), hipMemcpyHostToDevice, s);
+                    if (e == hipSuccess) {
+                        hipLaunchKernelGGL(fill_holes_kernel, dim3((unsigned)((n_moves + 255) / 256)), dim3(256), 0, s, out, n_valid, n_moves, d_bs, d_bp, (uint32_t)nb, d_as,
+                                           d_ap, (uint32_t)na);
+                        e = hipGetLastError();
+                    }
+                    if (e == hipSuccess) e = hipStreamSynchronize(s);  // the host vectors go out of scope
+                }
+            }
+        }
+    }
+    unsigned long long total = cur[0];
+    if (e == hipSuccess && rc == BL_OK && cur[1] > max_overflow) rc = bl_set_error(BL_ERR_INTERNAL, "more oversized buckets than the fallback list holds");
     if (e == hipSuccess && rc == BL_OK && cur[1] > 0) {
         // fallback for the listed buckets: gather their records, expand, sort, run-length encode, append
         const uint32_t n_over = (uint32_t)cur[1];
