@@ -103,8 +103,8 @@ struct bl_ctx {
     double kernel_ms = 0.0;
     uint64_t kernel_launches = 0;
     std::vector<bl_batch*> batches;  // live batches: destroyed with the context if the caller did not
-    void* scratch[4] = {nullptr, nullptr, nullptr, nullptr};  // grow-only device scratch of the non-scan entry points (bl_ctx_scratch)
-    size_t scratch_bytes[4] = {0, 0, 0, 0};
+    void* scratch[8] = {};  // grow-only device scratch of the non-scan entry points (bl_ctx_scratch)
+    size_t scratch_bytes[8] = {};
 
     unsigned long long* shards() const { return cur->shards(); }
     unsigned long long* result() const { return cur->result(); }
@@ -337,12 +337,14 @@ hipStream_t bl_ctx_stream(bl_ctx* c)
 int bl_batch_adopt_device(bl_ctx* ctx, void* d_bases, uint64_t n_bases, uint64_t* d_offsets, uint64_t n_seqs, bl_batch** out);
 int bl_ctx_device(bl_ctx* c) { return c->device; }
 
-// Device scratch that lives with the context (slot 0..3), grown on demand and never shrunk: the set operations and the
+// Device scratch that lives with the context (slot 0..7), grown on demand and never shrunk: the set operations and the
 // bucketed counter need gigabytes of temporary space per call, and hipMalloc / hipFree of that size costs more than their
 // kernels.  The caller has synchronised its previous use (these entry points are synchronous).  nullptr on failure.
+// Who uses what: 0-3 the k-mer counter and the text parser (which call the set operations while holding them), 4-6 the set
+// operations themselves (4 data, 5 library workspace, 6 counters).
 void* bl_ctx_scratch(bl_ctx* c, int slot, size_t bytes)
 {
-    if (!c || slot < 0 || slot >= 4) return nullptr;
+    if (!c || slot < 0 || slot >= 8) return nullptr;
     if (bytes <= c->scratch_bytes[slot]) return c->scratch[slot];
     (void)hipSetDevice(c->device);
     if (c->scratch[slot]) {

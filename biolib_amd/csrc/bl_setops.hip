@@ -17,6 +17,7 @@
 extern int bl_set_error(int code, const char* msg);
 extern hipStream_t bl_ctx_stream(bl_ctx* ctx);  // bl_capi.hip
 extern int bl_ctx_device(bl_ctx* ctx);
+extern void* bl_ctx_scratch(bl_ctx* ctx, int slot, size_t bytes);  // bl_capi.hip: grow-only device scratch of the context (slots 4-6 are ours)
 
 namespace {
 
@@ -60,20 +61,23 @@ int bl_sort_unique_u64(bl_ctx* ctx, uint64_t* d_keys, uint64_t n, uint64_t* n_un
     unsigned long long* d_count = nullptr;
     void* scratch = nullptr;
     size_t sort_bytes = 0, uniq_bytes = 0;
-    hipError_t e = hipMalloc(&tmp, n * sizeof(unsigned long long));
-    if (e == hipSuccess) e = hipMalloc(&d_count, sizeof(unsigned long long));
+    // temporaries from the context's scratch (no hipMalloc / hipFree per call: they cost more than the kernels on small inputs
+    // and a device-wide synchronisation each on large ones)
+    tmp = static_cast<unsigned long long*>(bl_ctx_scratch(ctx, 4, n * sizeof(unsigned long long)));
+    d_count = static_cast<unsigned long long*>(bl_ctx_scratch(ctx, 6, 64));
+    hipError_t e = tmp && d_count ? hipSuccess : hipErrorOutOfMemory;
     if (e == hipSuccess) e = rocprim::radix_sort_keys(nullptr, sort_bytes, keys, tmp, n, 0, 64, s);
     if (e == hipSuccess) e = rocprim::unique(nullptr, uniq_bytes, tmp, keys, d_count, n, rocprim::equal_to<unsigned long long>(), s);
     const size_t bytes = sort_bytes > uniq_bytes ? sort_bytes : uniq_bytes;
-    if (e == hipSuccess) e = hipMalloc(&scratch, bytes ? bytes : 16);
+    if (e == hipSuccess) {
+        scratch = bl_ctx_scratch(ctx, 5, bytes ? bytes : 16);
+        if (!scratch) e = hipErrorOutOfMemory;
+    }
     if (e == hipSuccess) e = rocprim::radix_sort_keys(scratch, sort_bytes, keys, tmp, n, 0, 64, s);             // keys -> tmp (sorted)
     if (e == hipSuccess) e = rocprim::unique(scratch, uniq_bytes, tmp, keys, d_count, n, rocprim::equal_to<unsigned long long>(), s);  // tmp -> keys
     unsigned long long cnt = 0;
     if (e == hipSuccess) e = hipMemcpyAsync(&cnt, d_count, sizeof(cnt), hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
-    if (tmp) (void)hipFree(tmp);
-    if (d_count) (void)hipFree(d_count);
-    if (scratch) (void)hipFree(scratch);
     if (e != hipSuccess) return bl_set_error(e == hipErrorOutOfMemory ? BL_ERR_OOM : BL_ERR_HIP, hipGetErrorString(e));
     *n_unique = cnt;
     return BL_OK;
@@ -85,8 +89,8 @@ int bl_jaccard_sorted_u64(bl_ctx* ctx, const uint64_t* d_a, uint64_t na, const u
     if (!ctx || !intersection || !union_size || (na && !d_a) || (nb && !d_b)) return bl_set_error(BL_ERR_INVALID, "NULL argument");
     SET_HIP(hipSetDevice(bl_ctx_device(ctx)));
     hipStream_t s = bl_ctx_stream(ctx);
-    unsigned long long* d_out = nullptr;
-    SET_HIP(hipMalloc(&d_out, sizeof(unsigned long long)));
+    unsigned long long* d_out = static_cast<unsigned long long*>(bl_ctx_scratch(ctx, 6, 64));
+    if (!d_out) return bl_set_error(BL_ERR_OOM, "scratch allocation failed");
     hipError_t e = hipMemsetAsync(d_out, 0, sizeof(unsigned long long), s);
     // search the larger set with the elements of the smaller one
     const bool a_small = na <= nb;
@@ -101,7 +105,6 @@ int bl_jaccard_sorted_u64(bl_ctx* ctx, const uint64_t* d_a, uint64_t na, const u
     unsigned long long inter = 0;
     if (e == hipSuccess) e = hipMemcpyAsync(&inter, d_out, sizeof(inter), hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
-    (void)hipFree(d_out);
     if (e != hipSuccess) return bl_set_error(BL_ERR_HIP, hipGetErrorString(e));
     *intersection = inter;
     *union_size = na + nb - inter;
@@ -154,18 +157,20 @@ int bl_count_sorted_u64(bl_ctx* ctx, const uint64_t* d_sorted, uint64_t n, uint6
     unsigned long long* d_runs = nullptr;
     void* tmp = nullptr;
     size_t bytes = 0;
-    SET_HIP(hipMalloc(&d_runs, sizeof(unsigned long long)));
+    d_runs = static_cast<unsigned long long*>(bl_ctx_scratch(ctx, 6, 64));
+    if (!d_runs) return bl_set_error(BL_ERR_OOM, "scratch allocation failed");
     hipError_t e = rocprim::run_length_encode(nullptr, bytes, reinterpret_cast<const unsigned long long*>(d_sorted), n,
                                               reinterpret_cast<unsigned long long*>(d_unique), d_counts, d_runs, s);
-    if (e == hipSuccess) e = hipMalloc(&tmp, bytes ? bytes : 16);
+    if (e == hipSuccess) {
+        tmp = bl_ctx_scratch(ctx, 5, bytes ? bytes : 16);
+        if (!tmp) e = hipErrorOutOfMemory;
+    }
     if (e == hipSuccess)
         e = rocprim::run_length_encode(tmp, bytes, reinterpret_cast<const unsigned long long*>(d_sorted), n, reinterpret_cast<unsigned long long*>(d_unique),
                                        d_counts, d_runs, s);
     unsigned long long runs = 0;
     if (e == hipSuccess) e = hipMemcpyAsync(&runs, d_runs, sizeof(runs), hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
-    (void)hipFree(d_runs);
-    if (tmp) (void)hipFree(tmp);
     if (e != hipSuccess) return bl_set_error(e == hipErrorOutOfMemory ? BL_ERR_OOM : BL_ERR_HIP, hipGetErrorString(e));
     *n_unique = runs;
     return BL_OK;
@@ -181,14 +186,16 @@ int bl_sort_u64(bl_ctx* ctx, uint64_t* d_keys, uint64_t n)
     unsigned long long* tmp = nullptr;
     void* scratch = nullptr;
     size_t bytes = 0;
-    SET_HIP(hipMalloc(&tmp, n * sizeof(unsigned long long)));
+    tmp = static_cast<unsigned long long*>(bl_ctx_scratch(ctx, 4, n * sizeof(unsigned long long)));
+    if (!tmp) return bl_set_error(BL_ERR_OOM, "scratch allocation failed");
     hipError_t e = rocprim::radix_sort_keys(nullptr, bytes, keys, tmp, n, 0, 64, s);
-    if (e == hipSuccess) e = hipMalloc(&scratch, bytes ? bytes : 16);
+    if (e == hipSuccess) {
+        scratch = bl_ctx_scratch(ctx, 5, bytes ? bytes : 16);
+        if (!scratch) e = hipErrorOutOfMemory;
+    }
     if (e == hipSuccess) e = rocprim::radix_sort_keys(scratch, bytes, keys, tmp, n, 0, 64, s);
     if (e == hipSuccess) e = hipMemcpyAsync(keys, tmp, n * sizeof(unsigned long long), hipMemcpyDeviceToDevice, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
-    (void)hipFree(tmp);
-    if (scratch) (void)hipFree(scratch);
     if (e != hipSuccess) return bl_set_error(e == hipErrorOutOfMemory ? BL_ERR_OOM : BL_ERR_HIP, hipGetErrorString(e));
     return BL_OK;
 }

@@ -605,12 +605,16 @@ int bl_expand_super_kmers(bl_ctx* ctx, const uint64_t* d_records, uint64_t n_gro
     void* tmp = nullptr;
     size_t bytes = 0;
     const unsigned blocks = (unsigned)((n_groups + 255) / 256);
-    hipError_t e = hipMalloc(&sizes, 2 * n_groups * sizeof(unsigned long long));
-    if (e != hipSuccess) return bl_set_error(BL_ERR_OOM, hipGetErrorString(e));
+    sizes = static_cast<unsigned long long*>(bl_ctx_scratch(ctx, 4, 2 * n_groups * sizeof(unsigned long long)));  // (slots 4-6: the set operations')
+    if (!sizes) return bl_set_error(BL_ERR_OOM, "scratch allocation failed");
+    hipError_t e = hipSuccess;
     offsets = sizes + n_groups;
     hipLaunchKernelGGL(sizes_kernel, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const ulonglong2*>(d_records), (unsigned long long)n_groups, sizes);
     e = rocprim::exclusive_scan(nullptr, bytes, sizes, offsets, 0ull, n_groups, rocprim::plus<unsigned long long>(), s);
-    if (e == hipSuccess) e = hipMalloc(&tmp, bytes ? bytes : 16);
+    if (e == hipSuccess) {
+        tmp = bl_ctx_scratch(ctx, 5, bytes ? bytes : 16);
+        if (!tmp) e = hipErrorOutOfMemory;
+    }
     if (e == hipSuccess) e = rocprim::exclusive_scan(tmp, bytes, sizes, offsets, 0ull, n_groups, rocprim::plus<unsigned long long>(), s);
     unsigned long long last[2] = {0, 0};
     if (e == hipSuccess) e = hipMemcpyAsync(&last[0], offsets + n_groups - 1, 8, hipMemcpyDeviceToHost, s);
@@ -628,8 +632,6 @@ int bl_expand_super_kmers(bl_ctx* ctx, const uint64_t* d_records, uint64_t n_gro
             if (e == hipSuccess) e = hipStreamSynchronize(s);
         }
     }
-    (void)hipFree(sizes);
-    if (tmp) (void)hipFree(tmp);
     if (e != hipSuccess) return bl_set_error(e == hipErrorOutOfMemory ? BL_ERR_OOM : BL_ERR_HIP, hipGetErrorString(e));
     return rc;
 }
@@ -804,8 +806,14 @@ int bl_count_super_kmers(bl_ctx* ctx, const uint64_t* d_records, uint64_t n_grou
         unsigned long long *d_off = nullptr, *kmers = nullptr, *uniq = nullptr;
         unsigned int* cnts = nullptr;
         uint64_t n_kmers = 0;
-        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&gathered), n_over_recs * sizeof(ulonglong2));
-        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_off), (n_over + 1) * sizeof(unsigned long long));
+        // (scratch slots 1-3 are free again here: the sort's workspace, the side buffer and the hole lists have done their work)
+        if (e == hipSuccess) {
+            const size_t gathered_bytes = up16(n_over_recs * sizeof(ulonglong2));
+            unsigned char* a1 = static_cast<unsigned char*>(bl_ctx_scratch(ctx, 1, gathered_bytes + (n_over + 1) * sizeof(unsigned long long)));
+            if (!a1) e = hipErrorOutOfMemory;
+            gathered = reinterpret_cast<ulonglong2*>(a1);
+            d_off = reinterpret_cast<unsigned long long*>(a1 + gathered_bytes);
+        }
         if (e == hipSuccess) e = hipMemcpy(d_off, off.data(), (n_over + 1) * sizeof(unsigned long long), hipMemcpyHostToDevice);
         if (e == hipSuccess) {
             hipLaunchKernelGGL(gather_ranges_kernel, dim3(n_over), dim3(256), 0, s, recs_sorted, overflow, d_off, gathered);
@@ -815,8 +823,11 @@ int bl_count_super_kmers(bl_ctx* ctx, const uint64_t* d_records, uint64_t n_grou
             int r2 = bl_expand_super_kmers(ctx, reinterpret_cast<const uint64_t*>(gathered), n_over_recs, k, flags, nullptr, 0, &n_kmers);
             if (r2 != BL_OK && r2 != BL_ERR_CAPACITY) rc = r2;
         }
-        if (e == hipSuccess && rc == BL_OK) e = hipMalloc(reinterpret_cast<void**>(&kmers), 2 * n_kmers * sizeof(unsigned long long) + 8);
-        if (e == hipSuccess && rc == BL_OK) e = hipMalloc(reinterpret_cast<void**>(&cnts), n_kmers * sizeof(unsigned int) + 4);
+        if (e == hipSuccess && rc == BL_OK) {
+            kmers = static_cast<unsigned long long*>(bl_ctx_scratch(ctx, 2, 2 * n_kmers * sizeof(unsigned long long) + 8));
+            cnts = static_cast<unsigned int*>(bl_ctx_scratch(ctx, 3, n_kmers * sizeof(unsigned int) + 4));
+            if (!kmers || !cnts) e = hipErrorOutOfMemory;
+        }
         if (e == hipSuccess && rc == BL_OK) {
             uniq = kmers + n_kmers;
             rc = bl_expand_super_kmers(ctx, reinterpret_cast<const uint64_t*>(gathered), n_over_recs, k, flags, reinterpret_cast<uint64_t*>(kmers), n_kmers, &n_kmers);
@@ -833,10 +844,6 @@ int bl_count_super_kmers(bl_ctx* ctx, const uint64_t* d_records, uint64_t n_grou
                 total += runs;
             }
         }
-        if (gathered) (void)hipFree(gathered);
-        if (d_off) (void)hipFree(d_off);
-        if (kmers) (void)hipFree(kmers);
-        if (cnts) (void)hipFree(cnts);
     }
     if (e != hipSuccess) return bl_set_error(e == hipErrorOutOfMemory ? BL_ERR_OOM : BL_ERR_HIP, hipGetErrorString(e));
     if (rc != BL_OK) return rc;
