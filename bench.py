@@ -17,6 +17,8 @@ Prints ONE JSON line on rank 0, including
   other_configs  (1 GPU) one pass each over the other BASELINE.json configurations at their stated sizes:
                  C2 canonical 31-mer + hash64 over 10 Gbp, C4 super-k-mers k=31 m=15 over 50 Gbp of 10-kbp reads,
                  C5 syncmers k=31 s=11 over 50 Gbp of 10-kbp reads — Gbp/s, kernel ms, roofline fraction
+  next_rows      (1 GPU) the rows SURVEY.md §8(f) marks "next", each on a small workload: the partitioned k-mer counter's
+                 chain (scan -> records -> owner split -> count) in Gbp/s and the device BGZF inflate in GB/s of text
   cpu_baseline   the CPU oracle (port of the reference algorithm) timed on this box's host cores on a bounded sample
                  of the same reads, a bit-exact check of the GPU result on it, and the reference itself on C2's path
 """
@@ -257,6 +259,7 @@ def main():
         del outs
         torch.cuda.empty_cache()
         out["other_configs"] = other_configs(ctx, args, load_json_or_none(MODEL_PATH))
+        out["next_rows"] = next_rows(ctx)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
@@ -342,6 +345,81 @@ def other_configs(ctx, args, model):
     b.close()
     res["note"] = ("parity of these configurations at these sizes: tests/test_gpu_edges.py (two cuttings agree, 256 Mbp against the oracle); "
                    "C5's 8-GPU RCCL leg needs hardware a 1-GPU box does not have (world-1 nccl reduce is tested)")
+    return res
+
+
+def next_rows(ctx):
+    """Driver-timed numbers for the rows SURVEY.md §8(f) marks "next" (they are not the headline and cannot fail it): the
+    partitioned k-mer counter's chain on one GPU and the device-side BGZF inflate, each on a small synthetic workload."""
+    import struct, zlib
+    import numpy as np
+    import torch
+    import biolib_amd as B
+
+    res = {}
+    try:  # scan -> pack -> owner split -> count (tests/perf/count_bench.py is the long form)
+        k, m, L = 31, 15, 150
+        n = 1_500_000_000 // L * L
+        b = ctx.synth(SEED, n, L)
+        keys = ctx.empty_u64(int(n * 0.82))
+        cnts = torch.empty(int(n * 0.82), dtype=torch.int32, device="cuda")
+        best = None
+        for _ in range(3):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            recs, hashes = b.super_kmer_records(k, m, seed=SEED, canonical=True)
+            bucketed, _ = ctx.partition_records(hashes, recs, 8)
+            u, c = ctx.count_super_kmers(bucketed, k, m, seed=SEED, canonical=True, out=(keys, cnts))
+            torch.cuda.synchronize(); dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        res["kmer_count_chain"] = {"value": round(n / best / 1e9, 1), "unit": "Gbp/s", "bases": n, "distinct_kmers": int(u.numel()),
+                                   "workload": "1.5 Gbp of 150-bp reads, k=31 m=15 canonical: super-k-mer scan -> 16-byte records -> split by owner (8) -> count in LDS tables"}
+        b.close()
+        del keys, cnts, recs, hashes, bucketed, u, c
+        torch.cuda.empty_cache()
+    except Exception as e:  # reported, not fatal
+        res["kmer_count_chain"] = {"error": repr(e)[:200]}
+    try:  # device BGZF inflate: 64 MB of FASTQ text, zlib level 6, 65280-byte members (tests/perf/inflate_bench.py is the long form)
+        import ctypes as C
+        rng = np.random.default_rng(1)
+        n_reads, L = 186_000, 150  # ~1,020 members: one resident set of the kernel (4 per CU)
+        seq = rng.choice(np.frombuffer(b"ACGT", np.uint8), (n_reads, L))
+        qual = np.where(rng.random((n_reads, L)) < 0.93, ord("F"), rng.choice(np.frombuffer(b":,#", np.uint8), (n_reads, L))).astype(np.uint8)
+        text = b"".join(b"@A00123:45:HXXXXXXXX:1:1101:%d:%d 1:N:0:ACGTACGT\n" % (1000 + i % 30000, 1000 + i // 7) + seq[i].tobytes() + b"\n+\n" + qual[i].tobytes() + b"\n"
+                        for i in range(n_reads))
+        data = bytearray()
+        for a in range(0, len(text), 65280):
+            chunk = text[a:a + 65280]
+            z = zlib.compressobj(6, zlib.DEFLATED, -15)
+            body = z.compress(chunk) + z.flush()
+            data += b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, 12 + 6 + len(body) + 8 - 1)
+            data += body + struct.pack("<II", zlib.crc32(chunk) & 0xFFFFFFFF, len(chunk))
+        data = bytes(data)
+        lib = ctx._lib
+        cap = len(data) // 26 + 1
+        members = np.zeros(cap * 4, np.uint64)
+        nm, used, tb = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        assert lib.bl_bgzf_walk(data, len(data), 0, 0, members.ctypes.data, cap, C.byref(nm), C.byref(used), C.byref(tb)) == 0
+        ptrs = []
+        for size in (len(data) + 8, 32 * nm.value, tb.value + 16, 4 * nm.value):
+            p = C.c_void_p()
+            assert lib.bl_device_alloc(ctx._h, size, C.byref(p)) == 0
+            ptrs.append(p)
+        lib.bl_copy_to_device(ctx._h, ptrs[0], data, len(data)); lib.bl_copy_to_device(ctx._h, ptrs[1], members.ctypes.data, 32 * nm.value)
+        best = None
+        for _ in range(4):
+            ctx.sync(); t0 = time.perf_counter()
+            assert lib.bl_bgzf_inflate(ctx._h, ptrs[0], len(data), ptrs[1], nm.value, ptrs[2], tb.value, ptrs[3]) == 0
+            ctx.sync(); dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        out_text = np.zeros(tb.value, np.uint8); st = np.zeros(nm.value, np.uint32)
+        lib.bl_copy_to_host(ctx._h, out_text.ctypes.data, ptrs[2], tb.value); lib.bl_copy_to_host(ctx._h, st.ctypes.data, ptrs[3], 4 * nm.value)
+        for p in ptrs:
+            lib.bl_device_free(ctx._h, p)
+        res["bgzf_inflate"] = {"value": round(len(text) / best / 1e9, 2), "unit": "GB/s of text", "members": int(nm.value), "text_MB": round(len(text) / 1e6), "kernel_ms": round(best * 1e3, 3),
+                               "same_text_as_zlib": bool(not st.any() and out_text.tobytes() == text),
+                               "workload": "FASTQ text (binned qualities), zlib level 6, 65280-byte BGZF members, inflate + CRC-32 on the device"}
+    except Exception as e:
+        res["bgzf_inflate"] = {"error": repr(e)[:200]}
     return res
 
 
