@@ -105,6 +105,10 @@ struct bl_ctx {
     std::vector<bl_batch*> batches;  // live batches: destroyed with the context if the caller did not
     void* scratch[8] = {};  // grow-only device scratch of the non-scan entry points (bl_ctx_scratch)
     size_t scratch_bytes[8] = {};
+    // device buffers of batches that came and went (bl_ctx_pool_*): a file is read as hundreds of batches of the same few
+    // sizes, and every hipFree waits for the whole device — including the reader's inflate of the next span on its own stream
+    std::vector<std::pair<void*, size_t>> pool_idle;
+    std::vector<std::pair<void*, size_t>> pool_live;
 
     unsigned long long* shards() const { return cur->shards(); }
     unsigned long long* result() const { return cur->result(); }
@@ -362,6 +366,50 @@ void* bl_ctx_scratch(bl_ctx* c, int slot, size_t bytes)
     return c->scratch[slot];
 }
 
+// Device memory for short-lived batch buffers: taken from the idle list when something of about the right size is there,
+// returned to it instead of freed (up to 16 buffers of at most 1 GiB each, 4 GiB together).  bl_ctx_pool_free of a pointer
+// that did not come from bl_ctx_pool_alloc is a plain hipFree.  The caller has synchronised the buffer's last use.
+void* bl_ctx_pool_alloc(bl_ctx* c, size_t bytes)
+{
+    if (!c) return nullptr;
+    if (bytes < 256) bytes = 256;
+    size_t best = c->pool_idle.size();
+    for (size_t i = 0; i < c->pool_idle.size(); ++i) {
+        const size_t have = c->pool_idle[i].second;
+        if (have >= bytes && have <= 2 * bytes + 65536 && (best == c->pool_idle.size() || have < c->pool_idle[best].second)) best = i;
+    }
+    if (best < c->pool_idle.size()) {
+        const auto entry = c->pool_idle[best];
+        c->pool_idle[best] = c->pool_idle.back();
+        c->pool_idle.pop_back();
+        c->pool_live.push_back(entry);
+        return entry.first;
+    }
+    void* p = nullptr;
+    const size_t want = bytes + bytes / 8;  // (the next span is rarely exactly as long as this one)
+    if (hipMalloc(&p, want) != hipSuccess) return nullptr;
+    c->pool_live.emplace_back(p, want);
+    return p;
+}
+
+void bl_ctx_pool_free(bl_ctx* c, void* p)
+{
+    if (!p) return;
+    if (c)
+        for (size_t i = 0; i < c->pool_live.size(); ++i)
+            if (c->pool_live[i].first == p) {
+                const auto entry = c->pool_live[i];
+                c->pool_live[i] = c->pool_live.back();
+                c->pool_live.pop_back();
+                size_t total = 0;
+                for (const auto& e : c->pool_idle) total += e.second;
+                if (c->pool_idle.size() < 16 && entry.second <= ((size_t)1 << 30) && total + entry.second <= ((size_t)4 << 30)) c->pool_idle.push_back(entry);
+                else (void)hipFree(p);
+                return;
+            }
+    (void)hipFree(p);
+}
+
 extern "C" {
 
 const char* bl_last_error(void) { return g_err.c_str(); }
@@ -450,6 +498,8 @@ int bl_ctx_destroy(bl_ctx* c)
     }
     for (void* p : c->scratch)
         if (p) (void)hipFree(p);
+    for (const auto& e : c->pool_idle) (void)hipFree(e.first);
+    for (const auto& e : c->pool_live) (void)hipFree(e.first);  // (none: every batch has been destroyed above)
     if (c->pinned) (void)hipHostFree(c->pinned);
     for (hipEvent_t ev : c->slot_ev)
         if (ev) (void)hipEventDestroy(ev);
@@ -622,17 +672,18 @@ int bl_batch_adopt_device(bl_ctx* c, void* d_bases, uint64_t n_bases, uint64_t* 
 {
     bl_batch* b = nullptr;
     int rc = new_batch(c, n_bases, out, b);
-    if (rc != BL_OK) { (void)hipFree(d_bases); (void)hipFree(d_offsets); return rc; }
+    if (rc != BL_OK) { bl_ctx_pool_free(c, d_bases); bl_ctx_pool_free(c, d_offsets); return rc; }
     b->bases = static_cast<uint8_t*>(d_bases);
     b->owns_bases = true;
     b->n_seqs = n_seqs;
     hipStream_t s = bl_ctx_stream(c);
     const uint64_t n_words = (n_bases + 31) / 32 + 4;
-    hipError_t e = hipMalloc(&b->start_bits, n_words * sizeof(uint32_t));
+    b->start_bits = static_cast<uint32_t*>(bl_ctx_pool_alloc(c, n_words * sizeof(uint32_t)));
+    hipError_t e = b->start_bits ? hipSuccess : hipErrorOutOfMemory;
     if (e == hipSuccess) e = hipMemsetAsync(b->start_bits, 0, n_words * sizeof(uint32_t), s);
     if (e == hipSuccess) e = bl::launch_start_bits_offsets(b->start_bits, d_offsets, n_seqs, n_bases, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
-    (void)hipFree(d_offsets);
+    bl_ctx_pool_free(c, d_offsets);
     if (e != hipSuccess) { bl_batch_destroy(b); return fail(BL_ERR_HIP, std::string("adopt: ") + hipGetErrorString(e)); }
     *out = b;
     return BL_OK;
@@ -652,8 +703,8 @@ int bl_batch_destroy(bl_batch* b)
         for (size_t i = 0; i < v.size(); ++i)
             if (v[i] == b) { v[i] = v.back(); v.pop_back(); break; }
     }
-    if (b->owns_bases && b->bases) (void)hipFree(b->bases);
-    if (b->start_bits) (void)hipFree(b->start_bits);
+    if (b->owns_bases && b->bases) bl_ctx_pool_free(b->ctx, b->bases);
+    if (b->start_bits) bl_ctx_pool_free(b->ctx, b->start_bits);
     delete b;
     return BL_OK;
 }

@@ -272,6 +272,15 @@ public:
     }
     void recycle(std::vector<unsigned char>&& v) { spare_.give(std::move(v)); }
     void abandon() { queue_.abandon(); }  // the consumer is leaving: next() returns false from now on
+    // a plain file whose chunk threads have not been started can be read straight into the caller's buffer (the text spans
+    // do: one copy less on the path of an uncompressed file).  -1 on a read error.
+    bool can_read_direct() const { return kind_[0] == 'p' && !started_; }
+    long read_direct(void* dst, size_t want)
+    {
+        const size_t n = std::fread(dst, 1, want, f_);
+        if (n < want && std::ferror(f_)) return -1;
+        return (long)n;
+    }
     const char* kind() const { return kind_; }
 
 private:
@@ -412,6 +421,7 @@ public:
     size_t left() const { return cur_.bytes.size() - pos_; }
     void skip(size_t n) { pos_ += n; }
     void abandon() { src_.abandon(); }
+    ByteSource& source() { return src_; }
 
 private:
     ByteSource& src_;
@@ -671,6 +681,7 @@ private:
         const char* carry = nullptr;  // the bytes behind the previous span's cut (they stay in the previous buffer until copied)
         size_t carry_n = 0;
         bool eof = false;
+        const bool direct = in_.source().can_read_direct();
         for (;;) {
             SpanBuf* b;
             {
@@ -693,6 +704,16 @@ private:
                     if (cut == 0 && eof) cut = filled;  // the tail of the file, whatever it is
                     if (cut) break;
                     want = filled + LOOK;  // one record longer than all this: keep reading
+                }
+                if (direct) {  // an uncompressed file: the bytes go from the page cache straight into the span
+                    size_t step = filled > ((size_t)1 << 20) ? filled : (size_t)1 << 20;  // (doubling: a small file gets a small buffer)
+                    if (step > want - filled) step = want - filled;
+                    if (!grow(*b, filled, filled + step)) { verdict = -1; break; }
+                    const long got = in_.source().read_direct(b->p + filled, step);
+                    if (got < 0) { verdict = -1; break; }
+                    if ((size_t)got < step) eof = true;
+                    filled += (size_t)got;
+                    continue;
                 }
                 if (!in_.more()) {
                     if (in_.broken()) { verdict = -1; break; }
@@ -830,7 +851,10 @@ private:
                     uint64_t got = 0, used = 0, tb = 0;
                     if (bl_bgzf_walk(b->p + walked, filled - walked, walked, text, &m, 1, &got, &used, &tb) != BL_OK) { verdict = -1; break; }
                     if (got == 0) break;
-                    if (!b->members.empty() && text + m.isize > limit_) { full = true; break; }
+                    // a span is full when its text would pass the limit — or when it holds as many members as the inflate kernel
+                    // keeps resident per 64 MiB of limit (1,024: four waves on each of 256 CUs): one member more would cost a
+                    // second round of the kernel for that member alone
+                    if (!b->members.empty() && (text + m.isize > limit_ || b->members.size() >= max_members_)) { full = true; break; }
                     b->members.push_back(m);
                     walked += used;
                     text += m.isize;
@@ -862,6 +886,7 @@ private:
 
     FILE* f_;
     const size_t limit_;
+    const size_t max_members_ = (limit_ >> 16) ? (limit_ >> 16) : 1;
     const SpanMemory mem_;
     PackedSpan ring_[RING];
     std::mutex m_;

@@ -15,6 +15,8 @@ extern int bl_set_error(int code, const char* msg);
 extern hipStream_t bl_ctx_stream(bl_ctx* ctx);
 extern int bl_ctx_device(bl_ctx* ctx);
 extern void* bl_ctx_scratch(bl_ctx* ctx, int slot, size_t bytes);  // bl_capi.hip: grow-only device scratch that lives with the context
+extern void* bl_ctx_pool_alloc(bl_ctx* ctx, size_t bytes);          // bl_capi.hip: batch buffers, recycled between batches
+extern void bl_ctx_pool_free(bl_ctx* ctx, void* p);
 extern int bl_batch_adopt_device(bl_ctx* ctx, void* d_bases, uint64_t n_bases, uint64_t* d_offsets, uint64_t n_seqs, bl_batch** out);  // bl_capi.hip
 
 namespace {
@@ -234,8 +236,8 @@ int bl_parse_device_text(bl_ctx* ctx, const uint8_t* d_text_in, uint64_t n_bytes
     auto cleanup = [&]() {     // every exit path: nothing may still be running on the scratch; the outputs go unless adopted
         (void)hipStreamSynchronize(s);
         if (!handed_over) {
-            if (d_bases) (void)hipFree(d_bases);
-            if (d_offsets) (void)hipFree(d_offsets);
+            bl_ctx_pool_free(ctx, d_bases);
+            bl_ctx_pool_free(ctx, d_offsets);
             d_bases = nullptr;
             d_offsets = nullptr;
         }
@@ -337,9 +339,10 @@ int bl_parse_device_text(bl_ctx* ctx, const uint8_t* d_text_in, uint64_t n_bytes
         return fail_free(BL_ERR_INVALID, msg);
     }
 
-    P_HIP(hipMalloc(&d_bases, total + 64));
+    d_bases = static_cast<uint8_t*>(bl_ctx_pool_alloc(ctx, total + 64));
+    d_offsets = static_cast<unsigned long long*>(bl_ctx_pool_alloc(ctx, (n_records + 1) * sizeof(unsigned long long)));
+    if (!d_bases || !d_offsets) return fail_free(BL_ERR_OOM, "device allocation failed (batch)");
     P_HIP(hipMemsetAsync(d_bases + (total & ~15ull), 0, 64 + (total & 15ull), s));
-    P_HIP(hipMalloc(&d_offsets, (n_records + 1) * sizeof(unsigned long long)));
     if (total) {
         const uint64_t threads = (total + 15) / 16;
         hipLaunchKernelGGL(gather_bases_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, d_text, d_line_end, d_dst, d_len, n_lines,

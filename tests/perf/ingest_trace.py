@@ -32,12 +32,21 @@ with tempfile.TemporaryDirectory() as d:
     ctx = B.Context(0)
     for scan in (False, True, True):
         t0 = time.perf_counter(); nb = 0
+        t_next = t_scan = t_close = 0.0
         r = B.Reader(path)
-        for batch in r.device_batches(ctx, span):
+        it = iter(r.device_batches(ctx, span))
+        while True:
+            a = time.perf_counter()
+            batch = next(it, None)
+            b_ = time.perf_counter(); t_next += b_ - a
+            if batch is None:
+                break
             nb += batch.n_bases
             if scan:
                 batch.minimizers_raw(31, 11, 42, B.FLAG_CANONICAL | B.FLAG_SYNC)
+            c_ = time.perf_counter(); t_scan += c_ - b_
             batch.close()
+            t_close += time.perf_counter() - c_
         r.close()
         dt = time.perf_counter() - t0
-        print(f"scan={scan}: {nb / dt / 1e9:.2f} Gbp/s ({dt * 1e3:.0f} ms)", flush=True)
+        print(f"scan={scan}: {nb / dt / 1e9:.2f} Gbp/s ({dt * 1e3:.0f} ms; next batch {t_next * 1e3:.0f}, scan {t_scan * 1e3:.0f}, close {t_close * 1e3:.0f} ms)", flush=True)
