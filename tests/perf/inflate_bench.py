@@ -35,7 +35,7 @@ def fastq(n_reads, quality, L=150):
                     for i in range(n_reads))
 
 
-n_reads = int(sys.argv[1]) if len(sys.argv) > 1 else 400_000
+n_reads = int(sys.argv[1]) if len(sys.argv) > 1 else 370_000
 QUICK = len(sys.argv) > 2 and sys.argv[2] == "quick"  # one case, one launch: for counter passes under rocprofv3
 ctx = B.Context(0)
 lib = ctx._lib
