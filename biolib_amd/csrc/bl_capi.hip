@@ -926,6 +926,27 @@ int bl_device_free(bl_ctx* c, void* d_ptr)
     return BL_OK;
 }
 
+// page-locked host memory: copies to and from it are single DMA transfers and it is touched (mapped) once, at allocation
+int bl_host_alloc(bl_ctx* c, uint64_t bytes, void** ptr)
+{
+    if (!c || !ptr) return fail(BL_ERR_INVALID, "NULL argument");
+    BL_HIP(hipSetDevice(c->device));
+    *ptr = nullptr;
+    hipError_t e = hipHostMalloc(ptr, bytes ? bytes : 16, hipHostMallocPortable);
+    if (e != hipSuccess) return fail(BL_ERR_OOM, std::string("hipHostMalloc: ") + hipGetErrorString(e));
+    return BL_OK;
+}
+
+int bl_host_free(bl_ctx* c, void* ptr)
+{
+    if (!c) return fail(BL_ERR_INVALID, "ctx is NULL");
+    BL_HIP(hipSetDevice(c->device));
+    int rc = sync_ctx(c);
+    if (rc != BL_OK) return rc;
+    if (ptr) BL_HIP(hipHostFree(ptr));
+    return BL_OK;
+}
+
 int bl_copy_to_host(bl_ctx* c, void* dst, const void* d_src, uint64_t bytes)
 {
     if (!c || (bytes && (!dst || !d_src))) return fail(BL_ERR_INVALID, "NULL argument");

@@ -315,6 +315,10 @@ int bl_merge_runs_u64(bl_ctx* ctx, const char* const* paths, uint32_t n_paths, u
 /* ---- device memory helpers (for callers without their own allocator) ----------------------------- */
 int bl_device_alloc(bl_ctx* ctx, uint64_t bytes, void** d_ptr);
 int bl_device_free(bl_ctx* ctx, void* d_ptr);
+/* Page-locked host memory (copies to and from it are single DMA transfers; its pages are mapped once, at allocation): what a
+ * caller that downloads results batch after batch should copy into (include/compat/read_pool.hpp does). */
+int bl_host_alloc(bl_ctx* ctx, uint64_t bytes, void** ptr);
+int bl_host_free(bl_ctx* ctx, void* ptr);
 int bl_copy_to_host(bl_ctx* ctx, void* dst, const void* d_src, uint64_t bytes); /* synchronous */
 int bl_copy_to_device(bl_ctx* ctx, void* d_dst, const void* src, uint64_t bytes); /* synchronous */
 

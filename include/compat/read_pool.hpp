@@ -7,7 +7,9 @@
 // batch (run when the first view of the batch asks, with that view's k and canonical flag): the loop body stays unchanged,
 //     biolib_amd::read_pool pool(path);
 //     while (pool.next(s, len)) { auto view = wrapper::kmer_view_from_cstr<kmer_t>(s, len, k, canonical); for (...) ... }
-// and pays one upload + one scan + one download per batch (default 32 Mbases) instead of per read.
+// and pays one upload + one scan + one download per batch (default 32 Mbases) instead of per read.  The device array the scan
+// writes and the page-locked host array it is downloaded into belong to the pool and are reused from batch to batch (a fresh
+// 256 MB vector per batch costs a page fault per 4 KiB and a device-wide wait per hipFree: more than the scan).
 #ifndef BIOLIB_AMD_COMPAT_READ_POOL_HPP
 #define BIOLIB_AMD_COMPAT_READ_POOL_HPP
 
@@ -33,6 +35,8 @@ class read_pool
                 if (*p == this) { *p = next_in_chain; break; }
             drop_batch();
             bl_reader_close(reader);
+            if (d_values) bl_device_free(context::get(), d_values);
+            if (h_values) bl_host_free(context::get(), h_values);
         }
         read_pool(read_pool const&) = delete;
 
@@ -62,7 +66,14 @@ class read_pool
         char const* bases = nullptr;
         uint64_t const* offsets = nullptr;
         uint64_t n_seqs = 0, n_bases = 0, at = 0, max_bases, scans = 0;
-        std::map<std::pair<unsigned, bool>, std::vector<uint64_t>> cache;  // (k, canonical) -> per-position k-mer values of the batch
+        // per-position k-mer values of the batch: the first (k, canonical) asked for lives in the pool's own arrays, any further
+        // one (unusual: two kinds of view over the same reads) in a vector of its own
+        uint64_t* d_values = nullptr;
+        uint64_t* h_values = nullptr;
+        uint64_t values_cap = 0;
+        bool have_primary = false;
+        std::pair<unsigned, bool> primary_key {0u, false};
+        std::map<std::pair<unsigned, bool>, std::vector<uint64_t>> cache;
         read_pool* next_in_chain = nullptr;
 
         static read_pool*& head() {thread_local read_pool* h = nullptr; return h;}
@@ -73,6 +84,7 @@ class read_pool
             batch = nullptr;
             bases = nullptr;
             cache.clear();
+            have_primary = false;
             n_seqs = n_bases = at = 0;
         }
         bool refill()
@@ -88,6 +100,28 @@ class read_pool
         uint64_t const* values(unsigned k, bool canonical)
         {
             auto key = std::make_pair(k, canonical);
+            if (have_primary and key == primary_key) return h_values;
+            if (not have_primary) {
+                if (n_bases > values_cap) {
+                    if (d_values) check(bl_device_free(context::get(), d_values), "bl_device_free");
+                    if (h_values) check(bl_host_free(context::get(), h_values), "bl_host_free");
+                    d_values = h_values = nullptr;
+                    values_cap = n_bases + n_bases / 8;
+                    void* p = nullptr;
+                    check(bl_device_alloc(context::get(), values_cap * sizeof(uint64_t), &p), "bl_device_alloc");
+                    d_values = static_cast<uint64_t*>(p);
+                    check(bl_host_alloc(context::get(), values_cap * sizeof(uint64_t), &p), "bl_host_alloc");
+                    h_values = static_cast<uint64_t*>(p);
+                }
+                bl_result res;
+                check(bl_scan_kmers(context::get(), batch, 0, 0, k, 0, (canonical ? (uint32_t)BL_FLAG_CANONICAL : 0u) | BL_FLAG_SYNC, d_values, nullptr, nullptr, &res),
+                      "bl_scan_kmers");
+                check(bl_copy_to_host(context::get(), h_values, d_values, n_bases * sizeof(uint64_t)), "bl_copy_to_host");
+                have_primary = true;
+                primary_key = key;
+                ++scans;
+                return h_values;
+            }
             auto it = cache.find(key);
             if (it == cache.end()) {  // the first view of this batch with these parameters: one scan for all its reads
                 device_array<uint64_t> d_values(n_bases);
