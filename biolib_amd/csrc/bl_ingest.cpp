@@ -18,6 +18,7 @@
 //   3. Text spans for the device-side parser (bl_batch_from_text): the decompressed text cut at record boundaries, so that
 //      .gz input takes  parallel inflate -> one H2D copy -> parse on the GPU  instead of the host record loop.
 // Bases are passed through untouched (the scan's own table decides what is a break).
+#include <fcntl.h>
 #include <sys/stat.h>
 #include <unistd.h>
 #include <zlib.h>
@@ -644,6 +645,25 @@ size_t find_record_cut(const char* p, size_t filled, size_t limit, char fmt_)
     return 0;
 }
 
+// The first place in p[0 .. n) where a record begins that can be RECOGNISED from the text alone: the first byte of a line (a
+// newline stands in front of it, inside the text) that opens a record.  0: none (offsets are >= 1); (size_t)-1: the text ends
+// before the candidate in hand can be decided.  This is how two readers that take neighbouring parts of one file agree on where
+// one's records end and the other's begin without talking to each other.
+size_t first_record_start(const char* p, size_t n, char fmt_)
+{
+    size_t from = 0;
+    while (from < n) {
+        const char* nl = static_cast<const char*>(std::memchr(p + from, '\n', n - from));
+        if (!nl) return 0;
+        const size_t at = (size_t)(nl - p) + 1;
+        const int v = record_opens_at(p, n, at, fmt_);
+        if (v == 1) return at;
+        if (v < 0) return (size_t)-1;
+        from = at;
+    }
+    return 0;
+}
+
 struct SpanMemory {  // where span buffers come from
     void* (*get)(size_t bytes);
     void (*put)(void* p);
@@ -806,6 +826,8 @@ struct PackedSpan {
     size_t n = 0;  // bytes of whole members; what follows them opens the next span
     std::vector<bl_bgzf_member> members;
     uint64_t text_bytes = 0;
+    uint64_t own_text = 0;  // text of the members that lie inside the reader's own part of the file (a prefix of the span's text;
+                            // less than text_bytes only for a sharded reader, whose last record ends in its neighbour's part)
     int state = 0;    // 0 free, 1 ready, 2 held by the caller
     int verdict = 1;  // 1 span, 0 end of file, -1 damaged file
 };
@@ -814,7 +836,12 @@ class PackedSpans {
 public:
     static constexpr int RING = 3;
     static constexpr size_t READ = 4u << 20;
-    PackedSpans(FILE* f, size_t limit, SpanMemory mem) : f_(f), limit_(limit), mem_(mem) { worker_ = std::thread([this] { produce(); }); }
+    // start / own_end: the part of the file that is this reader's own (whole file: 0 / ~0); members behind own_end are still
+    // delivered (the caller needs them to finish its last record) but in small spans
+    PackedSpans(FILE* f, size_t limit, SpanMemory mem, uint64_t start = 0, uint64_t own_end = ~0ULL) : f_(f), limit_(limit), mem_(mem), start_(start), own_end_(own_end)
+    {
+        worker_ = std::thread([this] { produce(); });
+    }
     ~PackedSpans()
     {
         {
@@ -870,6 +897,8 @@ private:
         const char* carry = nullptr;
         size_t carry_n = 0;
         bool eof = false;
+        uint64_t file_off = start_;  // where in the file the current span's first byte lies
+        if (start_ && fseeko(f_, (off_t)start_, SEEK_SET) != 0) eof = true;
         for (;;) {
             PackedSpan* b;
             {
@@ -880,7 +909,8 @@ private:
             }
             int verdict = 1;
             size_t filled = 0, walked = 0;
-            uint64_t text = 0;
+            uint64_t text = 0, own_text = 0;
+            unsigned borrowed = 0;
             b->members.clear();
             if (!grow(*b, 0, carry_n + READ)) verdict = -1;
             if (verdict == 1 && carry_n) std::memcpy(b->p, carry, carry_n);
@@ -895,10 +925,14 @@ private:
                     // a span is full when its text would pass the limit — or when it holds as many members as the inflate kernel
                     // keeps resident per 64 MiB of limit (1,024: four waves on each of 256 CUs): one member more would cost a
                     // second round of the kernel for that member alone
+                    const bool own = file_off + walked < own_end_;
                     if (!b->members.empty() && (text + m.isize > limit_ || b->members.size() >= max_members_)) { full = true; break; }
+                    if (!own && borrowed >= 16) { full = true; break; }  // (members of the neighbour's part: a few at a time)
                     b->members.push_back(m);
                     walked += used;
                     text += m.isize;
+                    if (own) own_text = text;
+                    else ++borrowed;
                 }
                 if (verdict != 1 || full || eof) break;
                 if (!grow(*b, filled, filled + READ)) { verdict = -1; break; }
@@ -912,9 +946,11 @@ private:
             if (verdict == 1 && b->members.empty()) verdict = filled > walked ? -1 : 0;  // a member cut short by the end of the file / the end
             b->n = walked;
             b->text_bytes = text;
+            b->own_text = own_text;
             b->verdict = verdict;
             carry = b->p + walked;
             carry_n = verdict == 1 ? filled - walked : 0;
+            file_off += walked;
             {
                 std::lock_guard<std::mutex> lk(m_);
                 b->state = 1;
@@ -929,6 +965,7 @@ private:
     const size_t limit_;
     const size_t max_members_ = (limit_ >> 16) ? (limit_ >> 16) : 1;
     const SpanMemory mem_;
+    const uint64_t start_, own_end_;
     PackedSpan ring_[RING];
     std::mutex m_;
     std::condition_variable cv_;
@@ -954,6 +991,11 @@ struct DeviceBgzf {
     size_t carry_n = 0;
     bool eof = false;
     char first_byte = 0;
+    // a reader of one part of the file (bl_reader_open_shard): the text in front of the first recognisable record start belongs
+    // to the part before (trim_front, parts 1 ..), and this part's last record is finished from the members of the next one:
+    // ext_start = where in the current text those borrowed members begin (npos: not reached yet)
+    bool trim_front = false, finished = false;
+    size_t ext_start = (size_t)-1;
     // what comes back from the device lands in page-locked memory: a copy into pageable memory would make the host wait for
     // everything queued in front of it (the inflate kernel), and nothing would overlap
     char* window = nullptr;
@@ -988,6 +1030,10 @@ struct DeviceBgzf {
 
 struct bl_reader {
     std::string path;
+    // a reader of one part of a BGZF file (bl_reader_open_shard): the part's members lie in [shard_start, shard_end) of the file
+    bool sharded = false, shard_first = true;
+    uint64_t shard_start = 0, shard_end = ~0ULL;
+    char shard_first_byte = 0;  // first byte of the FILE's text: tells FASTQ from FASTA to a part that does not begin with a record
     std::unique_ptr<DeviceBgzf> packed;
     std::unique_ptr<ByteSource> source;
     std::unique_ptr<RecordParser> records;
@@ -1035,6 +1081,92 @@ int bl_reader_open_threads(const char* path, int threads, bl_reader** out)
 
 int bl_reader_open(const char* path, bl_reader** out) { return bl_reader_open_threads(path, 0, out); }
 
+namespace {
+
+bool bgzf_header_ok(const unsigned char* h, uint64_t* bsize)
+{
+    const bool good = h[0] == 0x1f && h[1] == 0x8b && h[2] == 8 && (h[3] & 4) && h[12] == 'B' && h[13] == 'C' && h[14] == 2 && h[15] == 0 &&
+                      ((unsigned)h[10] | ((unsigned)h[11] << 8)) >= 6;
+    *bsize = ((uint64_t)h[16] | ((uint64_t)h[17] << 8)) + 1;
+    return good && *bsize >= 26;
+}
+
+// The first member boundary at or behind `from`: a BGZF header whose successor (where its BSIZE says) is a header too, or the
+// end of the file.  Members are at most 64 KiB long, so one lies within 64 KiB; `size` when there is none.
+uint64_t member_boundary_from(int fd, uint64_t from, uint64_t size)
+{
+    if (from >= size) return size;
+    std::vector<unsigned char> buf((size_t)((size - from) < (131072 + 18) ? (size - from) : (131072 + 18)));
+    size_t have = 0;
+    while (have < buf.size()) {
+        const ssize_t got = pread(fd, buf.data() + have, buf.size() - have, (off_t)(from + have));
+        if (got <= 0) break;
+        have += (size_t)got;
+    }
+    for (size_t i = 0; i + 18 <= have; ++i) {
+        uint64_t bsize = 0;
+        if (buf[i] != 0x1f || !bgzf_header_ok(buf.data() + i, &bsize)) continue;
+        const uint64_t next = from + i + bsize;
+        if (next == size) return from + i;
+        unsigned char h[18];
+        uint64_t b2 = 0;
+        if (next + 18 <= size && pread(fd, h, 18, (off_t)next) == 18 && bgzf_header_ok(h, &b2) && next + b2 <= size) return from + i;
+    }
+    return size;
+}
+
+}  // namespace
+
+int bl_reader_open_shard(const char* path, uint32_t rank, uint32_t world, bl_reader** out)
+{
+    if (!path || !out || world == 0 || rank >= world) return bl_set_error(BL_ERR_INVALID, "bad argument (rank < world)");
+    int rc = bl_reader_open_threads(path, 0, out);
+    if (rc != BL_OK) return rc;
+    bl_reader* r = *out;
+    auto fail_close = [&](const char* msg) {
+        bl_reader_close(r);
+        *out = nullptr;
+        return bl_set_error(BL_ERR_INVALID, msg);
+    };
+    if (r->source->kind()[0] != 'b') return fail_close("reading a file in parts needs BGZF (bgzip): its members are the entry points");
+    const int fd = open(path, O_RDONLY);
+    struct stat st;
+    if (fd < 0 || fstat(fd, &st) != 0) {
+        if (fd >= 0) close(fd);
+        return fail_close("cannot stat the file");
+    }
+    const uint64_t size = (uint64_t)st.st_size;
+    r->sharded = true;
+    r->shard_first = rank == 0;
+    r->shard_start = rank == 0 ? 0 : member_boundary_from(fd, size / world * rank, size);
+    r->shard_end = rank + 1 == world ? ~0ULL : member_boundary_from(fd, size / world * (rank + 1), size);
+    // the first byte of the file's text (FASTQ or FASTA?): the first member, inflated here
+    {
+        std::vector<unsigned char> m(65536 + 64);
+        const ssize_t got = pread(fd, m.data(), m.size(), 0);
+        uint64_t bsize = 0;
+        unsigned char first = 0;
+        if (got >= 28 && bgzf_header_ok(m.data(), &bsize) && (uint64_t)got >= bsize) {
+            const size_t xlen = (size_t)m[10] | ((size_t)m[11] << 8);
+            z_stream z;
+            std::memset(&z, 0, sizeof(z));
+            if (12 + xlen + 8 <= bsize && inflateInit2(&z, -15) == Z_OK) {
+                z.next_in = m.data() + 12 + xlen;
+                z.avail_in = (uInt)(bsize - 12 - xlen - 8);
+                z.next_out = &first;
+                z.avail_out = 1;
+                (void)inflate(&z, Z_SYNC_FLUSH);
+                if (z.avail_out != 0) first = 0;
+                inflateEnd(&z);
+            }
+        }
+        r->shard_first_byte = (char)first;
+    }
+    close(fd);
+    if (!r->shard_first_byte) return fail_close("cannot read the first member of the file");
+    return BL_OK;
+}
+
 int bl_reader_close(bl_reader* r)
 {
     if (!r) return BL_OK;
@@ -1051,6 +1183,7 @@ const char* bl_reader_kind(bl_reader* r) { return r && r->source ? r->source->ki
 int bl_reader_next_record(bl_reader* r, const char** name, const char** seq, uint64_t* seq_len)
 {
     if (!r || !seq_len) return bl_set_error(BL_ERR_INVALID, "NULL argument");
+    if (r->sharded) return bl_set_error(BL_ERR_INVALID, "a reader of one part of a file delivers device batches only");
     if (r->text || r->packed) return bl_set_error(BL_ERR_INVALID, "this reader is delivering text spans: records and spans cannot be mixed");
     if (!r->records) r->records.reset(new RecordParser(*r->source));
     const Step s = r->records->next(r->rec);
@@ -1070,6 +1203,7 @@ int bl_reader_next_record(bl_reader* r, const char** name, const char** seq, uin
 int bl_reader_next_batch(bl_ctx* ctx, bl_reader* r, uint64_t max_bases, bl_batch** out, uint64_t* n_seqs, uint64_t* n_bases)
 {
     if (!ctx || !r || !out) return bl_set_error(BL_ERR_INVALID, "NULL argument");
+    if (r->sharded) return bl_set_error(BL_ERR_INVALID, "a reader of one part of a file delivers device batches only");
     *out = nullptr;
     if (r->text || r->packed) return bl_set_error(BL_ERR_INVALID, "this reader is delivering text spans: records and spans cannot be mixed");
     if (!r->records) r->records.reset(new RecordParser(*r->source));
@@ -1109,6 +1243,7 @@ const SpanMemory PINNED_MEMORY = {[](size_t n) {
 
 int next_span(bl_reader* r, uint64_t max_bytes, const SpanMemory& mem, const char** text, uint64_t* n_bytes)
 {
+    if (r->sharded) return bl_set_error(BL_ERR_INVALID, "a reader of one part of a file delivers device batches only");
     if (r->records || r->packed) return bl_set_error(BL_ERR_INVALID, "this reader is delivering records: records and spans cannot be mixed");
     const size_t limit = max_bytes ? (size_t)max_bytes : (size_t)64 << 20;
     if (!r->text) r->text.reset(new TextCutter(*r->source, limit, mem));
@@ -1186,6 +1321,7 @@ int launch_packed(DeviceBgzf& d, int buf, size_t offset)
         if (rc == 0) d.eof = true;
     }
     const size_t add = sp ? (size_t)sp->text_bytes : 0, filled = offset + add;
+    if (sp && d.ext_start == (size_t)-1 && sp->own_text < sp->text_bytes) d.ext_start = offset + (size_t)sp->own_text;
     {
         void* p = d.d_text[buf];
         const int rc = device_reserve(&p, &d.text_cap[buf], filled + 64, offset, s);
@@ -1228,6 +1364,7 @@ int next_batch_packed(bl_ctx* ctx, bl_reader* r, bl_batch** out, uint64_t* n_seq
     hipStream_t s = d.stream;
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     for (;;) {
+        if (d.finished) return BL_OK;  // (a part of a file: its last record has been delivered)
         if (!d.pending.active) {
             const double t0 = now();
             const int rc = launch_packed(d, d.cur, d.carry_n);
@@ -1245,19 +1382,14 @@ int next_batch_packed(bl_ctx* ctx, bl_reader* r, bl_batch** out, uint64_t* n_seq
             if (d.eof) return BL_OK;  // end of file
             continue;
         }
-        // the end of the text comes back to the host: the cut is decided there
-        size_t win = filled < ((size_t)256 << 10) ? filled : (size_t)256 << 10;
-        size_t cut = 0;
-        for (;;) {
-            {
-                int rc = pinned_reserve(&d.window, &d.window_cap, win + 1);
-                if (rc == BL_OK && !d.first_back) {
-                    size_t one = 0;
-                    rc = pinned_reserve(&d.first_back, &one, 64);
-                }
-                if (rc != BL_OK) return rc;
+        auto fetch = [&](size_t from, size_t n) -> int {  // text[from, from + n) -> d.window, waited for; member statuses checked
+            int rc = pinned_reserve(&d.window, &d.window_cap, n + 1);
+            if (rc == BL_OK && !d.first_back) {
+                size_t one = 0;
+                rc = pinned_reserve(&d.first_back, &one, 64);
             }
-            R_HIP(hipMemcpyAsync(d.window, text + (filled - win), win, hipMemcpyDeviceToHost, s));
+            if (rc != BL_OK) return rc;
+            R_HIP(hipMemcpyAsync(d.window, text + from, n, hipMemcpyDeviceToHost, s));
             if (!d.first_byte) R_HIP(hipMemcpyAsync(d.first_back, text, 1, hipMemcpyDeviceToHost, s));
             const double t0 = now();
             R_HIP(hipStreamSynchronize(s));
@@ -1265,17 +1397,80 @@ int next_batch_packed(bl_ctx* ctx, bl_reader* r, bl_batch** out, uint64_t* n_seq
             if (!d.first_byte) d.first_byte = d.first_back[0];
             for (size_t i = 0; i < n_members; ++i)
                 if (d.status[i] != 0) return bl_set_error(BL_ERR_INVALID, "error reading the (compressed) stream");
-            if (d.eof) { cut = filled; break; }
-            const size_t at = find_record_cut(d.window, win, win, d.first_byte == '@' ? 'q' : 'a');
-            if (at >= 64 || (at > 0 && win == filled)) { cut = (filled - win) + at; break; }  // (64: the parser wants to see the bytes in front of the cut)
-            if (win == filled) break;  // no boundary in all of it: one record longer than the span
-            win = win * 8 < filled ? win * 8 : filled;
+            return BL_OK;
+        };
+        size_t win = 0, cut = 0, win_from = 0;
+        bool last_batch = false;
+        if (d.trim_front) {
+            // a reader of a later part of the file: its text begins at the first record start that can be recognised
+            size_t n = filled < ((size_t)1 << 20) ? filled : (size_t)1 << 20, at = 0;
+            for (;;) {
+                const int rc = fetch(0, n);
+                if (rc != BL_OK) return rc;
+                at = first_record_start(d.window, n, d.first_byte == '@' ? 'q' : 'a');
+                if ((at != 0 && at != (size_t)-1) || n == filled) break;
+                n = filled;
+            }
+            if (at == 0 || at == (size_t)-1) {  // none here
+                if (d.eof) { d.finished = true; return BL_OK; }  // nor anywhere: every byte of this part belongs to the part before
+                d.carry_n = filled;
+                continue;
+            }
+            // the borrowed members begin in front of that record start: the next part's reader finds the same start, so no record
+            // begins in this part at all
+            if (d.ext_start != (size_t)-1 && d.ext_start < at) { d.finished = true; return BL_OK; }
+            const size_t rest = filled - at;
+            const int other = d.cur ^ 1;
+            void* p = d.d_text[other];
+            const int rc = device_reserve(&p, &d.text_cap[other], rest + 64, 0, s);
+            d.d_text[other] = static_cast<uint8_t*>(p);
+            if (rc != BL_OK) return rc;
+            if (rest) R_HIP(hipMemcpyAsync(d.d_text[other], text + at, rest, hipMemcpyDeviceToDevice, s));
+            R_HIP(hipStreamSynchronize(s));
+            d.cur = other;
+            d.carry_n = rest;
+            if (d.ext_start != (size_t)-1) d.ext_start = d.ext_start > at ? d.ext_start - at : 0;
+            d.trim_front = false;
+            continue;  // (the next span is appended to what is left; this reader's first batch is that much longer)
+        }
+        if (d.ext_start != (size_t)-1) {
+            // the members of this reader's own part end inside this text: its last record ends at the first record start that
+            // can be recognised in what was borrowed from the next part (where that part's reader begins)
+            win_from = d.ext_start > 64 ? d.ext_start - 64 : 0;
+            win = filled - win_from;
+            const int rc = fetch(win_from, win);
+            if (rc != BL_OK) return rc;
+            const size_t off = d.ext_start - win_from;
+            const size_t at = first_record_start(d.window + off, win - off, d.first_byte == '@' ? 'q' : 'a');
+            if (at == 0 || at == (size_t)-1) {
+                if (!d.eof) {  // not in sight yet: borrow more
+                    d.carry_n = filled;
+                    continue;
+                }
+                cut = filled;  // the file ends first: everything is this part's
+            } else {
+                cut = d.ext_start + at;
+            }
+            last_batch = true;
+        } else {
+            // the end of the text comes back to the host: the cut is decided there
+            win = filled < ((size_t)256 << 10) ? filled : (size_t)256 << 10;
+            for (;;) {
+                win_from = filled - win;
+                const int rc = fetch(win_from, win);
+                if (rc != BL_OK) return rc;
+                if (d.eof) { cut = filled; break; }
+                const size_t at = find_record_cut(d.window, win, win, d.first_byte == '@' ? 'q' : 'a');
+                if (at >= 64 || (at > 0 && win == filled)) { cut = win_from + at; break; }  // (64: the parser wants to see the bytes in front of the cut)
+                if (win == filled) break;  // no boundary in all of it: one record longer than the span
+                win = win * 8 < filled ? win * 8 : filled;
+            }
         }
         if (cut == 0) {  // keep everything and read on
             d.carry_n = filled;
             continue;
         }
-        const size_t rest = filled - cut;
+        const size_t rest = last_batch ? 0 : filled - cut;
         const int other = d.cur ^ 1;
         if (rest) {
             void* p = d.d_text[other];
@@ -1286,14 +1481,15 @@ int next_batch_packed(bl_ctx* ctx, bl_reader* r, bl_batch** out, uint64_t* n_seq
         }
         d.cur = other;
         d.carry_n = rest;
-        if (!d.eof) {  // the next span starts now, behind the bytes just moved
+        if (last_batch) d.finished = true;
+        if (!d.eof && !last_batch) {  // the next span starts now, behind the bytes just moved
             const double t0 = now();
             const int rc = launch_packed(d, d.cur, d.carry_n);
             d.t_launch += now() - t0;
             if (rc != BL_OK) return rc;
         }
         const size_t ends_n = cut < 64 ? cut : 64;
-        const char* ends = d.window + (cut - (filled - win)) - ends_n;
+        const char* ends = d.window + (cut - win_from) - ends_n;
         const double t0 = now();
         const int rc = bl_parse_device_text(ctx, text, cut, d.first_byte, ends, ends_n, out, n_seqs, n_bases);
         d.t_parse += now() - t0;
@@ -1311,12 +1507,14 @@ int bl_reader_next_batch_device(bl_ctx* ctx, bl_reader* r, uint64_t max_text_byt
     if (n_seqs) *n_seqs = 0;
     if (n_bases) *n_bases = 0;
     // BGZF goes to the device compressed (BL_HOST_INFLATE=1: through the host's inflate pool instead — for comparisons)
-    if (!r->packed && !r->text && !r->records && r->source->kind()[0] == 'b' && !std::getenv("BL_HOST_INFLATE")) {
+    if (!r->packed && !r->text && !r->records && r->source->kind()[0] == 'b' && (r->sharded || !std::getenv("BL_HOST_INFLATE"))) {
         FILE* f = std::fopen(r->path.c_str(), "rb");
         if (!f) return bl_set_error(BL_ERR_INVALID, (std::string("cannot open ") + r->path).c_str());
         r->packed.reset(new DeviceBgzf());
         r->packed->ctx = ctx;
-        r->packed->spans.reset(new PackedSpans(f, max_text_bytes ? (size_t)max_text_bytes : (size_t)64 << 20, PINNED_MEMORY));
+        r->packed->trim_front = r->sharded && !r->shard_first;
+        if (r->sharded) r->packed->first_byte = r->shard_first_byte;
+        r->packed->spans.reset(new PackedSpans(f, max_text_bytes ? (size_t)max_text_bytes : (size_t)64 << 20, PINNED_MEMORY, r->shard_start, r->shard_end));
     }
     if (r->packed) {
         if (r->records || r->text) return bl_set_error(BL_ERR_INVALID, "records, spans and device batches cannot be mixed on one reader");

@@ -520,11 +520,16 @@ class Batch:
 class Reader:
     """FASTA / FASTQ (plain or gzip) reader of the library (bl_reader_*): host records or device batches."""
 
-    def __init__(self, path, threads=0):
-        """threads: inflate workers for BGZF input (0 = one per core, at most 16); other inputs use one read-ahead thread"""
+    def __init__(self, path, threads=0, shard=None):
+        """threads: inflate workers for BGZF input (0 = one per core, at most 16); other inputs use one read-ahead thread.
+        shard=(rank, world): this reader takes part `rank` of a BGZF file that `world` readers read between them (device
+        batches only; the parts' records in rank order are the file's records)"""
         self._lib = capi.lib()
         h = C.c_void_p()
-        check(self._lib.bl_reader_open_threads(str(path).encode(), int(threads), C.byref(h)))
+        if shard is not None:
+            check(self._lib.bl_reader_open_shard(str(path).encode(), int(shard[0]), int(shard[1]), C.byref(h)))
+        else:
+            check(self._lib.bl_reader_open_threads(str(path).encode(), int(threads), C.byref(h)))
         self._h = h
 
     @property

@@ -17,6 +17,22 @@ def shard_reads(n_reads, world_size, rank):
     return first, base + (1 if rank < extra else 0)
 
 
+def file_shard_reader(path, rank=None, world_size=None):
+    """A Reader of this rank's part of a bgzip'ed FASTA / FASTQ file that all ranks read between them (bl_reader_open_shard): no
+    rank reads the whole file, none talks to another, and the parts' records in rank order are the file's records.  rank /
+    world_size default to the initialised torch.distributed group (1 rank otherwise)."""
+    from .scan import Reader
+
+    if rank is None or world_size is None:
+        import torch.distributed as dist
+
+        if dist.is_available() and dist.is_initialized():
+            rank, world_size = dist.get_rank(), dist.get_world_size()
+        else:
+            rank, world_size = 0, 1
+    return Reader(path, shard=(int(rank), int(world_size)))
+
+
 def shard_ranges(offsets, world_size, rank):
     """For ragged batches: split the sequences so that every rank gets about the same number of BASES.
     offsets: uint64[n_seqs+1].  Returns (first_seq, end_seq)."""

@@ -182,6 +182,14 @@ typedef struct bl_reader bl_reader;
  * by `threads` workers (0 = one per core, at most 16), any other gzip stream by one thread, plain files are read ahead. */
 int bl_reader_open(const char* path, bl_reader** out);
 int bl_reader_open_threads(const char* path, int threads, bl_reader** out);
+/* One part of a BGZF file, for several readers (GPUs, ranks) that take one file between them: part `rank` of `world` holds the
+ * members from the first member boundary at or behind byte size / world * rank to the next part's, and delivers the records that
+ * BEGIN in its text — from the first record start that can be recognised there (a line that opens a record, a newline in front of
+ * it inside the part's text) to the place where the next part's reader finds its own, found by inflating into the next part.
+ * The parts' records, in rank order, are the file's records; the readers do not talk to each other.  Device batches only
+ * (bl_reader_next_batch_device); BL_ERR_INVALID for anything but BGZF.  This is how north_star's "shard by read" reaches the
+ * file: the reference's drivers read one file per process (tests/test_kmer_view.cpp:23-42). */
+int bl_reader_open_shard(const char* path, uint32_t rank, uint32_t world, bl_reader** out);
 int bl_reader_close(bl_reader* reader);
 /* "plain", "gzip" or "bgzf": how the file is being read */
 const char* bl_reader_kind(bl_reader* reader);

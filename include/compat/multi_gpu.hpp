@@ -86,13 +86,31 @@ class multi_gpu
                 return bl_scan_minimizers(c, b, first, n, unit, w, hash_seed, canonical ? (uint32_t)BL_FLAG_CANONICAL : 0u, nullptr, nullptr, nullptr, 0, r);
             });
         }
+        // the same scans over a bgzip'ed FASTA / FASTQ FILE that the devices read between them: every device thread opens its own
+        // part(s) of the file (bl_reader_open_shard: parts begin and end at record starts that each reader recognises by itself),
+        // inflates and parses them on its GPU and scans batch after batch.  xor_pos is folded over positions relative to each
+        // batch and means nothing here; count, xor_value and xor_hash do not depend on how the file was cut.
+        scan_digest minimizers_file(std::string const& path, uint32_t unit, uint32_t w, uint64_t seed, bool canonical, int parts_per_device = 1)
+        {
+            return run_file(path, parts_per_device, [=](bl_ctx* c, bl_batch* b, uint64_t first, uint64_t n, bl_result* r) {
+                return bl_scan_minimizers(c, b, first, n, unit, w, seed, canonical ? (uint32_t)BL_FLAG_CANONICAL : 0u, nullptr, nullptr, nullptr, 0, r);
+            });
+        }
+        scan_digest syncmers_file(std::string const& path, uint32_t k, uint32_t s, uint32_t start_offset, uint32_t end_offset, bool canonical, int parts_per_device = 1)
+        {
+            return run_file(path, parts_per_device, [=](bl_ctx* c, bl_batch* b, uint64_t first, uint64_t n, bl_result* r) {
+                return bl_scan_syncmers(c, b, first, n, k, s, start_offset, end_offset, 0, canonical ? (uint32_t)BL_FLAG_CANONICAL : 0u, nullptr, 0, r);
+            });
+        }
         std::vector<scan_digest> const& per_device() const noexcept {return last;}
+        uint64_t bases_read() const noexcept {return file_bases;}
 
     private:
         using scan_fn = std::function<int(bl_ctx*, bl_batch*, uint64_t, uint64_t, bl_result*)>;
         static constexpr uint64_t RANGE = 1500000000ull;
         std::vector<bl_ctx*> ctxs;
         std::vector<scan_digest> last;
+        uint64_t file_bases = 0;
 
         // scan a whole batch in ranges that end on sequence boundaries where offsets are known (fixed read length otherwise)
         static scan_digest scan_batch(bl_ctx* c, bl_batch* b, uint64_t n_bases, uint64_t align, scan_fn const& scan)
@@ -159,6 +177,37 @@ class multi_gpu
                 try { last[g] = scan_batch(ctxs[g], b, local.back(), 0, scan); } catch (...) { bl_batch_destroy(b); throw; }
                 bl_batch_destroy(b);
             });
+            return reduce();
+        }
+        scan_digest run_file(std::string const& path, int parts_per_device, scan_fn scan)
+        {
+            const int n = devices(), ppd = parts_per_device < 1 ? 1 : parts_per_device;
+            last.assign(n, scan_digest());
+            std::vector<uint64_t> bases(n, 0);
+            in_parallel([&](int g) {
+                for (int part = g * ppd; part < (g + 1) * ppd; ++part) {
+                    bl_reader* reader = nullptr;
+                    check(bl_reader_open_shard(path.c_str(), (uint32_t)part, (uint32_t)(n * ppd), &reader), "bl_reader_open_shard");
+                    try {
+                        for (;;) {
+                            bl_batch* b = nullptr;
+                            uint64_t n_seqs = 0, n_bases = 0;
+                            check(bl_reader_next_batch_device(ctxs[g], reader, 0, &b, &n_seqs, &n_bases), "bl_reader_next_batch_device");
+                            if (not b) break;
+                            scan_digest d;
+                            try { d = scan_batch(ctxs[g], b, n_bases, 0, scan); } catch (...) { bl_batch_destroy(b); throw; }
+                            bl_batch_destroy(b);
+                            last[g].count += d.count;
+                            last[g].xor_value ^= d.xor_value;
+                            last[g].xor_hash ^= d.xor_hash;
+                            bases[g] += n_bases;
+                        }
+                    } catch (...) { bl_reader_close(reader); throw; }
+                    bl_reader_close(reader);
+                }
+            });
+            file_bases = 0;
+            for (uint64_t b : bases) file_bases += b;
             return reduce();
         }
         scan_digest run_synth(uint64_t seed, uint64_t bases_per_device, uint64_t read_len, scan_fn scan)

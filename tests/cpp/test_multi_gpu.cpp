@@ -1,6 +1,8 @@
 // GPU test of the C++ multi-device driver (include/compat/multi_gpu.hpp) and of bl_count_allreduce (RCCL's C API): run with
 // every visible device — ONE on the test box, so what is exercised is the whole flow (threads, shards, ncclCommInitAll,
 // ncclAllReduce) at world size 1; N > 1 needs hardware this box does not have.
+#include <zlib.h>
+
 #include <cstdio>
 #include <string>
 #include <vector>
@@ -9,6 +11,35 @@
 
 extern "C" {
 #include "../../oracle/bl_oracle.h"
+}
+
+// a BGZF file (SAM spec 4.1: gzip members with the 'BC' extra field) holding `text`, members of `block` bytes of text
+static void write_bgzf(const std::string& path, const std::string& text, size_t block)
+{
+    FILE* f = std::fopen(path.c_str(), "wb");
+    for (size_t a = 0; a <= text.size(); a += block) {
+        const size_t n = a < text.size() ? std::min(block, text.size() - a) : 0;  // the last, empty member is the end-of-file marker
+        std::vector<unsigned char> body(compressBound(n) + 64);
+        z_stream z{};
+        deflateInit2(&z, 6, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY);
+        z.next_in = reinterpret_cast<unsigned char*>(const_cast<char*>(text.data() + a));
+        z.avail_in = (uInt)n;
+        z.next_out = body.data();
+        z.avail_out = (uInt)body.size();
+        deflate(&z, Z_FINISH);
+        const size_t nb = z.total_out;
+        deflateEnd(&z);
+        const unsigned bsize = (unsigned)(12 + 6 + nb + 8 - 1);
+        const unsigned long crc = crc32(crc32(0L, Z_NULL, 0), reinterpret_cast<const unsigned char*>(text.data() + a), (uInt)n);
+        const unsigned char head[18] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, (unsigned char)(bsize & 255), (unsigned char)(bsize >> 8)};
+        std::fwrite(head, 1, 18, f);
+        std::fwrite(body.data(), 1, nb, f);
+        const unsigned char tail[8] = {(unsigned char)crc, (unsigned char)(crc >> 8), (unsigned char)(crc >> 16), (unsigned char)(crc >> 24),
+                                       (unsigned char)n, (unsigned char)(n >> 8), (unsigned char)(n >> 16), (unsigned char)(n >> 24)};
+        std::fwrite(tail, 1, 8, f);
+        if (n == 0) break;
+    }
+    std::fclose(f);
 }
 
 static int g_fail = 0;
@@ -54,6 +85,33 @@ int main()
         const uint64_t cnt = blo_syncmers(s.data(), offs.data(), n_seqs, 31, 11, 0, 20, 1, 0, 1, pos.data(), pos.size());
         auto sy = node.syncmers(s.data(), offs.data(), n_seqs, 31, 11, 0, 20, true);
         CHECK(sy.count == cnt, "syncmers: %llu vs %llu", (unsigned long long)sy.count, (unsigned long long)cnt);
+    }
+    // the same reads as a bgzip'ed FASTQ file that the devices read between them (three parts per device here, so that the cutting is
+    // exercised on one GPU too): same count and XOR digests as the scan of the reads in memory
+    {
+        const uint64_t n_reads = 30000, L = 150;
+        std::string s(n_reads * L, 'A');
+        blo_synth(11, 0, n_reads * L, s.data());
+        for (uint64_t p = 500; p < s.size(); p += 4099) s[p] = 'N';
+        std::vector<uint64_t> offs;
+        std::string text;
+        for (uint64_t i = 0; i <= n_reads; ++i) offs.push_back(i * L);
+        for (uint64_t i = 0; i < n_reads; ++i) {
+            text += "@read" + std::to_string(i) + "\n";
+            text.append(s, i * L, L);
+            text += "\n+\n" + std::string(L, i % 3 ? 'F' : '@') + "\n";
+        }
+        const std::string path = "/tmp/bl_multi_gpu_test.fq.gz";
+        write_bgzf(path, text, 60000);
+        uint64_t dg[4];
+        blo_minimizer_digest(s.data(), offs.data(), n_reads, 31, 11, 42, 1, 1, dg);
+        for (int parts : {1, 3}) {
+            auto got = node.minimizers_file(path, 31, 11, 42, true, parts);
+            CHECK(got.count == dg[0] && got.xor_value == dg[1] && got.xor_hash == dg[2] && node.bases_read() == n_reads * L,
+                  "file in %d part(s) per device: %llu minimizers vs %llu, %llu bases", parts, (unsigned long long)got.count, (unsigned long long)dg[0],
+                  (unsigned long long)node.bases_read());
+        }
+        std::remove(path.c_str());
     }
     // synthetic shards on the devices (BASELINE C5's shape, small): per-device counts add up; device 0's shard = the oracle's seed
     {

@@ -417,3 +417,53 @@ def test_bgzf_device_path_awkward_files(tmp_path):
             for b in biolib_amd.Reader(path).device_batches(ctx, 1 << 20):
                 b.close()
     ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["fastq", "fasta"])
+def test_bgzf_file_read_in_parts(tmp_path, kind):
+    """one BGZF file read by `world` readers that take a part each (bl_reader_open_shard): the parts' sequences, in rank order,
+    are the file's sequences — whatever the number of parts (more parts than members included), the span size, and wherever the
+    member boundaries fall inside the records; the readers never see each other"""
+    import biolib_amd
+
+    ctx = biolib_amd.Context(0)
+    rng = np.random.default_rng(31)
+    if kind == "fastq":
+        seqs = [O.synth(500 + i, int(n)).tobytes() for i, n in enumerate(rng.integers(1, 400, 6000))]
+        first = [b"@", b"+", b"I", b"@", b">"]
+        text = b"".join(b"@r%d a@b" % i + b"\n" + s + b"\n+\n" + (first[i % 5] + b"@" * (len(s) - 1))[:len(s)] + b"\n" for i, s in enumerate(seqs))
+    else:
+        lens = [1, 69, 70, 71, 5000, 400_000, 3, 150_000, 12] + [int(x) for x in rng.integers(1, 3000, 300)]
+        seqs = [O.synth(700 + i, n).tobytes() for i, n in enumerate(lens)]
+        text = b"".join(b">c%d x>y\n" % i + b"\n".join(s[j:j + 70] for j in range(0, len(s), 70)) + b"\n" for i, s in enumerate(seqs))
+    whole = b"".join(seqs)
+    for block, eof in ((60000, True), (7001, False)):
+        path = tmp_path / f"parts_{block}.gz"
+        path.write_bytes(_bgzf(text, block=block, eof=eof))
+        n_members = (len(text) + block - 1) // block
+        for world, limit in ((1, 0), (2, 0), (3, 256 << 10), (5, 64 << 10), (8, 0), (n_members + 3 if block == 60000 else 40, 0)):
+            got, n_seqs, sizes = [], 0, []
+            for rank in range(world):
+                r = biolib_amd.Reader(path, shard=(rank, world))
+                part = 0
+                for b in r.device_batches(ctx, limit):
+                    got.append(bytes(b.download()))
+                    n_seqs += b.n_seqs
+                    part += b.n_bases
+                    b.close()
+                r.close()
+                sizes.append(part)
+            assert b"".join(got) == whole, (kind, block, world, sizes)
+            assert n_seqs == len(seqs) and sum(sizes) == len(whole)
+            if world in (2, 3) and kind == "fastq":
+                assert min(sizes) > 0.5 * len(whole) / world  # the parts are about equal
+    # a sharded reader refuses the host calls; anything but BGZF refuses to be read in parts
+    r = biolib_amd.Reader(path, shard=(0, 2))
+    with pytest.raises(biolib_amd.BiolibError):
+        list(r.records())
+    plain = tmp_path / "plain.fq"
+    plain.write_bytes(text[:1000])
+    with pytest.raises(biolib_amd.BiolibError):
+        biolib_amd.Reader(plain, shard=(0, 2))
+    ctx.close()
