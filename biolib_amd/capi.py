@@ -20,7 +20,7 @@ SYMBOLS = [
     "bl_batch_device_bases", "bl_batch_download", "bl_scan_kmers", "bl_scan_minimizers", "bl_scan_hash_sample", "bl_scan_super_kmers", "bl_scan_syncmers", "bl_sort_unique_u64", "bl_jaccard_sorted_u64", "bl_partition_u64", "bl_sort_u64", "bl_count_sorted_u64", "bl_probe_hbm", "bl_clock_probe_start", "bl_clock_probe_finish", "bl_ctx_set_lanes", "bl_pack_super_kmers", "bl_count_super_kmers", "bl_partition_records", "bl_expand_super_kmers",
     "bl_ctx_last_scan_ms", "bl_ctx_kernel_timing", "bl_ctx_kernel_time", "bl_reader_open", "bl_reader_open_threads", "bl_reader_kind", "bl_reader_next_text", "bl_reader_next_batch_device", "bl_reader_close", "bl_reader_next_record",
     "bl_reader_next_batch", "bl_reader_last_batch", "bl_reader_last_name", "bl_batch_from_text", "bl_run_file_name", "bl_write_run_u64", "bl_write_vector_u64", "bl_file_count_u64", "bl_read_file_u64_host", "bl_read_file_u64", "bl_merge_runs_u64", "bl_count_allreduce",
-    "bl_device_alloc", "bl_device_free", "bl_copy_to_host", "bl_copy_to_device", "bl_hash64_u64", "bl_bgzf_walk", "bl_bgzf_inflate", "bl_host_alloc", "bl_host_free", "bl_reader_open_shard",
+    "bl_device_alloc", "bl_device_free", "bl_copy_to_host", "bl_copy_to_device", "bl_hash64_u64", "bl_bgzf_walk", "bl_bgzf_inflate", "bl_host_alloc", "bl_host_free", "bl_reader_open_shard", "bl_reader_shard_range",
 ]
 
 
@@ -123,6 +123,7 @@ def lib():
     L.bl_copy_to_host.argtypes = [vp, vp, vp, u64]
     L.bl_copy_to_device.argtypes = [vp, vp, vp, u64]
     L.bl_reader_open_shard.argtypes = [C.c_char_p, u32, u32, C.POINTER(vp)]
+    L.bl_reader_shard_range.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]
     L.bl_host_alloc.argtypes = [vp, u64, C.POINTER(vp)]
     L.bl_host_free.argtypes = [vp, vp]
     L.bl_bgzf_walk.argtypes = [vp, u64, u64, u64, vp, u64, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]

@@ -1140,13 +1140,15 @@ int bl_reader_open_shard(const char* path, uint32_t rank, uint32_t world, bl_rea
     r->shard_first = rank == 0;
     r->shard_start = rank == 0 ? 0 : member_boundary_from(fd, size / world * rank, size);
     r->shard_end = rank + 1 == world ? ~0ULL : member_boundary_from(fd, size / world * (rank + 1), size);
-    // the first byte of the file's text (FASTQ or FASTA?): the first member, inflated here
+    // the first byte of the file's text (FASTQ or FASTA?): the first member that holds text, inflated here
     {
         std::vector<unsigned char> m(65536 + 64);
-        const ssize_t got = pread(fd, m.data(), m.size(), 0);
-        uint64_t bsize = 0;
         unsigned char first = 0;
-        if (got >= 28 && bgzf_header_ok(m.data(), &bsize) && (uint64_t)got >= bsize) {
+        uint64_t at = 0;
+        for (int tries = 0; tries < 64 && !first && at < size; ++tries) {
+            const ssize_t got = pread(fd, m.data(), m.size(), (off_t)at);
+            uint64_t bsize = 0;
+            if (got < 28 || !bgzf_header_ok(m.data(), &bsize) || (uint64_t)got < bsize) break;
             const size_t xlen = (size_t)m[10] | ((size_t)m[11] << 8);
             z_stream z;
             std::memset(&z, 0, sizeof(z));
@@ -1159,11 +1161,20 @@ int bl_reader_open_shard(const char* path, uint32_t rank, uint32_t world, bl_rea
                 if (z.avail_out != 0) first = 0;
                 inflateEnd(&z);
             }
+            at += bsize;  // (a member without text: look at the next one)
         }
         r->shard_first_byte = (char)first;
     }
     close(fd);
     if (!r->shard_first_byte) return fail_close("cannot read the first member of the file");
+    return BL_OK;
+}
+
+int bl_reader_shard_range(bl_reader* r, uint64_t* first_byte, uint64_t* end_byte)
+{
+    if (!r || !first_byte || !end_byte) return bl_set_error(BL_ERR_INVALID, "NULL argument");
+    *first_byte = r->shard_start;
+    *end_byte = r->shard_end;
     return BL_OK;
 }
 

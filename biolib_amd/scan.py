@@ -533,6 +533,13 @@ class Reader:
         self._h = h
 
     @property
+    def shard_range(self):
+        """(first byte, end byte) of the file whose members are this reader's own (end = 2^64 - 1: to the end of the file)"""
+        a, b = C.c_uint64(), C.c_uint64()
+        check(self._lib.bl_reader_shard_range(self._h, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
+
+    @property
     def kind(self):
         """'plain', 'gzip' or 'bgzf'"""
         return self._lib.bl_reader_kind(self._h).decode()

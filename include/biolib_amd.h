@@ -190,6 +190,9 @@ int bl_reader_open_threads(const char* path, int threads, bl_reader** out);
  * (bl_reader_next_batch_device); BL_ERR_INVALID for anything but BGZF.  This is how north_star's "shard by read" reaches the
  * file: the reference's drivers read one file per process (tests/test_kmer_view.cpp:23-42). */
 int bl_reader_open_shard(const char* path, uint32_t rank, uint32_t world, bl_reader** out);
+/* the bytes of the file whose members are the reader's own: [first_byte, end_byte), end_byte = UINT64_MAX for the last part
+ * (0 / UINT64_MAX for a reader of the whole file) */
+int bl_reader_shard_range(bl_reader* reader, uint64_t* first_byte, uint64_t* end_byte);
 int bl_reader_close(bl_reader* reader);
 /* "plain", "gzip" or "bgzf": how the file is being read */
 const char* bl_reader_kind(bl_reader* reader);

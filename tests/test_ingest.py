@@ -419,6 +419,49 @@ def test_bgzf_device_path_awkward_files(tmp_path):
     ctx.close()
 
 
+def test_shard_ranges_are_member_boundaries(tmp_path):
+    """CPU: the parts of a BGZF file (bl_reader_open_shard) begin at member boundaries, follow each other without a gap and
+    cover the file; a deflate payload that happens to hold the gzip magic is not taken for a member; an empty first member
+    does not hide the format; plain gzip is refused"""
+    import gzip
+    import struct
+
+    import biolib_amd
+
+    rng = np.random.default_rng(3)
+    # incompressible text (stored blocks: the payload IS the text) seeded with fake BGZF headers
+    fake = b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00\x40\x00"
+    body = bytearray(rng.integers(0, 256, 600_000, dtype=np.uint8).tobytes())
+    for at in range(1000, len(body) - 100, 9973):
+        body[at:at + len(fake)] = fake
+    text = b">x\n" + bytes(body)
+    data = _bgzf(text, block=30000)
+    path = tmp_path / "f.gz"
+    path.write_bytes(data)
+    offs, at = [], 0
+    while at < len(data):
+        offs.append(at)
+        at += struct.unpack_from("<H", data, at + 16)[0] + 1
+    for world in (1, 2, 3, 7, 64):
+        prev_end = 0
+        for rank in range(world):
+            r = biolib_amd.Reader(path, shard=(rank, world))
+            a, b = r.shard_range
+            r.close()
+            assert a == prev_end and (a in offs or a == len(data)), (world, rank, a)
+            assert (b == 2**64 - 1) == (rank == world - 1)
+            if b != 2**64 - 1:
+                assert b >= a and (b in offs or b == len(data)) and b >= len(data) // world * (rank + 1)
+                prev_end = b
+    # an empty member in front of the text
+    empty = _bgzf(b"", eof=False)[:0] + _bgzf(b"")  # (the end-of-file marker alone is an empty member)
+    (tmp_path / "e.gz").write_bytes(empty + _bgzf(b"@r\nACGT\n+\nIIII\n"))
+    biolib_amd.Reader(tmp_path / "e.gz", shard=(1, 2)).close()
+    (tmp_path / "g.gz").write_bytes(gzip.compress(b"@r\nACGT\n+\nIIII\n"))
+    with pytest.raises(biolib_amd.BiolibError):
+        biolib_amd.Reader(tmp_path / "g.gz", shard=(0, 2))
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("kind", ["fastq", "fasta"])
 def test_bgzf_file_read_in_parts(tmp_path, kind):
