@@ -109,15 +109,29 @@ struct Input {
         advance(1);
         return w;
     }
+    uint32_t words_taken() const { return taken; }
+    // the symbol loop's form: nothing is counted per word; `over` rises (at the latest 64 words late) once more words have been
+    // taken than `limit`
+    uint32_t over = 0;
+    uint32_t next_word_hot(uint32_t limit)
+    {
+        const uint32_t w = next_word();
+        if ((taken & 63u) == 0 && taken > limit) over = 1;
+        return w;
+    }
     uint32_t lead_bits() const { return 0; }
 };
 #else
 struct Input {
     const uint32_t* words;  // the data's first byte lies in words[0] (lead bytes in front of it are skipped by the bit reader)
-    uint32_t max_word;      // highest index that may be loaded (the buffer is padded accordingly)
+    uint32_t max_word;      // highest index that may be loaded (inside the packed buffer)
     uint32_t lead;          // bytes of words[0] in front of the data
     uint32_t cur, nxt;      // this lane's dword of the current / next 64-dword chunk
-    uint32_t chunk = 0, idx = 0, taken = 0;
+    uint32_t chunk = 0, idx = 0;
+    uint32_t over = 0;  // more words taken than the data holds (noticed when a chunk is finished: at most 64 words late)
+    // (Tried: the scalar memory path — every lane wants the same dword — with the next dword's load issued as the current one
+    // is taken.  The compiler loads into a temporary and waits for it at once to copy it into the loop-carried register, so
+    // every refill paid a scalar-load latency; one wait per 64 dwords, as here, is cheaper.)
     __device__ __forceinline__ uint32_t load(uint32_t c) const
     {
         uint32_t i = c * 64u + (threadIdx.x & 63u);
@@ -138,7 +152,6 @@ struct Input {
     __device__ __forceinline__ uint32_t peek_word() const { return (uint32_t)__builtin_amdgcn_readlane((int)cur, (int)idx); }
     __device__ __forceinline__ void advance(uint32_t n)  // n = 0 or 1
     {
-        taken += n;
         idx += n;
         if (idx == 64u) {  // once per 256 bytes of input
             idx = 0;
@@ -151,6 +164,19 @@ struct Input {
     {
         const uint32_t w = peek_word();
         advance(1);
+        return w;
+    }
+    __device__ __forceinline__ uint32_t words_taken() const { return chunk * 64u + idx; }
+    __device__ __forceinline__ uint32_t next_word_hot(uint32_t limit)  // the symbol loop's form
+    {
+        const uint32_t w = peek_word();
+        if (++idx == 64u) {
+            idx = 0;
+            cur = nxt;
+            ++chunk;
+            nxt = load(chunk + 1);
+            over |= (limit - chunk * 64u) >> 31;  // (both far below 2^31)
+        }
         return w;
     }
     __device__ __forceinline__ uint32_t lead_bits() const { return lead * 8u; }
@@ -243,7 +269,7 @@ struct Bits {
         if (nb <= 32) {
             bb |= (uint64_t)in.next_word() << nb;
             nb += 32;
-            if (in.taken > word_limit) return false;
+            if (in.words_taken() > word_limit) return false;
         }
         return true;
     }
@@ -543,25 +569,46 @@ BL_IDEV uint32_t inflate_member(Shared& sh, In& in, uint32_t n_in, uint8_t* out,
             if (!build_code(sh, sh.lens + MAX_LL, n_d, D_ROOT, sh.d_table, sh.d_sorted, sh.d, true)) { status = ERR_CODE_SET; break; }
             ll_regs.load(sh.ll_table);
             d_regs.load(sh.d_table);
-            // The symbols of the block.  The loop is written for the instruction count and for plain control flow (one exit, no
-            // jumps out of nested blocks: anything else costs this compiler several extra jumps per symbol): whatever can go
-            // wrong is gathered in `bad` and looked at together with the one bound on q, and a wrong path only ever touches
-            // the ring (whose index is masked) before it is noticed.
-            uint32_t bad = 0, stop = 0;
-            do {
-                b.refill(in);
-                uint32_t e = ll_regs.lookup(b.peek(LL_ROOT));
-                if ((e & 15u) == 0) {  // rare: a code longer than the root
-                    const uint32_t f = decode_long(b, sh.ll_sorted, sh.ll);
-                    e = f ? expand_ll(f >> 4, f & 15u) : (E_RESERVED | 1u);
-                }
-                b.drop((int)(e & 15u));
-                if (e & E_LITERAL) {
-                    sh.ring[q & (WINDOW - 1)] = (uint8_t)(e >> 8);  // (the same store from every lane; one byte past the text's end
-                    ++q;                                             // is caught below before anything leaves the ring)
-                } else if ((e & (E_END | E_RESERVED)) == 0) {
+            // The symbols of the block.  The loop is written for the instruction count (a lone wave issues one instruction per
+            // four cycles at best, and pays for every taken jump): a literal is a straight run back to the top; whatever can go
+            // wrong is gathered in `bad` / `in.over` and looked at together with the one bound on q, and a wrong path only ever
+            // touches the ring (whose index is masked) before it is noticed.
+            uint32_t bad = 0;
+            // Two loops: the inner one decodes symbols and changes nothing but the bit buffer, q and the error bits, so that the
+            // bound, the flush positions and the status are constants to it (as one loop, every symbol paid a dozen register
+            // copies for the rare path that moves them); it is left at the bound (or on an error bit) and at the end of the block.
+            for (;;) {
+                bool block_done = false;
+                // the ONE number a symbol is checked against: the bound, or 0 as soon as an error bit is up (looked at after
+                // every match; a run of literals reaches the bound soon enough)
+                uint32_t q_limit = (bad | in.over) ? 0u : q_stop;
+                for (;;) {
+                    if (b.nb <= 32) {
+                        b.bb |= (uint64_t)in.next_word_hot(word_limit) << b.nb;
+                        b.nb += 32;
+                    }
+                    uint32_t e = ll_regs.lookup(b.peek(LL_ROOT));
+                    if ((e & 15u) == 0) {  // rare: a code longer than the root
+                        const uint32_t f = decode_long(b, sh.ll_sorted, sh.ll);
+                        e = f ? expand_ll(f >> 4, f & 15u) : (E_RESERVED | 1u);
+                    }
+                    b.drop((int)(e & 15u));
+                    if (e & E_LITERAL) {
+                        sh.ring[q & (WINDOW - 1)] = (uint8_t)(e >> 8);  // (the same store from every lane; one byte past the text's
+                        ++q;                                             // end is caught at the bound before anything leaves the ring)
+                        if (q >= q_limit) break;
+                        continue;
+                    }
+                    if (e & (E_END | E_RESERVED)) {  // end of block, or a reserved symbol
+                        bad |= e & E_RESERVED;
+                        block_done = true;
+                        break;
+                    }
                     const uint32_t len = (e >> 16) + b.take((int)((e >> 4) & 15u));
-                    b.refill(in);
+                    if (b.nb <= 32) {
+                        b.bb |= (uint64_t)in.next_word_hot(word_limit) << b.nb;
+                        b.nb += 32;
+                    }
                     uint32_t de = d_regs.lookup(b.peek(D_ROOT));
                     if ((de & 15u) == 0) {
                         const uint32_t f = decode_long(b, sh.d_sorted, sh.d);
@@ -588,27 +635,23 @@ BL_IDEV uint32_t inflate_member(Shared& sh, In& in, uint32_t n_in, uint8_t* out,
                     }
                     BL_WAVE_SYNC();
                     q += len;
-                } else {
-                    stop = e;  // end of block, or a reserved symbol
+                    q_limit = (bad | in.over) ? 0u : q_stop;
+                    if (q >= q_limit) break;
                 }
-                if ((q >= q_stop) | (bad != 0) | (in.taken > word_limit)) {
-                    if (in.taken > word_limit) status = ERR_INPUT;
-                    else if (bad) status = (bad & E_RESERVED) ? ERR_SYMBOL : ERR_DISTANCE;
-                    else if (q > q_end) status = ERR_OVERRUN;
-                    else {
-                        if (q >= next_flush) {
-                            BL_WAVE_SYNC();
-                            flush_range(sh, g, flushed, next_flush);
-                            flushed = next_flush;
-                            next_flush += FLUSH;
-                        }
-                        // at the text's end only the end-of-block code may follow: the bound then sits one past it
-                        q_stop = q == q_end ? q_end + 1u : (next_flush < q_end ? next_flush : q_end);
-                    }
-                    if (status != OK) stop = E_RESERVED;
+                // the bound, an error bit, or the end of the block
+                if (in.over) status = ERR_INPUT;
+                else if (bad) status = (bad & E_RESERVED) ? ERR_SYMBOL : ERR_DISTANCE;
+                else if (q > q_end) status = ERR_OVERRUN;
+                if (status != OK || block_done) break;
+                if (q >= next_flush) {
+                    BL_WAVE_SYNC();
+                    flush_range(sh, g, flushed, next_flush);
+                    flushed = next_flush;
+                    next_flush += FLUSH;
                 }
-            } while (!stop);
-            if (status == OK && (stop & E_RESERVED)) status = ERR_SYMBOL;
+                // at the text's end only the end-of-block code may follow: the bound then sits one past it
+                q_stop = q == q_end ? q_end + 1u : (next_flush < q_end ? next_flush : q_end);
+            }
             if (status != OK) break;
         }
         if (last) break;
@@ -618,7 +661,7 @@ BL_IDEV uint32_t inflate_member(Shared& sh, In& in, uint32_t n_in, uint8_t* out,
     if (q > q_end) q = q_end;  // (a literal one past the end was refused above; it stays in the ring)
     if (q > flushed) flush_range(sh, g, flushed, q);  // what a damaged stream produced before it failed is within [0, isize) too
     if (status == OK) {
-        const uint32_t bits_used = in.taken * 32u - (uint32_t)b.nb - in.lead_bits();
+        const uint32_t bits_used = in.words_taken() * 32u - (uint32_t)b.nb - in.lead_bits();
         if (bits_used > n_in * 8u) status = ERR_INPUT;
         else if (q != q_end) status = ERR_SIZE;
     }
