@@ -619,18 +619,40 @@ BL_IDEV uint32_t inflate_member(Shared& sh, In& in, uint32_t n_in, uint8_t* out,
                     bad |= (de & E_RESERVED) | (uint32_t)(dist > q - shift);
                     BL_WAVE_SYNC();  // the literals written since the last match are in the ring
                     const uint32_t from = q - dist;
-                    // (most matches are shorter than a wave is wide: one masked read and write, no loop)
-                    if (dist >= len) {
+                    if (dist >= len || dist >= 64u) {
+                        // the source of every byte is in place before the round of 64 that writes it (rounds run one after the
+                        // other: LDS operations of a wave keep their order); most matches are this one round
                         BL_LANES(lane)
                         {
                             if ((uint32_t)lane < len) sh.ring[(q + lane) & (WINDOW - 1)] = sh.ring[(from + lane) & (WINDOW - 1)];
-                            for (uint32_t i = (uint32_t)lane + 64u; i < len; i += 64) sh.ring[(q + i) & (WINDOW - 1)] = sh.ring[(from + i) & (WINDOW - 1)];
                         }
-                    } else {  // the match runs into itself: its first `dist` bytes repeat (dist < 258 here; 0 only on a wrong path)
-                        const uint32_t period = dist ? dist : 1u;
+                        for (uint32_t base = 64u; base < len; base += 64u) {
+                            BL_LANES(lane)
+                            {
+                                const uint32_t i = base + (uint32_t)lane;
+                                if (i < len) sh.ring[(q + i) & (WINDOW - 1)] = sh.ring[(from + i) & (WINDOW - 1)];
+                            }
+                        }
+                    } else if (dist <= 1u) {
+                        // a run of one byte (quality values, poly-A; dist is 0 only on a wrong path)
                         BL_LANES(lane)
                         {
-                            for (uint32_t i = (uint32_t)lane; i < len; i += 64) sh.ring[(q + i) & (WINDOW - 1)] = sh.ring[(from + i % period) & (WINDOW - 1)];
+                            const uint8_t v = sh.ring[from & (WINDOW - 1)];
+                            for (uint32_t i = (uint32_t)lane; i < len; i += 64) sh.ring[(q + i) & (WINDOW - 1)] = v;
+                        }
+                    } else {
+                        // the match runs into itself with a short period: its `dist` last bytes repeat.  Rounds of R = the largest
+                        // multiple of the period within 64 bytes: byte `lane` of every round is the same pattern byte, read once
+                        const uint32_t per_round = BL_UNI((uint32_t)(64.0f / (float)dist));  // exact: both small integers
+                        const uint32_t round = per_round * dist;
+                        BL_LANES(lane)
+                        {
+                            int m = (int)lane - (int)((uint32_t)((float)lane / (float)dist) * dist);  // lane % dist, up to a rounding step
+                            if (m < 0) m += (int)dist;
+                            if (m >= (int)dist) m -= (int)dist;
+                            const uint8_t pattern = sh.ring[(from + (uint32_t)m) & (WINDOW - 1)];
+                            if ((uint32_t)lane < round)
+                                for (uint32_t i = (uint32_t)lane; i < len; i += round) sh.ring[(q + i) & (WINDOW - 1)] = pattern;
                         }
                     }
                     BL_WAVE_SYNC();
