@@ -297,7 +297,7 @@ public:
         }
         const uint64_t left = direct_off_ < direct_size_ ? direct_size_ - direct_off_ : 0;
         const size_t n = want < left ? want : (size_t)left;
-        constexpr int PARTS = 4;
+        constexpr int PARTS = 4;  // (eight measured no faster)
         const size_t part = (n + PARTS - 1) / PARTS;
         bool ok[PARTS];
         std::thread helpers[PARTS];
@@ -767,7 +767,9 @@ private:
                     want = filled + LOOK;  // one record longer than all this: keep reading
                 }
                 if (direct) {  // an uncompressed file: the bytes go from the page cache straight into the span
-                    size_t step = filled > ((size_t)1 << 20) ? filled : (size_t)1 << 20;  // (doubling: a small file gets a small buffer)
+                    // doubling steps while the buffer is still growing (a small file gets a small buffer); once it has its full
+                    // size, everything that is missing in one (parallel) read
+                    size_t step = b->cap >= want ? want - filled : (filled > ((size_t)1 << 20) ? filled : (size_t)1 << 20);
                     if (step > want - filled) step = want - filled;
                     if (!grow(*b, filled, filled + step)) { verdict = -1; break; }
                     const long got = in_.source().read_direct(b->p + filled, step);

@@ -29,8 +29,11 @@ text = b"".join(b"@r%d\n" % i + seq[i].tobytes() + b"\n+\n" + b"I" * 150 + b"\n"
 with tempfile.TemporaryDirectory() as d:
     path = os.path.join(d, "r.bgzf.gz")
     open(path, "wb").write(bgzf(text))
+    plain = os.path.join(d, "r.fq")
+    open(plain, "wb").write(text)
     ctx = B.Context(0)
-    for scan in (False, True, True):
+    for what, scan in (("bgzf", False), ("bgzf", True), ("bgzf", True), ("plain", True), ("plain", True)):
+        path = plain if what == "plain" else os.path.join(d, "r.bgzf.gz")
         t0 = time.perf_counter(); nb = 0
         t_next = t_scan = t_close = 0.0
         r = B.Reader(path)
@@ -49,4 +52,4 @@ with tempfile.TemporaryDirectory() as d:
             t_close += time.perf_counter() - c_
         r.close()
         dt = time.perf_counter() - t0
-        print(f"scan={scan}: {nb / dt / 1e9:.2f} Gbp/s ({dt * 1e3:.0f} ms; next batch {t_next * 1e3:.0f}, scan {t_scan * 1e3:.0f}, close {t_close * 1e3:.0f} ms)", flush=True)
+        print(f"{what} scan={scan}: {nb / dt / 1e9:.2f} Gbp/s ({dt * 1e3:.0f} ms; next batch {t_next * 1e3:.0f}, scan {t_scan * 1e3:.0f}, close {t_close * 1e3:.0f} ms)", flush=True)
