@@ -588,7 +588,7 @@ BL_IDEV uint32_t inflate_member(Shared& sh, In& in, uint32_t n_in, uint8_t* out,
                         b.nb += 32;
                     }
                     uint32_t e = ll_regs.lookup(b.peek(LL_ROOT));
-                    if ((e & 15u) == 0) {  // rare: a code longer than the root
+                    if (__builtin_expect((e & 15u) == 0, 0)) {  // rare: a code longer than the root
                         const uint32_t f = decode_long(b, sh.ll_sorted, sh.ll);
                         e = f ? expand_ll(f >> 4, f & 15u) : (E_RESERVED | 1u);
                     }
@@ -596,10 +596,10 @@ BL_IDEV uint32_t inflate_member(Shared& sh, In& in, uint32_t n_in, uint8_t* out,
                     if (e & E_LITERAL) {
                         sh.ring[q & (WINDOW - 1)] = (uint8_t)(e >> 8);  // (the same store from every lane; one byte past the text's
                         ++q;                                             // end is caught at the bound before anything leaves the ring)
-                        if (q >= q_limit) break;
+                        if (__builtin_expect(q >= q_limit, 0)) break;
                         continue;
                     }
-                    if (e & (E_END | E_RESERVED)) {  // end of block, or a reserved symbol
+                    if (__builtin_expect((e & (E_END | E_RESERVED)) != 0, 0)) {  // end of block, or a reserved symbol
                         bad |= e & E_RESERVED;
                         block_done = true;
                         break;
@@ -610,7 +610,7 @@ BL_IDEV uint32_t inflate_member(Shared& sh, In& in, uint32_t n_in, uint8_t* out,
                         b.nb += 32;
                     }
                     uint32_t de = d_regs.lookup(b.peek(D_ROOT));
-                    if ((de & 15u) == 0) {
+                    if (__builtin_expect((de & 15u) == 0, 0)) {
                         const uint32_t f = decode_long(b, sh.d_sorted, sh.d);
                         de = f ? expand_d(f >> 4, f & 15u) : (E_RESERVED | 1u);
                     }
@@ -658,7 +658,7 @@ BL_IDEV uint32_t inflate_member(Shared& sh, In& in, uint32_t n_in, uint8_t* out,
                     BL_WAVE_SYNC();
                     q += len;
                     q_limit = (bad | in.over) ? 0u : q_stop;
-                    if (q >= q_limit) break;
+                    if (__builtin_expect(q >= q_limit, 0)) break;
                 }
                 // the bound, an error bit, or the end of the block
                 if (in.over) status = ERR_INPUT;
