@@ -140,8 +140,30 @@ std::vector<uint8_t> make_text(std::mt19937_64& rng, int kind, size_t n)
 
 }  // namespace
 
+static std::vector<uint8_t> read_file(const char* path)
+{
+    std::vector<uint8_t> v;
+    FILE* f = std::fopen(path, "rb");
+    if (!f) return v;
+    uint8_t buf[65536];
+    size_t n;
+    while ((n = std::fread(buf, 1, sizeof(buf), f)) > 0) v.insert(v.end(), buf, buf + n);
+    std::fclose(f);
+    return v;
+}
+
 int main(int argc, char** argv)
 {
+    // emu_inflate --check RAW_DEFLATE_FILE TEXT_FILE: streams from encoders other than zlib (tests/test_inflate.py feeds it what GNU
+    // gzip wrote); the text is at most 64 KiB, as in a BGZF member
+    if (argc == 4 && std::string(argv[1]) == "--check") {
+        const auto packed = read_file(argv[2]), text = read_file(argv[3]);
+        if (text.size() > 65536) return 2;
+        const Result r = ours(packed, (uint32_t)text.size(), 5);
+        const bool ok = r.status == bl_inflate::OK && r.text == text && !r.wrote_outside;
+        std::printf("%s status %u\n", ok ? "same" : "DIFFERENT", r.status);
+        return ok ? 0 : 1;
+    }
     const size_t n_sound = argc > 1 ? std::strtoul(argv[1], nullptr, 10) : 400;
     const size_t n_damaged = argc > 2 ? std::strtoul(argv[2], nullptr, 10) : 4000;
     std::mt19937_64 rng(12345);

@@ -40,6 +40,41 @@ def test_decoder_on_host_vs_zlib():
     assert out.returncode == 0 and "emu_inflate: OK" in out.stdout, out.stdout[-3000:] + out.stderr[-3000:]
 
 
+def _gnu_gzip_payload(chunk, level):
+    """raw deflate data as GNU gzip writes it (its own encoder, not zlib's: other block splits, other code lengths)"""
+    out = subprocess.run(["gzip", "-n", "-c", f"-{level}"], input=chunk, capture_output=True, check=True).stdout
+    assert out[:3] == b"\x1f\x8b\x08" and out[3] == 0  # 10-byte header, no optional fields
+    return out[10:-8]
+
+
+def bgzf_from_gnu_gzip(data, level, block=65280):
+    out = bytearray()
+    for a in range(0, len(data), block):
+        chunk = data[a:a + block]
+        body = _gnu_gzip_payload(chunk, level)
+        if 12 + 6 + len(body) + 8 > 65536:  # would not fit a BGZF member: store it
+            z = zlib.compressobj(0, zlib.DEFLATED, -15)
+            body = z.compress(chunk) + z.flush()
+        out += b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, 12 + 6 + len(body) + 8 - 1)
+        out += body + struct.pack("<II", zlib.crc32(chunk) & 0xFFFFFFFF, len(chunk))
+    return bytes(out)
+
+
+def test_decoder_on_host_vs_gnu_gzip(tmp_path):
+    """streams from a second encoder (GNU gzip, levels 1 / 6 / 9) through the host build of the decoder"""
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "emu")])
+    exe = os.path.join(ROOT, "tests", "emu", "_build", "emu_inflate")
+    rng = np.random.default_rng(4)
+    texts = [fastq_text(400, seed=2)[:65000], rng.integers(0, 4, 60000, dtype=np.uint8).tobytes(), bytes(rng.integers(0, 256, 3000, dtype=np.uint8)) * 20,
+             b"A" * 65536, b"", b"x", open(os.path.join(ROOT, "SURVEY.md"), "rb").read()[:60000]]
+    for i, text in enumerate(texts):
+        for level in (1, 6, 9):
+            (tmp_path / "t.bin").write_bytes(text)
+            (tmp_path / "p.bin").write_bytes(_gnu_gzip_payload(text, level))
+            out = subprocess.run([exe, "--check", str(tmp_path / "p.bin"), str(tmp_path / "t.bin")], capture_output=True, text=True)
+            assert out.returncode == 0, (i, level, out.stdout)
+
+
 def test_member_walk():
     import ctypes as C
 
@@ -82,6 +117,9 @@ def test_device_inflate_vs_zlib():
     runs = b"".join(bytes([65 + int(rng.integers(0, 4))]) * int(rng.integers(1, 4000)) for _ in range(800))
     noise = rng.integers(0, 256, 300_000, dtype=np.uint8).tobytes()
     skew = rng.choice(np.arange(256, dtype=np.uint8), 500_000, p=np.r_[[0.6, 0.25, 0.1], np.full(253, 0.05 / 253)]).tobytes()
+    for level in (1, 6, 9):  # a second encoder: GNU gzip
+        got, status = ctx.bgzf_inflate(bgzf_from_gnu_gzip(fq[:3_000_000] + skew[:200_000], level))
+        assert not status.any() and got.tobytes() == fq[:3_000_000] + skew[:200_000], level
     cases = [(fq, 1, zlib.Z_DEFAULT_STRATEGY, 65280), (fq, 6, zlib.Z_DEFAULT_STRATEGY, 65280), (fq, 9, zlib.Z_DEFAULT_STRATEGY, 65536), (fq, 6, zlib.Z_FIXED, 4096),
              (fq[:300_000], 0, zlib.Z_DEFAULT_STRATEGY, 65280), (runs, 6, zlib.Z_DEFAULT_STRATEGY, 65280), (runs, 6, zlib.Z_RLE, 30000),
              (noise, 6, zlib.Z_DEFAULT_STRATEGY, 65280), (skew, 9, zlib.Z_DEFAULT_STRATEGY, 65280), (skew, 6, zlib.Z_HUFFMAN_ONLY, 65280),
