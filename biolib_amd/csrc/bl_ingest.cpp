@@ -481,6 +481,7 @@ struct Record {
 class RecordParser {
 public:
     explicit RecordParser(ByteSource& s) : in_(s) {}
+    void abandon() { in_.abandon(); }  // the consumer is leaving: a parser waiting for bytes sees the end of the stream
 
     Step next(Record& r)
     {
@@ -979,6 +980,131 @@ private:
 
 }  // namespace
 
+// Batches of whole records for bl_reader_next_batch, assembled one batch AHEAD of the caller by a thread of the reader: while
+// the caller uploads, scans or walks batch i (include/compat/read_pool.hpp walks it k-mer by k-mer), batch i + 1 is being parsed.
+struct HostBatch {
+    std::string bases;
+    std::vector<uint64_t> offsets;
+    std::vector<std::string> names;
+    Step end = Step::Record;  // Record: a batch; End: nothing left; Malformed / Broken: the file failed here
+    int state = 0;            // 0 free, 1 ready, 2 held by the caller
+};
+
+class RecordBatcher {
+public:
+    RecordBatcher(ByteSource& src, uint64_t max_bases) : parser_(src), max_bases_(max_bases) { worker_ = std::thread([this] { produce(); }); }
+    ~RecordBatcher()
+    {
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            quit_ = true;
+        }
+        cv_.notify_all();
+        parser_source_abandon();
+        if (worker_.joinable()) worker_.join();
+    }
+    uint64_t max_bases() const { return max_bases_; }
+    // the next batch (valid until the following call); its `end` says whether it is one
+    HostBatch* next()
+    {
+        std::unique_lock<std::mutex> lk(m_);
+        if (held_ >= 0) {
+            slot_[held_].state = 0;
+            held_ = -1;
+            cv_.notify_all();
+        }
+        if (last_) return last_;
+        HostBatch& b = slot_[take_];
+        cv_.wait(lk, [&] { return b.state == 1; });
+        if (b.end != Step::Record) {
+            last_ = &b;  // the end (or the failure) stays the answer
+            return last_;
+        }
+        b.state = 2;
+        held_ = take_;
+        take_ ^= 1;
+        return &b;
+    }
+
+private:
+    void parser_source_abandon() { parser_.abandon(); }
+    void produce()
+    {
+        int put = 0;
+        bool have_pending = false;
+        Record rec;
+        for (;;) {
+            HostBatch* b;
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                b = &slot_[put];
+                cv_.wait(lk, [&] { return quit_ || b->state == 0; });
+                if (quit_) return;
+            }
+            b->bases.clear();
+            b->offsets.assign(1, 0);
+            b->names.clear();
+            b->end = Step::Record;
+            if (max_bases_ && max_bases_ <= ((uint64_t)1 << 30) && b->bases.capacity() < max_bases_) b->bases.reserve((size_t)max_bases_);  // (no regrowth copies)
+            for (;;) {
+                if (!have_pending) {
+                    const Step st = parser_.next(rec);
+                    if (st != Step::Record) {
+                        if (b->names.empty() || st != Step::End) b->end = st;  // (records in front of a clean end are a last batch)
+                        else end_after_ = true;
+                        break;
+                    }
+                }
+                have_pending = false;
+                if (!b->names.empty() && max_bases_ && b->bases.size() + rec.seq.size() > max_bases_) {
+                    have_pending = true;  // the record opens the next batch
+                    break;
+                }
+                b->bases += rec.seq;
+                b->offsets.push_back(b->bases.size());
+                b->names.push_back(rec.name);
+            }
+            const bool stop = b->end != Step::Record;
+            {
+                std::lock_guard<std::mutex> lk(m_);
+                b->state = 1;
+            }
+            cv_.notify_all();
+            if (stop) return;
+            put ^= 1;
+            if (end_after_) {  // the file ended behind that batch: the next answer is "nothing left"
+                HostBatch* e;
+                {
+                    std::unique_lock<std::mutex> lk(m_);
+                    e = &slot_[put];
+                    cv_.wait(lk, [&] { return quit_ || e->state == 0; });
+                    if (quit_) return;
+                }
+                e->bases.clear();
+                e->offsets.assign(1, 0);
+                e->names.clear();
+                e->end = Step::End;
+                {
+                    std::lock_guard<std::mutex> lk(m_);
+                    e->state = 1;
+                }
+                cv_.notify_all();
+                return;
+            }
+        }
+    }
+
+    RecordParser parser_;
+    const uint64_t max_bases_;
+    HostBatch slot_[2];
+    std::mutex m_;
+    std::condition_variable cv_;
+    std::thread worker_;
+    int take_ = 0, held_ = -1;
+    HostBatch* last_ = nullptr;
+    bool quit_ = false, end_after_ = false;
+};
+
 // Device side of the compressed path: the members of a span are inflated into `text[cur]` behind the bytes the previous span
 // left over (the part of its last record that was not complete yet), the text is cut at its last record boundary, parsed there,
 // and what lies behind the cut moves to the front of the other buffer.
@@ -1038,6 +1164,8 @@ struct bl_reader {
     char shard_first_byte = 0;  // first byte of the FILE's text: tells FASTQ from FASTA to a part that does not begin with a record
     std::unique_ptr<DeviceBgzf> packed;
     std::unique_ptr<ByteSource> source;
+    std::unique_ptr<RecordBatcher> batcher;  // bl_reader_next_batch: batches parsed one ahead
+    HostBatch* batch = nullptr;              // the one handed out last
     std::unique_ptr<RecordParser> records;
     std::unique_ptr<TextCutter> text;
     Record rec;
@@ -1183,6 +1311,7 @@ int bl_reader_shard_range(bl_reader* r, uint64_t* first_byte, uint64_t* end_byte
 int bl_reader_close(bl_reader* r)
 {
     if (!r) return BL_OK;
+    r->batcher.reset();
     r->records.reset();
     r->text.reset();
     r->packed.reset();
@@ -1198,6 +1327,7 @@ int bl_reader_next_record(bl_reader* r, const char** name, const char** seq, uin
     if (!r || !seq_len) return bl_set_error(BL_ERR_INVALID, "NULL argument");
     if (r->sharded) return bl_set_error(BL_ERR_INVALID, "a reader of one part of a file delivers device batches only");
     if (r->text || r->packed) return bl_set_error(BL_ERR_INVALID, "this reader is delivering text spans: records and spans cannot be mixed");
+    if (r->batcher) return bl_set_error(BL_ERR_INVALID, "this reader is delivering batches: records and batches cannot be mixed");
     if (!r->records) r->records.reset(new RecordParser(*r->source));
     const Step s = r->records->next(r->rec);
     if (s == Step::End) {
@@ -1219,29 +1349,16 @@ int bl_reader_next_batch(bl_ctx* ctx, bl_reader* r, uint64_t max_bases, bl_batch
     if (r->sharded) return bl_set_error(BL_ERR_INVALID, "a reader of one part of a file delivers device batches only");
     *out = nullptr;
     if (r->text || r->packed) return bl_set_error(BL_ERR_INVALID, "this reader is delivering text spans: records and spans cannot be mixed");
-    if (!r->records) r->records.reset(new RecordParser(*r->source));
-    r->bases.clear();
-    r->offsets.assign(1, 0);
-    r->names.clear();
-    for (;;) {
-        if (!r->have_pending) {
-            const Step s = r->records->next(r->rec);
-            if (s == Step::End) break;
-            if (s != Step::Record) return step_error(s);
-        }
-        r->have_pending = false;
-        if (!r->names.empty() && max_bases && r->bases.size() + r->rec.seq.size() > max_bases) {
-            r->have_pending = true;  // keep the parsed record for the next batch
-            break;
-        }
-        r->bases += r->rec.seq;
-        r->offsets.push_back(r->bases.size());
-        r->names.push_back(r->rec.name);
-    }
-    if (n_seqs) *n_seqs = r->names.size();
-    if (n_bases) *n_bases = r->bases.size();
-    if (r->names.empty()) return BL_OK;  // end of file: *out stays NULL
-    return bl_batch_upload(ctx, r->bases.data(), r->bases.size(), r->offsets.data(), r->names.size(), out);
+    if (r->records) return bl_set_error(BL_ERR_INVALID, "this reader is delivering single records: records and batches cannot be mixed");
+    if (!r->batcher) r->batcher.reset(new RecordBatcher(*r->source, max_bases));
+    if (r->batcher->max_bases() != max_bases) return bl_set_error(BL_ERR_INVALID, "the batch size of a reader is fixed by its first batch call");
+    r->batch = r->batcher->next();
+    const HostBatch& b = *r->batch;
+    if (b.end == Step::Malformed || b.end == Step::Broken) return step_error(b.end);
+    if (n_seqs) *n_seqs = b.names.size();
+    if (n_bases) *n_bases = b.bases.size();
+    if (b.end == Step::End || b.names.empty()) return BL_OK;  // end of file: *out stays NULL
+    return bl_batch_upload(ctx, b.bases.data(), b.bases.size(), b.offsets.data(), b.names.size(), out);
 }
 
 namespace {
@@ -1257,7 +1374,7 @@ const SpanMemory PINNED_MEMORY = {[](size_t n) {
 int next_span(bl_reader* r, uint64_t max_bytes, const SpanMemory& mem, const char** text, uint64_t* n_bytes)
 {
     if (r->sharded) return bl_set_error(BL_ERR_INVALID, "a reader of one part of a file delivers device batches only");
-    if (r->records || r->packed) return bl_set_error(BL_ERR_INVALID, "this reader is delivering records: records and spans cannot be mixed");
+    if (r->records || r->packed || r->batcher) return bl_set_error(BL_ERR_INVALID, "this reader is delivering records: records and spans cannot be mixed");
     const size_t limit = max_bytes ? (size_t)max_bytes : (size_t)64 << 20;
     if (!r->text) r->text.reset(new TextCutter(*r->source, limit, mem));
     if (r->text->limit() != limit) return bl_set_error(BL_ERR_INVALID, "the span size of a reader is fixed by its first span call");
@@ -1543,12 +1660,14 @@ int bl_reader_next_batch_device(bl_ctx* ctx, bl_reader* r, uint64_t max_text_byt
 int bl_reader_last_batch(bl_reader* r, const char** bases, const uint64_t** offsets, uint64_t* n_seqs)
 {
     if (!r) return bl_set_error(BL_ERR_INVALID, "NULL argument");
-    if (bases) *bases = r->bases.data();
-    if (offsets) *offsets = r->offsets.data();
-    if (n_seqs) *n_seqs = r->names.size();
+    static const uint64_t zero = 0;
+    const HostBatch* b = r->batch;
+    if (bases) *bases = b ? b->bases.data() : "";
+    if (offsets) *offsets = b && !b->offsets.empty() ? b->offsets.data() : &zero;
+    if (n_seqs) *n_seqs = b ? b->names.size() : 0;
     return BL_OK;
 }
 
-const char* bl_reader_last_name(bl_reader* r, uint64_t i) { return (r && i < r->names.size()) ? r->names[i].c_str() : nullptr; }
+const char* bl_reader_last_name(bl_reader* r, uint64_t i) { return (r && r->batch && i < r->batch->names.size()) ? r->batch->names[i].c_str() : nullptr; }
 
 }  // extern "C"

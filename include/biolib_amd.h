@@ -199,7 +199,9 @@ const char* bl_reader_kind(bl_reader* reader);
 /* Host only: next record.  Returns BL_OK, 1 at end of file, or an error.  Pointers stay valid until the next call. */
 int bl_reader_next_record(bl_reader* reader, const char** name, const char** seq, uint64_t* seq_len);
 /* Next batch of whole records holding at most max_bases bases (0 = the rest of the file; always at least one
- * record), uploaded to the device.  At end of file *out is NULL and *n_seqs is 0. */
+ * record), uploaded to the device.  At end of file *out is NULL and *n_seqs is 0.  A thread of the reader parses the following
+ * batch meanwhile; max_bases is fixed by the first call (BL_ERR_INVALID if a later call differs), and single records
+ * (bl_reader_next_record) cannot be mixed with batches on one reader. */
 int bl_reader_next_batch(bl_ctx* ctx, bl_reader* reader, uint64_t max_bases, bl_batch** out, uint64_t* n_seqs, uint64_t* n_bases);
 /* The high-throughput path for regular files: the decompressed TEXT, cut at record boundaries (4-line FASTQ: in front of a header
  * line, recognised by the '+' line two lines on; FASTA: before a line-initial '>'), goes to the device-side parser

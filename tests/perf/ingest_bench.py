@@ -41,7 +41,7 @@ with tempfile.TemporaryDirectory() as d:
         for mode in ("host_records", "device_parser"):
             t0 = time.perf_counter(); nb = 0; cnt = 0
             r = B.Reader(p, threads=threads)
-            it = (b for b, _, _ in r.batches(ctx, 256_000_000, names=False)) if mode == "host_records" else r.device_batches(ctx, 64 << 20)
+            it = (b for b, _, _ in r.batches(ctx, 64_000_000, names=False)) if mode == "host_records" else r.device_batches(ctx, 64 << 20)
             for batch in it:
                 nb += batch.n_bases
                 cnt += batch.minimizers_raw(31, 11, 42, B.FLAG_CANONICAL | B.FLAG_SYNC).count
