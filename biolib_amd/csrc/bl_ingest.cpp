@@ -1483,8 +1483,9 @@ int launch_packed(DeviceBgzf& d, int buf, size_t offset)
 }
 
 // One batch from the compressed path (*out NULL at the end of the file).  The span after the one returned is uploaded and
-// inflated on the reader's own stream before this call parses its text, so that it overlaps the parse and whatever the caller
-// does with the batch (the inflate kernel leaves most of every CU's issue slots free: one wave per SIMD).
+// inflated on the reader's own stream before this call parses its text: the upload, the launch and the host's part overlap the
+// parse and whatever the caller does with the batch.  (The kernels themselves take turns: four members per CU hold all of its
+// LDS, so a scan queued behind a span's inflate starts when that has drained — tests/perf/ingest_trace.py.)
 int next_batch_packed(bl_ctx* ctx, bl_reader* r, bl_batch** out, uint64_t* n_seqs, uint64_t* n_bases)
 {
     DeviceBgzf& d = *r->packed;
