@@ -574,6 +574,16 @@ BL_IDEV uint32_t inflate_member(Shared& sh, In& in, uint32_t n_in, uint8_t* out,
             // wrong is gathered in `bad` / `in.over` and looked at together with the one bound on q, and a wrong path only ever
             // touches the ring (whose index is masked) before it is noticed.
             uint32_t bad = 0;
+            // a match of one round whose bytes have been read and not yet written (one byte per lane)
+#ifdef BL_INFLATE_EMU
+            uint8_t pend_v[64] = {0};
+#define BL_LANE_SLOT(l) (l)
+#else
+            uint8_t pend_v[1] = {0};
+#define BL_LANE_SLOT(l) 0
+#endif
+            bool pend_on = false;
+            uint32_t pend_q = 0, pend_len = 0;
             // Two loops: the inner one decodes symbols and changes nothing but the bit buffer, q and the error bits, so that the
             // bound, the flush positions and the status are constants to it (as one loop, every symbol paid a dozen register
             // copies for the rare path that moves them); it is left at the bound (or on an error bit) and at the end of the block.
@@ -617,11 +627,27 @@ BL_IDEV uint32_t inflate_member(Shared& sh, In& in, uint32_t n_in, uint8_t* out,
                     b.drop((int)(de & 15u));
                     const uint32_t dist = ((de >> 8) & 0x7fffu) + b.take((int)((de >> 4) & 15u));
                     bad |= (de & E_RESERVED) | (uint32_t)(dist > q - shift);
-                    BL_WAVE_SYNC();  // the literals written since the last match are in the ring
+                    // the previous match's bytes go into the ring now (see below), then the literals written since are in place
+                    BL_LANES(lane)
+                    {
+                        if (pend_on && (uint32_t)lane < pend_len) sh.ring[(pend_q + lane) & (WINDOW - 1)] = pend_v[BL_LANE_SLOT(lane)];
+                    }
+                    pend_on = false;
+                    BL_WAVE_SYNC();
                     const uint32_t from = q - dist;
-                    if (dist >= len || dist >= 64u) {
+                    if (dist >= len && len <= 64u) {
+                        // one round: the bytes are READ now and WRITTEN when the next match (or the end of the run of symbols)
+                        // needs them in place — the symbols decoded meanwhile hide the LDS round trip
+                        BL_LANES(lane)
+                        {
+                            pend_v[BL_LANE_SLOT(lane)] = sh.ring[(from + lane) & (WINDOW - 1)];
+                        }
+                        pend_on = true;
+                        pend_q = q;
+                        pend_len = len;
+                    } else if (dist >= len || dist >= 64u) {
                         // the source of every byte is in place before the round of 64 that writes it (rounds run one after the
-                        // other: LDS operations of a wave keep their order); most matches are this one round
+                        // other: LDS operations of a wave keep their order)
                         BL_LANES(lane)
                         {
                             if ((uint32_t)lane < len) sh.ring[(q + lane) & (WINDOW - 1)] = sh.ring[(from + lane) & (WINDOW - 1)];
@@ -660,7 +686,12 @@ BL_IDEV uint32_t inflate_member(Shared& sh, In& in, uint32_t n_in, uint8_t* out,
                     q_limit = (bad | in.over) ? 0u : q_stop;
                     if (__builtin_expect(q >= q_limit, 0)) break;
                 }
-                // the bound, an error bit, or the end of the block
+                // the bound, an error bit, or the end of the block: the ring is brought up to date first
+                BL_LANES(lane)
+                {
+                    if (pend_on && (uint32_t)lane < pend_len) sh.ring[(pend_q + lane) & (WINDOW - 1)] = pend_v[BL_LANE_SLOT(lane)];
+                }
+                pend_on = false;
                 if (in.over) status = ERR_INPUT;
                 else if (bad) status = (bad & E_RESERVED) ? ERR_SYMBOL : ERR_DISTANCE;
                 else if (q > q_end) status = ERR_OVERRUN;
@@ -679,6 +710,7 @@ BL_IDEV uint32_t inflate_member(Shared& sh, In& in, uint32_t n_in, uint8_t* out,
         if (last) break;
     }
 #undef BL_NEED32
+#undef BL_LANE_SLOT
     BL_WAVE_SYNC();
     if (q > q_end) q = q_end;  // (a literal one past the end was refused above; it stays in the ring)
     if (q > flushed) flush_range(sh, g, flushed, q);  // what a damaged stream produced before it failed is within [0, isize) too

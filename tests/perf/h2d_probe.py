@@ -1,3 +1,4 @@
+"""Host <-> device copy rates of this box (page-locked and pageable): what the ingest paths can hope for per byte they move."""
 import torch, time
 x = torch.empty(256<<20, dtype=torch.uint8).pin_memory()
 y = torch.empty(256<<20, dtype=torch.uint8, device="cuda")
