@@ -309,6 +309,83 @@ BL_IDEV uint32_t reverse_bits(uint32_t v, int n)  // the low n bits of v, revers
 // Build the decoder of one code from lens[0 .. n): `table` answers codes of at most `root` bits, `sorted` + `ct` the longer
 // ones.  Returns false for an over-subscribed set and for an incomplete one — except, when `lone_code_ok`, a set of one 1-bit
 // code or of no code at all (what zlib lets through for the literal/length and distance codes, not for the code-length code).
+#ifndef BL_INFLATE_EMU
+// The same on the device with one symbol per lane and register (up to 320 symbols = 5 registers): lengths are counted and the
+// symbols of a length ranked with ballots, 75 of each, instead of two walks over the symbols in which every lane did the same
+// thing 340 times.  (The host build keeps the walk: it is what the emulation tests check the tables against on the GPU, where
+// tests/test_inflate.py sends thousands of different code sets through this version.)
+__device__ __forceinline__ bool build_code(Shared& sh, const uint8_t* lens, int n, int root, uint16_t* table, uint16_t* sorted, CodeTable& ct, bool lone_code_ok)
+{
+    const int lane = (int)(threadIdx.x & 63u);
+    for (int i = lane; i < (1 << root); i += 64) table[i] = 0;
+    uint32_t my_len[5];
+#pragma unroll
+    for (int r = 0; r < 5; ++r) {
+        const int s = r * 64 + lane;
+        my_len[r] = s < n ? (uint32_t)(lens[s] & 15) : 0u;
+    }
+    uint32_t cnt[16];
+    cnt[0] = 0;
+#pragma unroll
+    for (int k = 1; k < 16; ++k) {
+        uint32_t c = 0;
+#pragma unroll
+        for (int r = 0; r < 5; ++r) c += (uint32_t)__popcll(__ballot(my_len[r] == (uint32_t)k));
+        cnt[k] = c;
+    }
+    int left = 1, longest = 0;
+    uint32_t first = 0, at = 0;  // canonical code / slot among the sorted symbols where each length starts
+    uint32_t first_of[16], slot_of[16];
+#pragma unroll
+    for (int l = 1; l < 16; ++l) {
+        left = (left << 1) - (int)cnt[l];
+        if (left < 0) return false;  // over-subscribed
+        if (cnt[l]) longest = l;
+        first_of[l] = first;
+        slot_of[l] = at;
+        first = (first + cnt[l]) << 1;
+        at += cnt[l];
+    }
+    if (left > 0 && !(lone_code_ok && (at == 0 || (longest == 1 && at == 1)))) return false;  // incomplete
+    if (lane < 16) {
+        uint32_t c = 0;
+#pragma unroll
+        for (int l = 1; l < 16; ++l)
+            if (l == lane) c = cnt[l];
+        ct.count[lane] = c;
+    }
+    // the k-th symbol of a length (in symbol order: register by register, lane by lane) gets that length's k-th code and slot
+    const unsigned long long below = (1ull << lane) - 1ull;
+    uint32_t my_code[5] = {0, 0, 0, 0, 0};
+#pragma unroll
+    for (int k = 1; k < 16; ++k) {
+        uint32_t run = 0;
+#pragma unroll
+        for (int r = 0; r < 5; ++r) {
+            const unsigned long long mask = __ballot(my_len[r] == (uint32_t)k);
+            if (my_len[r] == (uint32_t)k) {
+                const uint32_t rank = run + (uint32_t)__popcll(mask & below);
+                sorted[slot_of[k] + rank] = (uint16_t)(r * 64 + lane);
+                my_code[r] = first_of[k] + rank;
+            }
+            run += (uint32_t)__popcll(mask);
+        }
+    }
+    BL_WAVE_SYNC();  // (the cleared table is in place)
+    // every symbol of at most `root` bits fills the table entries whose low bits are its (bit-reversed) code
+#pragma unroll
+    for (int r = 0; r < 5; ++r) {
+        const uint32_t l = my_len[r];
+        if (l && l <= (uint32_t)root) {
+            const uint32_t rev = reverse_bits(my_code[r], (int)l);
+            const uint16_t e = (uint16_t)(((r * 64 + lane) << 4) | (int)l);
+            for (uint32_t j = rev; j < (1u << root); j += (1u << l)) table[j] = e;
+        }
+    }
+    BL_WAVE_SYNC();
+    return true;
+}
+#else
 BL_IDEV bool build_code(Shared& sh, const uint8_t* lens, int n, int root, uint16_t* table, uint16_t* sorted, CodeTable& ct, bool lone_code_ok)
 {
     BL_LANES(lane)
@@ -382,6 +459,8 @@ BL_IDEV bool build_code(Shared& sh, const uint8_t* lens, int n, int root, uint16
     BL_WAVE_SYNC();
     return true;
 }
+
+#endif
 
 // A code longer than its table's root (or bits that are no code at all): walk the canonical code one bit at a time.
 // Returns (symbol << 4) | code length without dropping the bits, or 0 when the bits are no code.  (One loop with one exit, not

@@ -134,6 +134,46 @@ def test_device_inflate_vs_zlib():
 
 
 @pytest.mark.gpu
+def test_device_inflate_many_code_sets():
+    """3,000 members, each with a text of its own kind and size and therefore code sets of its own (alphabets from 1 to 256
+    symbols, flat and steep distributions, runs, far and near repeats; zlib levels 1-9, fixed / Huffman-only / RLE strategies):
+    the device builds every table with ballots over one symbol per lane, the host build of the decoder by walking the symbols"""
+    import biolib_amd
+
+    ctx = biolib_amd.Context(0)
+    rng = np.random.default_rng(77)
+    texts, data = [], bytearray()
+    strategies = [zlib.Z_DEFAULT_STRATEGY, zlib.Z_FILTERED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE, zlib.Z_FIXED]
+    for i in range(3000):
+        n = int(rng.integers(1, 9000))
+        kind = i % 6
+        if kind == 0:
+            k = int(rng.integers(1, 257))
+            t = rng.integers(0, k, n, dtype=np.uint8)
+        elif kind == 1:  # steep: a few common symbols and a long tail (long codes)
+            k = int(rng.integers(2, 257))
+            p = 1.0 / np.arange(1, k + 1) ** float(rng.uniform(0.5, 3.0))
+            t = rng.choice(np.arange(k, dtype=np.uint8), n, p=p / p.sum())
+        elif kind == 2:
+            t = np.repeat(rng.integers(0, 256, n // 7 + 1, dtype=np.uint8), rng.integers(1, 15, n // 7 + 1))[:n]
+        elif kind == 3:
+            base = rng.integers(0, 256, int(rng.integers(1, 300)), dtype=np.uint8)
+            t = np.tile(base, n // len(base) + 1)[:n].copy()
+            t[rng.integers(0, n, n // 50 + 1)] ^= 1
+        elif kind == 4:
+            t = np.frombuffer(fastq_text(40, seed=i)[:n], np.uint8)
+        else:
+            t = rng.integers(0, 4, n, dtype=np.uint8) + 65
+        text = t.tobytes()
+        texts.append(text)
+        data += bgzf(text, int(rng.integers(1, 10)), strategies[int(rng.integers(0, 5))], block=65536, eof=False)
+    got, status = ctx.bgzf_inflate(bytes(data))
+    assert len(status) == len(texts) and not status.any(), np.nonzero(status)[0][:10]
+    assert got.tobytes() == b"".join(texts)
+    ctx.close()
+
+
+@pytest.mark.gpu
 def test_device_inflate_damaged_members():
     """bit flips, garbage and wrong trailers inside some members: exactly those members report an error (their CRC-32 or size no
     longer fits, or their deflate data is no stream), the others are inflated as if nothing had happened, and the call returns"""
