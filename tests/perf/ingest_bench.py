@@ -26,14 +26,20 @@ def bgzf(data, block=65280):
 
 n_reads = int(sys.argv[1]) if len(sys.argv) > 1 else 4_000_000
 threads = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+repeat = int(sys.argv[3]) if len(sys.argv) > 3 else 4  # the files hold the reads this many times over (records, gzip and BGZF members
+                                                        # all concatenate): a few GB, so that the readers' start-up does not dominate
 seq = O.synth(42, n_reads * 150).reshape(n_reads, 150)
-res = {"workload": f"{n_reads} reads x 150 bp FASTQ ({n_reads * 150 / 1e6:.0f} Mbp)", "inflate_threads": threads or "one per core (max 16)", "Gbp_per_s": {}}
+res = {"workload": f"{n_reads * repeat} reads x 150 bp FASTQ ({n_reads * repeat * 150 / 1e6:.0f} Mbp: {n_reads} reads, {repeat} times over)",
+       "inflate_threads": threads or "one per core (max 16)", "Gbp_per_s": {}}
 with tempfile.TemporaryDirectory() as d:
     text = b"".join(b"@r%d\n" % i + seq[i].tobytes() + b"\n+\n" + b"I" * 150 + b"\n" for i in range(n_reads))
     files = {"plain": os.path.join(d, "r.fq"), "gzip": os.path.join(d, "r.fq.gz"), "bgzf": os.path.join(d, "r.bgzf.gz")}
-    open(files["plain"], "wb").write(text)
-    open(files["gzip"], "wb").write(gzip.compress(text, 1))
-    open(files["bgzf"], "wb").write(bgzf(text))
+    with open(files["plain"], "wb") as f:
+        for _ in range(repeat):
+            f.write(text)
+    open(files["gzip"], "wb").write(gzip.compress(text, 1) * repeat)
+    packed = bgzf(text)
+    open(files["bgzf"], "wb").write(packed[:-28] * repeat + packed[-28:])  # (one end-of-file marker, at the end)
     res["file_MB"] = {k: round(os.path.getsize(v) / 1e6) for k, v in files.items()}
     ctx = B.Context(0)
     want = None
@@ -47,7 +53,7 @@ with tempfile.TemporaryDirectory() as d:
                 cnt += batch.minimizers_raw(31, 11, 42, B.FLAG_CANONICAL | B.FLAG_SYNC).count
                 batch.close()
             dt = time.perf_counter() - t0
-            assert nb == n_reads * 150
+            assert nb == n_reads * repeat * 150
             want = cnt if want is None else want
             assert cnt == want
             res["Gbp_per_s"][f"{form}/{mode}"] = round(nb / dt / 1e9, 3)

@@ -24,13 +24,18 @@ def bgzf(data, level=1, block=65280):
 
 n_reads = int(sys.argv[1]) if len(sys.argv) > 1 else 4_000_000
 span = (int(sys.argv[2]) if len(sys.argv) > 2 else 64) << 20
+repeat = int(sys.argv[3]) if len(sys.argv) > 3 else 1  # the file holds the reads this many times over (BGZF members and FASTQ records concatenate)
 seq = O.synth(42, n_reads * 150).reshape(n_reads, 150)
 text = b"".join(b"@r%d\n" % i + seq[i].tobytes() + b"\n+\n" + b"I" * 150 + b"\n" for i in range(n_reads))
 with tempfile.TemporaryDirectory() as d:
     path = os.path.join(d, "r.bgzf.gz")
-    open(path, "wb").write(bgzf(text))
+    packed = bgzf(text)
+    eof_marker = 28
+    open(path, "wb").write(packed[:-eof_marker] * repeat + packed[-eof_marker:])
     plain = os.path.join(d, "r.fq")
-    open(plain, "wb").write(text)
+    with open(plain, "wb") as f:
+        for _ in range(repeat):
+            f.write(text)
     ctx = B.Context(0)
     for what, scan in (("bgzf", False), ("bgzf", True), ("bgzf", True), ("plain", True), ("plain", True)):
         path = plain if what == "plain" else os.path.join(d, "r.bgzf.gz")
