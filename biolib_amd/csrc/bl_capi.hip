@@ -338,7 +338,7 @@ hipStream_t bl_ctx_stream(bl_ctx* c)
     if (c->n_lanes == 2 && c->lanes[1].scan_recorded) (void)hipStreamWaitEvent(c->lanes[0].own, c->lanes[1].ev_stop, 0);
     return c->lanes[0].own;
 }
-int bl_batch_adopt_device(bl_ctx* ctx, void* d_bases, uint64_t n_bases, uint64_t* d_offsets, uint64_t n_seqs, bl_batch** out);
+int bl_batch_adopt_device(bl_ctx* ctx, void* d_bases, uint64_t n_bases, uint64_t* d_offsets, uint64_t n_seqs, uint64_t fixed_len, bl_batch** out);
 int bl_ctx_device(bl_ctx* c) { return c->device; }
 
 // Device scratch that lives with the context (slot 0..7), grown on demand and never shrunk: the set operations and the
@@ -667,8 +667,9 @@ int bl_batch_synth(bl_ctx* c, uint64_t seed, uint64_t n_bases, uint64_t read_len
 }  // extern "C"
 
 // Used by the device-side text parser (bl_parse.hip): take ownership of a device base buffer (>= n_bases + 64 bytes,
-// zero padded) and of DEVICE offsets[n_seqs + 1]; builds the start bits and frees the offsets.
-int bl_batch_adopt_device(bl_ctx* c, void* d_bases, uint64_t n_bases, uint64_t* d_offsets, uint64_t n_seqs, bl_batch** out)
+// zero padded) and of DEVICE offsets[n_seqs + 1]; builds the start bits and frees the offsets.  fixed_len != 0: the parser
+// found every sequence that long (the usual short-read file): the batch is a fixed-length one — read-tiled scans, no start bits.
+int bl_batch_adopt_device(bl_ctx* c, void* d_bases, uint64_t n_bases, uint64_t* d_offsets, uint64_t n_seqs, uint64_t fixed_len, bl_batch** out)
 {
     bl_batch* b = nullptr;
     int rc = new_batch(c, n_bases, out, b);
@@ -676,6 +677,12 @@ int bl_batch_adopt_device(bl_ctx* c, void* d_bases, uint64_t n_bases, uint64_t* 
     b->bases = static_cast<uint8_t*>(d_bases);
     b->owns_bases = true;
     b->n_seqs = n_seqs;
+    if (fixed_len && n_seqs > 1 && fixed_len < n_bases) {
+        b->read_len = fixed_len;
+        bl_ctx_pool_free(c, d_offsets);
+        *out = b;
+        return BL_OK;
+    }
     hipStream_t s = bl_ctx_stream(c);
     const uint64_t n_words = (n_bases + 31) / 32 + 4;
     b->start_bits = static_cast<uint32_t*>(bl_ctx_pool_alloc(c, n_words * sizeof(uint32_t)));

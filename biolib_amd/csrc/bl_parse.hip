@@ -17,7 +17,8 @@ extern int bl_ctx_device(bl_ctx* ctx);
 extern void* bl_ctx_scratch(bl_ctx* ctx, int slot, size_t bytes);  // bl_capi.hip: grow-only device scratch that lives with the context
 extern void* bl_ctx_pool_alloc(bl_ctx* ctx, size_t bytes);          // bl_capi.hip: batch buffers, recycled between batches
 extern void bl_ctx_pool_free(bl_ctx* ctx, void* p);
-extern int bl_batch_adopt_device(bl_ctx* ctx, void* d_bases, uint64_t n_bases, uint64_t* d_offsets, uint64_t n_seqs, bl_batch** out);  // bl_capi.hip
+extern int bl_batch_adopt_device(bl_ctx* ctx, void* d_bases, uint64_t n_bases, uint64_t* d_offsets, uint64_t n_seqs, uint64_t fixed_len,
+                                 bl_batch** out);  // bl_capi.hip
 
 namespace {
 
@@ -139,6 +140,13 @@ __global__ void record_offsets_kernel(const unsigned long long* hdr, const unsig
     const uint64_t li = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (li == 0) offsets[n_records] = total;
     if (li < n_lines && hdr[li]) offsets[rec_incl[li] - 1] = dst[li];
+}
+
+// do all records hold exactly `len` bases?  (flag |= 1 where one does not)
+__global__ void uniform_length_kernel(const unsigned long long* offsets, uint64_t n_records, uint64_t len, unsigned int* flag)
+{
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r <= n_records && offsets[r] != r * len) atomicOr(flag, 1u);
 }
 
 // one thread per 16 output bytes: find the sequence line that holds output byte x (last line with dst <= x), gather
@@ -349,11 +357,20 @@ int bl_parse_device_text(bl_ctx* ctx, const uint8_t* d_text_in, uint64_t n_bytes
                            d_bases, (uint64_t)total);
     }
     hipLaunchKernelGGL(record_offsets_kernel, dim3(lb), dim3(256), 0, s, d_hdr, d_rec, d_dst, n_lines, d_offsets, (uint64_t)n_records, (uint64_t)total);
+    // reads of one length (the usual short-read file) make a fixed-length batch: the read-tiled scan kernels, no start-bit vector
+    uint64_t fixed_len = n_records > 1 && total % n_records == 0 ? total / n_records : 0;
+    unsigned int ragged = 0;
+    if (fixed_len) {
+        P_HIP(hipMemsetAsync(d_err + 1, 0, sizeof(unsigned int), s));
+        hipLaunchKernelGGL(uniform_length_kernel, dim3((unsigned)((n_records + 256) / 256)), dim3(256), 0, s, d_offsets, (uint64_t)n_records, fixed_len, d_err + 1);
+        P_HIP(hipMemcpyAsync(&ragged, d_err + 1, sizeof(ragged), hipMemcpyDeviceToHost, s));
+    }
     P_HIP(hipGetLastError());
     P_HIP(hipStreamSynchronize(s));
+    if (ragged) fixed_len = 0;
     handed_over = true;
     cleanup();
-    int rc = bl_batch_adopt_device(ctx, d_bases, total, reinterpret_cast<uint64_t*>(d_offsets), n_records, out);  // takes ownership of both
+    int rc = bl_batch_adopt_device(ctx, d_bases, total, reinterpret_cast<uint64_t*>(d_offsets), n_records, fixed_len, out);  // takes ownership of both
     if (rc != BL_OK) return rc;
     if (n_seqs) *n_seqs = n_records;
     if (n_bases) *n_bases = total;
