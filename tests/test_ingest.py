@@ -399,6 +399,13 @@ def test_bgzf_device_path_awkward_files(tmp_path):
         fq = b"".join(b"@r%d a@b" % i + nl + s + nl + b"+" + nl + (first[i % 5] + b"@" * (len(s) - 1))[:len(s)] + nl for i, s in enumerate(seqs))
         check(fq, 64 << 10)
         check(fq, 64 << 10, eof=False, block=9000)
+    # long reads (nanopore-like): records from 1 kbp to 600 kbp with noisy quality strings, spans of 256 KiB — most records are
+    # longer than the window of text that is looked at first for the cut, some are longer than a span
+    lens = [int(x) for x in rng.integers(1000, 60_000, 60)] + [600_000, 5, 300_000]
+    long_seqs = [O.synth(900 + i, n).tobytes() for i, n in enumerate(lens)]
+    fq = b"".join(b"@read%d ch=%d\n" % (i, i % 512) + s + b"\n+\n" + rng.integers(33, 74, len(s), dtype=np.uint8).tobytes() + b"\n" for i, s in enumerate(long_seqs))
+    check(fq, 256 << 10)
+    check(fq, 0)
     # damaged / truncated
     text = b"".join(b"@r%d\n" % i + s + b"\n+\n" + b"I" * len(s) + b"\n" for i, s in enumerate(seqs)) * 4
     good = bytearray(_bgzf(text))
@@ -463,7 +470,7 @@ def test_shard_ranges_are_member_boundaries(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kind", ["fastq", "fasta"])
+@pytest.mark.parametrize("kind", ["fastq", "fasta", "fastq_long"])
 def test_bgzf_file_read_in_parts(tmp_path, kind):
     """one BGZF file read by `world` readers that take a part each (bl_reader_open_shard): the parts' sequences, in rank order,
     are the file's sequences — whatever the number of parts (more parts than members included), the span size, and wherever the
@@ -476,6 +483,10 @@ def test_bgzf_file_read_in_parts(tmp_path, kind):
         seqs = [O.synth(500 + i, int(n)).tobytes() for i, n in enumerate(rng.integers(1, 400, 6000))]
         first = [b"@", b"+", b"I", b"@", b">"]
         text = b"".join(b"@r%d a@b" % i + b"\n" + s + b"\n+\n" + (first[i % 5] + b"@" * (len(s) - 1))[:len(s)] + b"\n" for i, s in enumerate(seqs))
+    elif kind == "fastq_long":  # nanopore-like: most members lie inside ONE record, quality strings hold every printable character
+        lens = [int(x) for x in rng.integers(1000, 150_000, 40)] + [400_000, 7]
+        seqs = [O.synth(800 + i, n).tobytes() for i, n in enumerate(lens)]
+        text = b"".join(b"@read%d\n" % i + s + b"\n+\n" + rng.integers(33, 127, len(s), dtype=np.uint8).tobytes() + b"\n" for i, s in enumerate(seqs))
     else:
         lens = [1, 69, 70, 71, 5000, 400_000, 3, 150_000, 12] + [int(x) for x in rng.integers(1, 3000, 300)]
         seqs = [O.synth(700 + i, n).tobytes() for i, n in enumerate(lens)]
@@ -499,7 +510,7 @@ def test_bgzf_file_read_in_parts(tmp_path, kind):
                 sizes.append(part)
             assert b"".join(got) == whole, (kind, block, world, sizes)
             assert n_seqs == len(seqs) and sum(sizes) == len(whole)
-            if world in (2, 3) and kind == "fastq":
+            if world in (2, 3) and kind == "fastq":  # (short reads: the parts are cut close to the byte targets)
                 assert min(sizes) > 0.5 * len(whole) / world  # the parts are about equal
     # a sharded reader refuses the host calls; anything but BGZF refuses to be read in parts
     r = biolib_amd.Reader(path, shard=(0, 2))
