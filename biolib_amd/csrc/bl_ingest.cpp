@@ -15,8 +15,14 @@
 //          what has been gathered so far is dropped after each line, unless that is all there is
 //        * after a '+' line, quality lines are gathered until they are at least as long as the sequence; a different
 //          total length (or no quality at all) makes the record malformed
-//   3. Text spans for the device-side parser (bl_batch_from_text): the decompressed text cut at record boundaries, so that
-//      .gz input takes  parallel inflate -> one H2D copy -> parse on the GPU  instead of the host record loop.
+//      RecordBatcher: batches of whole records (bl_reader_next_batch), parsed one batch ahead of the caller by a thread.
+//   3. TextCutter: text spans for the device-side parser (bl_batch_from_text) — the decompressed text cut at record boundaries
+//      found from the span's own last bytes, assembled ahead of the caller in a ring of (page-locked) buffers; plain files are
+//      read straight into them.
+//   4. The compressed path (PackedSpans, DeviceBgzf, next_batch_packed): a BGZF file goes to the device as it is — a thread reads
+//      it and walks the member headers, bl_inflate.hip inflates a span's members on the GPU, the text is cut and parsed there.
+//      bl_reader_open_shard gives each of several readers its own part of one file (parts meet at record starts that every
+//      reader recognises by itself).
 // Bases are passed through untouched (the scan's own table decides what is a break).
 #include <fcntl.h>
 #include <sys/stat.h>
@@ -1168,12 +1174,7 @@ struct bl_reader {
     HostBatch* batch = nullptr;              // the one handed out last
     std::unique_ptr<RecordParser> records;
     std::unique_ptr<TextCutter> text;
-    Record rec;
-    bool have_pending = false;  // a record was parsed but did not fit the previous batch
-    // last batch
-    std::string bases;
-    std::vector<uint64_t> offsets;
-    std::vector<std::string> names;
+    Record rec;  // bl_reader_next_record: the record handed out last
 };
 
 namespace {
