@@ -19,6 +19,7 @@
 #include "biolib_amd_runtime.hpp"
 #include "constants.hpp"
 #include "hash.hpp"
+#include "read_pool.hpp"
 
 namespace wrapper {
 
@@ -97,6 +98,14 @@ class minimizer_view
         {
             if (cache) return cache.get();
             auto out = std::make_shared<materialised>();
+            if constexpr (std::is_same<Iterator, char_iterator>::value) {
+                // contiguous memory: is it a record a read_pool handed out?  then ONE scan of the pool's whole batch holds its minimizers
+                const std::size_t len = static_cast<std::size_t>(itr_stop.base() - itr_start.base());
+                if (biolib_amd::read_pool::lookup_minimizers(itr_start.base(), len, klen, mlen, mseed, canon, out->values, out->positions, out->hashes)) {
+                    cache = out;
+                    return cache.get();
+                }
+            }
             std::string chars;
             for (Iterator it = itr_start; it != itr_stop; ++it) chars.push_back(*it);
             const std::size_t n = chars.size();

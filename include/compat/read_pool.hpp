@@ -13,7 +13,9 @@
 #ifndef BIOLIB_AMD_COMPAT_READ_POOL_HPP
 #define BIOLIB_AMD_COMPAT_READ_POOL_HPP
 
+#include <algorithm>
 #include <map>
+#include <tuple>
 #include <utility>
 
 #include "biolib_amd_runtime.hpp"
@@ -37,6 +39,10 @@ class read_pool
             bl_reader_close(reader);
             if (d_values) bl_device_free(context::get(), d_values);
             if (h_values) bl_host_free(context::get(), h_values);
+            for (uint64_t* d : {d_mvalues, d_mpositions, d_mhashes})
+                if (d) bl_device_free(context::get(), d);
+            for (uint64_t* h : {mscan.values, mscan.positions, mscan.hashes})
+                if (h) bl_host_free(context::get(), h);
         }
         read_pool(read_pool const&) = delete;
 
@@ -60,7 +66,78 @@ class read_pool
             return nullptr;
         }
 
+        // used by minimizer_view: if [p, p + len) lies in the current batch of a live pool of this thread, the minimizer records
+        // (value, position relative to p, hash) of the windows inside that stretch, taken from ONE scan of the whole batch
+        static bool lookup_minimizers(char const* p, std::size_t len, unsigned k, unsigned m, uint64_t seed, bool canonical, std::vector<uint64_t>& values,
+                                      std::vector<uint64_t>& positions, std::vector<uint64_t>& hashes)
+        {
+            for (read_pool* q = head(); q; q = q->next_in_chain)
+                if (q->bases and p >= q->bases and p + len <= q->bases + q->n_bases) {
+                    q->minimizers(static_cast<uint64_t>(p - q->bases), len, k, m, seed, canonical, values, positions, hashes);
+                    return true;
+                }
+            return false;
+        }
+
     private:
+        // the batch's minimizer records for one (k, m, seed, canonical): page-locked host arrays that live with the pool
+        struct minimizer_scan {
+            uint64_t *values = nullptr, *positions = nullptr, *hashes = nullptr;
+            uint64_t count = 0, cap = 0;
+            bool valid = false;
+            std::tuple<unsigned, unsigned, uint64_t, bool> key {0u, 0u, 0ull, false};
+        };
+        minimizer_scan mscan;
+        uint64_t *d_mvalues = nullptr, *d_mpositions = nullptr, *d_mhashes = nullptr;
+        uint64_t d_mcap = 0;
+
+        void minimizers(uint64_t first, std::size_t len, unsigned k, unsigned m, uint64_t seed, bool canonical, std::vector<uint64_t>& values,
+                        std::vector<uint64_t>& positions, std::vector<uint64_t>& hashes)
+        {
+            auto key = std::make_tuple(k, m, seed, canonical);
+            if (not mscan.valid or mscan.key != key) {  // the first view of this batch (or other parameters): one scan for all its reads
+                bl_ctx* c = context::get();
+                const uint64_t cap = n_bases + 64;  // at most one record per position
+                if (cap > d_mcap) {
+                    for (uint64_t** d : {&d_mvalues, &d_mpositions, &d_mhashes}) {
+                        if (*d) check(bl_device_free(c, *d), "bl_device_free");
+                        void* p = nullptr;
+                        check(bl_device_alloc(c, (cap + cap / 8) * sizeof(uint64_t), &p), "bl_device_alloc");
+                        *d = static_cast<uint64_t*>(p);
+                    }
+                    d_mcap = cap + cap / 8;
+                }
+                bl_result res;
+                check(bl_scan_minimizers(c, batch, 0, 0, m, k - m + 1, seed, (canonical ? (uint32_t)BL_FLAG_CANONICAL : 0u) | BL_FLAG_SYNC, d_mvalues, d_mpositions,
+                                         d_mhashes, d_mcap, &res), "bl_scan_minimizers");
+                if (res.count > mscan.cap) {
+                    for (uint64_t** h : {&mscan.values, &mscan.positions, &mscan.hashes}) {
+                        if (*h) check(bl_host_free(c, *h), "bl_host_free");
+                        void* p = nullptr;
+                        check(bl_host_alloc(c, (res.count + res.count / 8 + 64) * sizeof(uint64_t), &p), "bl_host_alloc");
+                        *h = static_cast<uint64_t*>(p);
+                    }
+                    mscan.cap = res.count + res.count / 8 + 64;
+                }
+                check(bl_copy_to_host(c, mscan.values, d_mvalues, res.count * sizeof(uint64_t)), "bl_copy_to_host");
+                check(bl_copy_to_host(c, mscan.positions, d_mpositions, res.count * sizeof(uint64_t)), "bl_copy_to_host");
+                check(bl_copy_to_host(c, mscan.hashes, d_mhashes, res.count * sizeof(uint64_t)), "bl_copy_to_host");
+                mscan.count = res.count;
+                mscan.key = key;
+                mscan.valid = true;
+                ++scans;
+            }
+            // records are in position order: those of this read are the ones that start inside it (a window never spans two reads)
+            uint64_t const* const all_end = mscan.positions + mscan.count;
+            uint64_t const* lo = std::lower_bound(static_cast<uint64_t const*>(mscan.positions), all_end, first);
+            uint64_t const* hi = std::lower_bound(lo, all_end, first + static_cast<uint64_t>(len));
+            const std::size_t a = static_cast<std::size_t>(lo - mscan.positions), n = static_cast<std::size_t>(hi - lo);
+            values.assign(mscan.values + a, mscan.values + a + n);
+            hashes.assign(mscan.hashes + a, mscan.hashes + a + n);
+            positions.resize(n);
+            for (std::size_t i = 0; i < n; ++i) positions[i] = mscan.positions[a + i] - first;
+        }
+
         bl_reader* reader = nullptr;
         bl_batch* batch = nullptr;
         char const* bases = nullptr;
@@ -85,6 +162,7 @@ class read_pool
             bases = nullptr;
             cache.clear();
             have_primary = false;
+            mscan.valid = false;
             n_seqs = n_bases = at = 0;
         }
         bool refill()

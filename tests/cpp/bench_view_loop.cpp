@@ -3,6 +3,8 @@
 //   pooled    records come from a biolib_amd::read_pool: one upload + one scan per batch of reads, views index into it
 //   per_view  records come from a plain host buffer: every view uploads, scans and downloads by itself (first N reads only)
 // usage: bench_view_loop file.fq k canonical [per_view_reads]   -> one JSON line
+//        bench_view_loop file.fq k canonical per_view_reads m seed
+//            the same for the reference's minimizer driver (tests/test_minimizer_view.cpp:37-43): minimizer_view_from_cstr per read
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -10,8 +12,60 @@
 #include <vector>
 
 #include "kmer_view.hpp"
+#include "minimizer_view.hpp"
 
 typedef uint64_t kmer_t;
+typedef uint64_t mmer_t;
+
+// the minimizer driver's loop: count, XOR of values, XOR of (hash-free) positions rebased to the read, over pooled / plain memory
+struct mini_digest {
+    uint64_t count = 0, xor_value = 0, sum_pos = 0;
+};
+static void add_view(mini_digest& d, char const* s, std::size_t l, uint8_t k, uint8_t m, uint64_t seed, bool canonical)
+{
+    auto view = wrapper::minimizer_view_from_cstr<kmer_t, mmer_t, hash::hash64>(s, l, k, m, seed, canonical);
+    for (auto itr = view.cbegin(); itr != view.cend(); ++itr) {
+        auto val = *itr;
+        ++d.count;
+        d.xor_value ^= val.value;
+        d.sum_pos += val.position;
+    }
+}
+static int minimizer_loop(const std::string& path, uint8_t k, uint8_t m, uint64_t seed, bool canonical, size_t per_view_reads)
+{
+    using clock = std::chrono::steady_clock;
+    (void)biolib_amd::context::get();
+    mini_digest pooled, pooled_head, plain;
+    uint64_t reads = 0, bases = 0, scans = 0;
+    std::vector<std::string> keep;
+    const auto t0 = clock::now();
+    {
+        biolib_amd::read_pool pool(path);
+        char const* s; std::size_t l;
+        while (pool.next(s, l)) {
+            add_view(pooled, s, l, k, m, seed, canonical);
+            if (keep.size() < per_view_reads) {
+                add_view(pooled_head, s, l, k, m, seed, canonical);
+                keep.emplace_back(s, l);
+            }
+            ++reads;
+            bases += l;
+        }
+        scans = pool.batches_scanned();
+    }
+    const double pooled_s = std::chrono::duration<double>(clock::now() - t0).count();
+    const auto t1 = clock::now();
+    for (auto const& r : keep) add_view(plain, r.c_str(), r.size(), k, m, seed, canonical);
+    const double per_view_s = std::chrono::duration<double>(clock::now() - t1).count();
+    std::printf("{\"reads\": %llu, \"bases\": %llu, \"minimizers\": %llu, \"xor_values\": %llu, \"sum_positions\": %llu, \"batch_scans\": %llu, \"pooled_seconds\": %.4f, "
+                "\"pooled_reads_per_s\": %.0f, \"per_view_reads\": %zu, \"per_view_seconds\": %.4f, \"per_view_reads_per_s\": %.0f, "
+                "\"head_pooled\": [%llu, %llu, %llu], \"head_per_view\": [%llu, %llu, %llu]}\n",
+                (unsigned long long)reads, (unsigned long long)bases, (unsigned long long)pooled.count, (unsigned long long)pooled.xor_value, (unsigned long long)pooled.sum_pos,
+                (unsigned long long)scans, pooled_s, reads / pooled_s, keep.size(), per_view_s, keep.size() / per_view_s, (unsigned long long)pooled_head.count,
+                (unsigned long long)pooled_head.xor_value, (unsigned long long)pooled_head.sum_pos, (unsigned long long)plain.count, (unsigned long long)plain.xor_value,
+                (unsigned long long)plain.sum_pos);
+    return 0;
+}
 
 int main(int argc, char* argv[])
 {
@@ -20,6 +74,7 @@ int main(int argc, char* argv[])
     const uint8_t k = (uint8_t)std::atoi(argv[2]);
     const bool canonical = std::atoi(argv[3]) != 0;
     const size_t per_view_reads = argc > 4 ? (size_t)std::atoll(argv[4]) : 2000;
+    if (argc > 6) return minimizer_loop(path, k, (uint8_t)std::atoi(argv[5]), std::strtoull(argv[6], nullptr, 10), canonical, per_view_reads);
     using clock = std::chrono::steady_clock;
     (void)biolib_amd::context::get();  // context creation is not part of either loop
 

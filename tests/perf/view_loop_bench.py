@@ -27,6 +27,11 @@ with tempfile.TemporaryDirectory() as d:
     t0 = time.perf_counter()
     x = R.ref_read_loop_kmers_xor(path.encode(), k, canon, C.byref(nr), C.byref(nk))
     dt = time.perf_counter() - t0
+    # the minimizer driver's loop (tests/test_minimizer_view.cpp:37-43: k = 15, m = 10, seed 42) through the pool; the reference's own
+    # minimizer_view yields nothing, so there is no reference figure beside it
+    mm = json.loads(subprocess.run([exe, path, "15", "0", "2000", "10", "42"], capture_output=True, text=True, check=True).stdout.strip().splitlines()[-1])
+    res["minimizer_loop"] = {key: mm[key] for key in ("reads", "minimizers", "batch_scans", "pooled_seconds", "pooled_reads_per_s", "per_view_reads", "per_view_reads_per_s")}
+    res["minimizer_loop"]["pooled_equals_per_view_on_head"] = mm["head_pooled"] == mm["head_per_view"]
     res.update(reference_reads_per_s=round(nr.value / dt), reference_seconds=round(dt, 3), reference_cores=1,
                same_kmers_as_reference=bool(x == res["xor_values"] and nk.value == res["kmers"] and nr.value == res["reads"]),
                workload=f"{n_reads} reads x {L} bp FASTQ, kmer_view k={k} canonical, `it != cend()` idiom")

@@ -76,6 +76,39 @@ def test_cpp_view_loop_pooled_vs_per_view(tmp_path):
     assert d["batch_scans"] <= 2 and d["pooled_reads_per_s"] > 5 * d["per_view_reads_per_s"]
 
 
+@pytest.mark.gpu
+def test_cpp_minimizer_loop_pooled_vs_per_view(tmp_path):
+    """the reference's minimizer driver loop (tests/test_minimizer_view.cpp:37-43, k = 15, m = 10, seed 42) over a read_pool:
+    the minimizers of every read come from ONE scan per batch — same records as view by view, and as the oracle on the reads"""
+    import json
+
+    import numpy as np
+
+    import oracle_lib as O
+
+    exe = os.path.join(ROOT, "tests", "cpp", "_build", "bench_view_loop")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "cpp")])
+    rng = np.random.default_rng(6)
+    lens = rng.integers(12, 300, 20_000)  # some reads shorter than k: no window, no record
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    seq = O.synth(4, int(offs[-1]))
+    seq[::911] = ord("N")
+    path = tmp_path / "reads.fa"
+    with open(path, "wb") as f:
+        for i in range(len(lens)):
+            f.write(b">r%d\n" % i + seq[int(offs[i]):int(offs[i + 1])].tobytes() + b"\n")
+    out = subprocess.run([exe, str(path), "15", "0", "400", "10", "42"], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    d = json.loads(out.stdout.strip().splitlines()[-1])
+    v, p, h = O.minimizers(seq, offs, 10, 6, 42, False, brute=False)  # unit = m = 10, window = k - m + 1 = 6
+    read_of = np.searchsorted(offs, p, side="right") - 1
+    rel = p - offs[read_of]
+    assert (d["reads"], d["minimizers"], d["xor_values"], d["sum_positions"]) == (len(lens), len(v), O.xor_reduce(v), int(rel.sum()))
+    assert d["head_pooled"] == d["head_per_view"] and d["batch_scans"] <= 2
+    assert d["pooled_reads_per_s"] > 5 * d["per_view_reads_per_s"]
+
+
 def test_cpp_compat_headers_compile():
     """CPU-only: the drop-in headers and their test compile and link against the C ABI."""
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "biolib_amd", "csrc")])
