@@ -14,6 +14,7 @@
 #define BIOLIB_AMD_COMPAT_READ_POOL_HPP
 
 #include <algorithm>
+#include <cstring>
 #include <map>
 #include <tuple>
 #include <utility>
@@ -79,7 +80,61 @@ class read_pool
             return false;
         }
 
+        // used by super_kmer_view, in the same way: the super-k-mers that begin inside [p, p + len).  That view keeps its own
+        // copy of the sequence and may outlive the batch it was cut from, so `copy` (its bytes) must still be what the pool holds.
+        static bool lookup_super_kmers(char const* p, char const* copy, std::size_t len, unsigned k, unsigned m, uint64_t seed, bool canonical,
+                                       std::vector<uint64_t>& minimizers, std::vector<uint64_t>& first_pos, std::vector<uint64_t>& hashes, std::vector<uint8_t>& mm_pos,
+                                       std::vector<uint8_t>& sizes)
+        {
+            for (read_pool* q = head(); q; q = q->next_in_chain)
+                if (q->bases and p >= q->bases and p + len <= q->bases + q->n_bases and std::memcmp(p, copy, len) == 0) {
+                    q->super_kmers(static_cast<uint64_t>(p - q->bases), len, k, m, seed, canonical, minimizers, first_pos, hashes, mm_pos, sizes);
+                    return true;
+                }
+            return false;
+        }
+
     private:
+        // the batch's super-k-mers for one (k, m, seed, canonical)
+        struct super_kmer_scan {
+            std::vector<uint64_t> minimizers, first_pos, hashes;
+            std::vector<uint8_t> mm_pos, sizes;
+            bool valid = false;
+            std::tuple<unsigned, unsigned, uint64_t, bool> key {0u, 0u, 0ull, false};
+        };
+        super_kmer_scan sscan;
+
+        void super_kmers(uint64_t first, std::size_t len, unsigned k, unsigned m, uint64_t seed, bool canonical, std::vector<uint64_t>& minimizers,
+                         std::vector<uint64_t>& first_pos, std::vector<uint64_t>& hashes, std::vector<uint8_t>& mm_pos, std::vector<uint8_t>& sizes)
+        {
+            auto key = std::make_tuple(k, m, seed, canonical);
+            if (not sscan.valid or sscan.key != key) {
+                const std::size_t cap = n_bases + 64;
+                device_array<uint64_t> dm(cap), df(cap), dh(cap);
+                device_array<uint8_t> dp(cap), ds(cap);
+                bl_result res;
+                check(bl_scan_super_kmers(context::get(), batch, 0, 0, k, m, seed, (canonical ? (uint32_t)BL_FLAG_CANONICAL : 0u) | BL_FLAG_SYNC, dm.d, df.d, dp.d, ds.d, dh.d,
+                                          cap, &res), "bl_scan_super_kmers");
+                sscan.minimizers = dm.to_host(res.count);
+                sscan.first_pos = df.to_host(res.count);
+                sscan.hashes = dh.to_host(res.count);
+                sscan.mm_pos = dp.to_host(res.count);
+                sscan.sizes = ds.to_host(res.count);
+                sscan.key = key;
+                sscan.valid = true;
+                ++scans;
+            }
+            auto lo = std::lower_bound(sscan.first_pos.begin(), sscan.first_pos.end(), first);
+            auto hi = std::lower_bound(lo, sscan.first_pos.end(), first + static_cast<uint64_t>(len));
+            const std::size_t a = static_cast<std::size_t>(lo - sscan.first_pos.begin()), n = static_cast<std::size_t>(hi - lo);
+            minimizers.assign(sscan.minimizers.begin() + a, sscan.minimizers.begin() + a + n);
+            hashes.assign(sscan.hashes.begin() + a, sscan.hashes.begin() + a + n);
+            mm_pos.assign(sscan.mm_pos.begin() + a, sscan.mm_pos.begin() + a + n);
+            sizes.assign(sscan.sizes.begin() + a, sscan.sizes.begin() + a + n);
+            first_pos.resize(n);
+            for (std::size_t i = 0; i < n; ++i) first_pos[i] = sscan.first_pos[a + i] - first;
+        }
+
         // the batch's minimizer records for one (k, m, seed, canonical): page-locked host arrays that live with the pool
         struct minimizer_scan {
             uint64_t *values = nullptr, *positions = nullptr, *hashes = nullptr;
@@ -163,6 +218,7 @@ class read_pool
             cache.clear();
             have_primary = false;
             mscan.valid = false;
+            sscan.valid = false;
             n_seqs = n_bases = at = 0;
         }
         bool refill()

@@ -15,6 +15,7 @@
 
 #include "biolib_amd_runtime.hpp"
 #include "hash.hpp"
+#include "read_pool.hpp"
 
 namespace wrapper {
 
@@ -61,7 +62,7 @@ class super_kmer_view
         };
 
         super_kmer_view(char const* contig, std::size_t contig_len, uint8_t k, uint8_t m, bool canonical = false, uint64_t seed = 0)
-            : seq(contig, contig_len), klen(k), mlen(m), canon(canonical), mseed(seed) {validate();}
+            : seq(contig, contig_len), origin(contig), klen(k), mlen(m), canon(canonical), mseed(seed) {validate();}
         super_kmer_view(std::string const& contig, uint8_t k, uint8_t m, bool canonical = false, uint64_t seed = 0)
             : seq(contig), klen(k), mlen(m), canon(canonical), mseed(seed) {validate();}
         const_iterator cbegin() const {return const_iterator(this);}
@@ -77,6 +78,7 @@ class super_kmer_view
             std::vector<uint8_t> mm_pos, sizes;
         };
         std::string seq;
+        char const* origin = nullptr;  // where the contig was handed over from: a read_pool's arena, perhaps
         uint8_t klen, mlen;
         bool canon;
         uint64_t mseed;
@@ -92,6 +94,12 @@ class super_kmer_view
             if (cache) return cache.get();
             auto out = std::make_shared<materialised>();
             const std::size_t n = seq.size();
+            // a record a read_pool handed out?  then ONE scan of the pool's whole batch holds its super-k-mers
+            if (origin and biolib_amd::read_pool::lookup_super_kmers(origin, seq.data(), n, klen, mlen, mseed, canon, out->minimizers, out->first_pos, out->hashes, out->mm_pos,
+                                                                     out->sizes)) {
+                cache = out;
+                return cache.get();
+            }
             if (n >= klen) {
                 biolib_amd::batch_handle batch(seq.data(), n);
                 const std::size_t cap = n - klen + 1;

@@ -5,6 +5,8 @@
 // usage: bench_view_loop file.fq k canonical [per_view_reads]   -> one JSON line
 //        bench_view_loop file.fq k canonical per_view_reads m seed
 //            the same for the reference's minimizer driver (tests/test_minimizer_view.cpp:37-43): minimizer_view_from_cstr per read
+//        bench_view_loop file.fq k canonical per_view_reads m seed super
+//            and for its super-k-mer driver (tests/test_super_kmer_view.cpp:30-36): one super_kmer_view per read
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -13,6 +15,7 @@
 
 #include "kmer_view.hpp"
 #include "minimizer_view.hpp"
+#include "super_kmer_view.hpp"
 
 typedef uint64_t kmer_t;
 typedef uint64_t mmer_t;
@@ -21,8 +24,19 @@ typedef uint64_t mmer_t;
 struct mini_digest {
     uint64_t count = 0, xor_value = 0, sum_pos = 0;
 };
+static bool g_super = false;  // digest super-k-mers instead: value = minimizer, position = first k-mer + mm_pos + 256 * size
 static void add_view(mini_digest& d, char const* s, std::size_t l, uint8_t k, uint8_t m, uint64_t seed, bool canonical)
 {
+    if (g_super) {
+        wrapper::super_kmer_view<kmer_t, mmer_t, hash::hash64> view(s, l, k, m, canonical, seed);
+        for (auto itr = view.cbegin(); itr != view.cend(); ++itr) {
+            auto const& sk = *itr;
+            ++d.count;
+            d.xor_value ^= sk.minimizer;
+            d.sum_pos += sk.position + sk.mm_pos + 256ull * sk.size;
+        }
+        return;
+    }
     auto view = wrapper::minimizer_view_from_cstr<kmer_t, mmer_t, hash::hash64>(s, l, k, m, seed, canonical);
     for (auto itr = view.cbegin(); itr != view.cend(); ++itr) {
         auto val = *itr;
@@ -74,6 +88,7 @@ int main(int argc, char* argv[])
     const uint8_t k = (uint8_t)std::atoi(argv[2]);
     const bool canonical = std::atoi(argv[3]) != 0;
     const size_t per_view_reads = argc > 4 ? (size_t)std::atoll(argv[4]) : 2000;
+    g_super = argc > 7 and std::string(argv[7]) == "super";
     if (argc > 6) return minimizer_loop(path, k, (uint8_t)std::atoi(argv[5]), std::strtoull(argv[6], nullptr, 10), canonical, per_view_reads);
     using clock = std::chrono::steady_clock;
     (void)biolib_amd::context::get();  // context creation is not part of either loop

@@ -32,6 +32,10 @@ with tempfile.TemporaryDirectory() as d:
     mm = json.loads(subprocess.run([exe, path, "15", "0", "2000", "10", "42"], capture_output=True, text=True, check=True).stdout.strip().splitlines()[-1])
     res["minimizer_loop"] = {key: mm[key] for key in ("reads", "minimizers", "batch_scans", "pooled_seconds", "pooled_reads_per_s", "per_view_reads", "per_view_reads_per_s")}
     res["minimizer_loop"]["pooled_equals_per_view_on_head"] = mm["head_pooled"] == mm["head_per_view"]
+    sk = json.loads(subprocess.run([exe, path, "31", "0", "2000", "13", "0", "super"], capture_output=True, text=True, check=True).stdout.strip().splitlines()[-1])
+    res["super_kmer_loop"] = {key: sk[key] for key in ("reads", "batch_scans", "pooled_seconds", "pooled_reads_per_s", "per_view_reads", "per_view_reads_per_s")}
+    res["super_kmer_loop"]["super_kmers"] = sk["minimizers"]
+    res["super_kmer_loop"]["pooled_equals_per_view_on_head"] = sk["head_pooled"] == sk["head_per_view"]
     res.update(reference_reads_per_s=round(nr.value / dt), reference_seconds=round(dt, 3), reference_cores=1,
                same_kmers_as_reference=bool(x == res["xor_values"] and nk.value == res["kmers"] and nr.value == res["reads"]),
                workload=f"{n_reads} reads x {L} bp FASTQ, kmer_view k={k} canonical, `it != cend()` idiom")

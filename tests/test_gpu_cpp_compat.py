@@ -109,6 +109,42 @@ def test_cpp_minimizer_loop_pooled_vs_per_view(tmp_path):
     assert d["pooled_reads_per_s"] > 5 * d["per_view_reads_per_s"]
 
 
+@pytest.mark.gpu
+def test_cpp_super_kmer_loop_pooled_vs_per_view(tmp_path):
+    """the reference's super-k-mer driver loop (tests/test_super_kmer_view.cpp:30-36) over a read_pool: every read's super-k-mers come
+    from ONE scan per batch — same records as view by view, and as the oracle on the reads"""
+    import json
+
+    import numpy as np
+
+    import oracle_lib as O
+
+    exe = os.path.join(ROOT, "tests", "cpp", "_build", "bench_view_loop")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "cpp")])
+    rng = np.random.default_rng(16)
+    lens = rng.integers(20, 300, 20_000)  # some reads shorter than k
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    seq = O.synth(14, int(offs[-1]))
+    seq[::733] = ord("N")
+    path = tmp_path / "reads.fq"
+    with open(path, "wb") as f:
+        for i in range(len(lens)):
+            r = seq[int(offs[i]):int(offs[i + 1])].tobytes()
+            f.write(b"@r%d\n" % i + r + b"\n+\n" + b"I" * len(r) + b"\n")
+    for canon in (0, 1):
+        out = subprocess.run([exe, str(path), "31", str(canon), "300", "13", "7", "super"], capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+        d = json.loads(out.stdout.strip().splitlines()[-1])
+        mn, fp, mp, sz, _ = O.super_kmers(seq, offs, 31, 13, 7, bool(canon))
+        read_of = np.searchsorted(offs, fp, side="right") - 1
+        rel = fp - offs[read_of]
+        want = int(rel.sum()) + int(mp.astype(np.uint64).sum()) + 256 * int(sz.astype(np.uint64).sum())
+        assert (d["reads"], d["minimizers"], d["xor_values"], d["sum_positions"]) == (len(lens), len(mn), O.xor_reduce(mn), want)
+        assert d["head_pooled"] == d["head_per_view"] and d["batch_scans"] <= 2
+        assert d["pooled_reads_per_s"] > 5 * d["per_view_reads_per_s"]
+
+
 def test_cpp_compat_headers_compile():
     """CPU-only: the drop-in headers and their test compile and link against the C ABI."""
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "biolib_amd", "csrc")])
