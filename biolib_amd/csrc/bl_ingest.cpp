@@ -25,6 +25,7 @@
 //      reader recognises by itself).
 // Bases are passed through untouched (the scan's own table decides what is a break).
 #include <fcntl.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 #include <zlib.h>
@@ -36,6 +37,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <functional>
 #include <memory>
 #include <mutex>
 #include <new>
@@ -46,6 +48,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include "../../include/biolib_amd.h"
+#include "bl_pgzip.hpp"
 
 extern int bl_set_error(int code, const char* msg);  // bl_capi.hip
 extern hipStream_t bl_ctx_stream(bl_ctx* ctx);
@@ -241,6 +244,428 @@ private:
     bool stop_ = false;
 };
 
+// One gzip stream inflated by many threads (the pieces: bl_pgzip.hpp).  The file is cut into parts of `part_bytes`; a pool decodes
+// each part from the first block it finds in it to the first block boundary in the next part, as symbols; this thread takes the
+// parts in file order, checks that a part begins at the very bit the part before ended on, turns the symbols into text (pool
+// again, by pieces that become the queue's chunks) and keeps the members' CRC-32.  Whatever lies between the end of one part
+// and the start of the next that fits (blocks the finder does not look for: stored, fixed, final ones; a false find; anything
+// damaged) is inflated here by zlib, block by block, which also gives zlib the verdict on every odd or broken stream.
+class ParallelGzip {
+public:
+    ParallelGzip(int fd, uint64_t size, int threads, size_t part_bytes, OrderedQueue& q, SpareBuffers& spare)
+        : fd_(fd), size_(size), threads_(threads), part_bytes_(part_bytes), q_(q), spare_(spare)
+    {
+    }
+    ~ParallelGzip()
+    {
+        stop_workers();
+        if (map_ && map_ != MAP_FAILED) munmap(const_cast<uint8_t*>(map_), size_);
+    }
+    // false: nothing has been delivered and the caller should inflate the stream the plain way
+    bool run()
+    {
+        void* m = mmap(nullptr, size_, PROT_READ, MAP_PRIVATE, fd_, 0);
+        if (m == MAP_FAILED) return false;
+        map_ = static_cast<const uint8_t*>(m);
+        (void)madvise(m, size_, MADV_SEQUENTIAL);
+        const uint64_t data = blpg::skip_member_header(map_, size_, 0);
+        if (data == blpg::NPOS) return false;
+        pos_ = 8 * data;
+        const uint64_t n_parts = (size_ + part_bytes_ - 1) / part_bytes_;
+        const int ahead = threads_ + 2;
+        for (int i = 0; i < ahead + 2; ++i) free_parts_.push_back(new PartSlot());
+        for (int i = 0; i < threads_; ++i) workers_.emplace_back([this] { work(); });
+        uint64_t issued = 0;
+        std::deque<PartSlot*> flying;
+        bool done = false;
+        for (uint64_t i = 0; i < n_parts && !done && !gone_; ++i) {
+            while (issued < n_parts && issued < i + (uint64_t)ahead) {
+                PartSlot* s = take_part(issued == i);  // (must have part i; the others only if a slot is free)
+                if (!s) break;
+                issue(s, issued++);
+                flying.push_back(s);
+            }
+            PartSlot* s = flying.front();
+            flying.pop_front();
+            wait_decoded(s);
+            std::shared_ptr<PartSlot> ref(s, [this](PartSlot* x) { give_part(x); });
+            if (!s->found || s->part.start_bit < pos_) {  // nothing found in this part, or the stream is past it already
+                ++(s->found ? n_missed_ : n_none_);
+                continue;
+            }
+            if (s->part.start_bit > pos_ && !by_zlib(s->part.start_bit, done)) break;
+            if (done || failed_ || gone_) break;
+            if (s->part.start_bit != pos_) {  // zlib's block boundaries stepped over the find: it was a false one
+                ++n_missed_;
+                continue;
+            }
+            if (!accept(ref)) break;
+            ++n_taken_;
+            pool_bytes_ += s->part.n;
+            pos_ = s->part.end_bit;
+            done = s->part.at_eof;
+            settle(false);
+        }
+        cancel_ = true;
+        for (PartSlot* s : flying) {
+            wait_decoded(s);
+            give_part(s);
+        }
+        if (!done && !failed_ && !gone_) by_zlib(blpg::NPOS, done);
+        if (!gone_) {
+            settle(true);
+            if (failed_ || !done) {
+                auto c = q_.reserve();
+                if (c) {
+                    c->ok = false;
+                    q_.finish(c);
+                }
+            }
+        }
+        stop_workers();
+        if (std::getenv("BL_INGEST_TRACE"))
+            std::fprintf(stderr, "[pgzip] %llu parts of %zu bytes: %llu taken as found, %llu without a find, %llu not reached; text by the pool %llu bytes, by zlib %llu bytes\n",
+                         (unsigned long long)n_parts, part_bytes_, (unsigned long long)n_taken_, (unsigned long long)n_none_, (unsigned long long)n_missed_,
+                         (unsigned long long)pool_bytes_, (unsigned long long)zlib_bytes_);
+        return true;
+    }
+
+private:
+    uint64_t n_taken_ = 0, n_none_ = 0, n_missed_ = 0, pool_bytes_ = 0, zlib_bytes_ = 0;  // (trace)
+    struct PartSlot {
+        blpg::Part part;
+        bool found = false;
+        bool decoded = false;
+    };
+    struct Piece {
+        int state = 0;  // 0: being made, 1: good, 2: bad (guarded by m_)
+        uint32_t crc = 0;
+        uint64_t len = 0;
+        bool is_end = false;  // not a piece: the end of a member, whose CRC-32 and length are due
+        uint32_t want_crc = 0, want_isize = 0;
+    };
+
+    int fd_;
+    uint64_t size_;
+    int threads_;
+    size_t part_bytes_;
+    OrderedQueue& q_;
+    SpareBuffers& spare_;
+    const uint8_t* map_ = nullptr;
+    uint64_t pos_ = 0;                  // the bit where the next block of the stream begins
+    uint8_t window_[blpg::WINDOW];      // the last 32 KiB of text made so far
+    uint32_t known_ = 0;                // how many of them exist
+    bool failed_ = false, gone_ = false;  // damaged stream; the consumer has left
+    std::atomic<bool> cancel_{false};
+
+    std::mutex m_;
+    std::condition_variable cv_jobs_, cv_done_;
+    std::deque<std::function<void()>> urgent_, normal_;
+    std::vector<std::thread> workers_;
+    bool stopping_ = false;
+    std::vector<PartSlot*> free_parts_;
+    std::deque<std::shared_ptr<Piece>> ledger_;
+    uint32_t run_crc_ = 0;
+    uint64_t run_len_ = 0;
+
+    void work()
+    {
+        for (;;) {
+            std::function<void()> job;
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_jobs_.wait(lk, [&] { return stopping_ || !urgent_.empty() || !normal_.empty(); });
+                if (!urgent_.empty()) {
+                    job = std::move(urgent_.front());
+                    urgent_.pop_front();
+                } else if (!normal_.empty()) {
+                    job = std::move(normal_.front());
+                    normal_.pop_front();
+                } else {
+                    return;
+                }
+            }
+            job();
+        }
+    }
+    void stop_workers()
+    {
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            stopping_ = true;
+        }
+        cv_jobs_.notify_all();
+        for (auto& t : workers_) t.join();
+        workers_.clear();
+        for (PartSlot* s : free_parts_) delete s;
+        free_parts_.clear();
+    }
+    PartSlot* take_part(bool wait)
+    {
+        std::unique_lock<std::mutex> lk(m_);
+        if (wait) cv_done_.wait(lk, [&] { return !free_parts_.empty(); });
+        if (free_parts_.empty()) return nullptr;
+        PartSlot* s = free_parts_.back();
+        free_parts_.pop_back();
+        return s;
+    }
+    void give_part(PartSlot* s)
+    {
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            free_parts_.push_back(s);
+        }
+        cv_done_.notify_all();
+    }
+    void issue(PartSlot* s, uint64_t index)
+    {
+        s->found = false;
+        s->decoded = false;
+        const uint64_t first = index == 0 ? pos_ : 8 * index * (uint64_t)part_bytes_;
+        const uint64_t limit = 8 * (index + 1) * (uint64_t)part_bytes_;
+        auto job = [this, s, index, first, limit] {
+            static thread_local blpg::SymbolDecoder decoder;
+            constexpr uint64_t MAX_SYMBOLS = 48ull << 20;
+            if (!cancel_) {
+                uint64_t at = index == 0 ? first : blpg::find_block(map_, size_, first, limit);
+                for (int tries = 0; at != blpg::NPOS && tries < 16 && !cancel_; ++tries) {
+                    if (decoder.run(map_, size_, at, limit, MAX_SYMBOLS, s->part)) {
+                        s->found = true;
+                        break;
+                    }
+                    at = index == 0 ? blpg::NPOS : blpg::find_block(map_, size_, at + 1, limit);
+                }
+            }
+            {
+                std::lock_guard<std::mutex> lk(m_);
+                s->decoded = true;
+            }
+            cv_done_.notify_all();
+        };
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            normal_.push_back(std::move(job));
+        }
+        cv_jobs_.notify_one();
+    }
+    void wait_decoded(PartSlot* s)
+    {
+        std::unique_lock<std::mutex> lk(m_);
+        cv_done_.wait(lk, [&] { return s->decoded; });
+    }
+    void push_window(const uint8_t* text, uint64_t n)
+    {
+        if (n >= blpg::WINDOW) {
+            std::memcpy(window_, text + (n - blpg::WINDOW), blpg::WINDOW);
+        } else {
+            std::memmove(window_, window_ + n, blpg::WINDOW - n);
+            std::memcpy(window_ + (blpg::WINDOW - n), text, n);
+        }
+        known_ = known_ + n >= blpg::WINDOW ? blpg::WINDOW : (uint32_t)(known_ + n);
+    }
+    void note_member_end(uint32_t crc, uint32_t isize)
+    {
+        auto e = std::make_shared<Piece>();
+        e->is_end = true;
+        e->state = 1;
+        e->want_crc = crc;
+        e->want_isize = isize;
+        std::lock_guard<std::mutex> lk(m_);
+        ledger_.push_back(e);
+    }
+    // fold the finished pieces at the front of the ledger into the running CRC; check it where a member ends
+    void settle(bool wait_all)
+    {
+        std::unique_lock<std::mutex> lk(m_);
+        while (!ledger_.empty()) {
+            auto e = ledger_.front();
+            if (e->state == 0) {
+                if (!wait_all) return;
+                cv_done_.wait(lk, [&] { return e->state != 0; });
+            }
+            ledger_.pop_front();
+            if (e->state == 2) failed_ = true;
+            if (e->is_end) {
+                if (run_crc_ != e->want_crc || (uint32_t)run_len_ != e->want_isize) failed_ = true;
+                run_crc_ = 0;
+                run_len_ = 0;
+            } else if (e->len) {
+                run_crc_ = (uint32_t)crc32_combine(run_crc_, e->crc, (z_off_t)e->len);
+                run_len_ += e->len;
+            }
+        }
+    }
+    // the symbols of a part that begins where the stream stands -> chunks of text, made by the pool
+    bool accept(const std::shared_ptr<PartSlot>& ref)
+    {
+        const blpg::Part& part = ref->part;
+        auto window = std::make_shared<std::vector<uint8_t>>(window_, window_ + blpg::WINDOW);
+        const uint32_t known = known_;
+        uint64_t at = 0;
+        size_t next_end = 0;
+        while (at < part.n || next_end < part.ends.size()) {
+            while (next_end < part.ends.size() && part.ends[next_end].out_off == at) {
+                note_member_end(part.ends[next_end].crc, part.ends[next_end].isize);
+                ++next_end;
+            }
+            if (at >= part.n) break;
+            uint64_t stop = at + CHUNK_BYTES < part.n ? at + CHUNK_BYTES : part.n;
+            if (next_end < part.ends.size() && part.ends[next_end].out_off < stop) stop = part.ends[next_end].out_off;
+            auto c = q_.reserve();
+            if (!c) {
+                gone_ = true;
+                return false;
+            }
+            c->bytes = spare_.take();
+            c->bytes.resize(stop - at);
+            auto piece = std::make_shared<Piece>();
+            piece->len = stop - at;
+            const uint64_t from = at;
+            auto job = [this, ref, window, known, c, piece, from] {
+                const bool good = blpg::resolve(ref->part.sym.p + from, piece->len, window->data(), known, c->bytes.data());
+                const uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), c->bytes.data(), (uInt)piece->len);
+                c->ok = good;
+                q_.finish(c);
+                {
+                    std::lock_guard<std::mutex> lk(m_);
+                    piece->crc = crc;
+                    piece->state = good ? 1 : 2;
+                }
+                cv_done_.notify_all();
+            };
+            {
+                std::lock_guard<std::mutex> lk(m_);
+                ledger_.push_back(piece);
+                urgent_.push_back(std::move(job));
+            }
+            cv_jobs_.notify_one();
+            at = stop;
+        }
+        // the window behind this part: its last 32 KiB as text
+        if (part.n >= blpg::WINDOW) {
+            uint8_t tail[blpg::WINDOW];
+            if (!blpg::resolve(part.sym.p + (part.n - blpg::WINDOW), blpg::WINDOW, window_, known_, tail)) failed_ = true;
+            push_window(tail, blpg::WINDOW);
+        } else if (part.n) {
+            std::vector<uint8_t> text(part.n);
+            if (!blpg::resolve(part.sym.p, part.n, window_, known_, text.data())) failed_ = true;
+            push_window(text.data(), part.n);
+        }
+        return !failed_;
+    }
+    // zlib from pos_ on, block by block, until a block begins at or beyond `target` (or the stream ends: done = true).
+    // false: the stream is damaged (failed_) or the consumer has left (gone_).
+    bool by_zlib(uint64_t target, bool& done)
+    {
+        z_stream z;
+        std::memset(&z, 0, sizeof(z));
+        if (inflateInit2(&z, -15) != Z_OK) {
+            failed_ = true;
+            return false;
+        }
+        uint64_t in_at = pos_ >> 3;
+        if (pos_ & 7) {
+            inflatePrime(&z, 8 - (int)(pos_ & 7), map_[in_at] >> (pos_ & 7));
+            ++in_at;
+        }
+        if (known_) inflateSetDictionary(&z, window_ + (blpg::WINDOW - known_), known_);
+        std::shared_ptr<Chunk> c;
+        auto flush = [&]() {  // what has been written to the open chunk goes out
+            if (!c) return;
+            const size_t n = CHUNK_BYTES - z.avail_out;
+            c->bytes.resize(n);
+            auto piece = std::make_shared<Piece>();
+            piece->len = n;
+            piece->crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), c->bytes.data(), (uInt)n);
+            piece->state = 1;
+            zlib_bytes_ += n;
+            push_window(c->bytes.data(), n);
+            {
+                std::lock_guard<std::mutex> lk(m_);
+                ledger_.push_back(piece);
+            }
+            q_.finish(c);
+            c.reset();
+        };
+        bool good = true;
+        for (;;) {
+            if (!c) {
+                c = q_.reserve();
+                if (!c) {
+                    gone_ = true;
+                    good = false;
+                    break;
+                }
+                c->bytes = spare_.take();
+                c->bytes.resize(CHUNK_BYTES);
+                z.next_out = c->bytes.data();
+                z.avail_out = (uInt)CHUNK_BYTES;
+            }
+            if (z.avail_in == 0) {
+                const uint64_t left = size_ - in_at;
+                const uint64_t n = left < (1ull << 30) ? left : (1ull << 30);
+                z.next_in = const_cast<uint8_t*>(map_ + in_at);
+                z.avail_in = (uInt)n;
+            }
+            const uint8_t* before = z.next_in;
+            const int rc = inflate(&z, Z_BLOCK);
+            in_at += (uint64_t)(z.next_in - before);
+            if (rc == Z_STREAM_END) {  // a member's last block: trailer, then another member or the end of the file
+                flush();
+                if (in_at + 8 > size_) {
+                    failed_ = true;
+                    good = false;
+                    break;
+                }
+                auto le32 = [&](uint64_t q) { return (uint32_t)map_[q] | ((uint32_t)map_[q + 1] << 8) | ((uint32_t)map_[q + 2] << 16) | ((uint32_t)map_[q + 3] << 24); };
+                note_member_end(le32(in_at), le32(in_at + 4));
+                in_at += 8;
+                if (in_at == size_) {
+                    pos_ = 8 * size_;
+                    done = true;
+                    break;
+                }
+                const uint64_t data = blpg::skip_member_header(map_, size_, in_at);
+                if (data == blpg::NPOS || inflateReset(&z) != Z_OK) {
+                    failed_ = true;
+                    good = false;
+                    break;
+                }
+                in_at = data;
+                pos_ = 8 * data;
+                z.avail_in = 0;
+                if (pos_ >= target) break;
+                continue;
+            }
+            if (rc != Z_OK && rc != Z_BUF_ERROR) {
+                failed_ = true;
+                good = false;
+                break;
+            }
+            if ((z.data_type & 128) && !(z.data_type & 64)) {  // stopped between two blocks
+                pos_ = 8 * in_at - (uint64_t)(z.data_type & 7);
+                if (pos_ >= target) break;
+            }
+            if (z.avail_out == 0) flush();
+            if (rc == Z_BUF_ERROR && z.avail_in == 0 && in_at == size_) {  // the file ends inside a member
+                failed_ = true;
+                good = false;
+                break;
+            }
+        }
+        if (c) {
+            if (good || CHUNK_BYTES - z.avail_out) {
+                flush();
+            } else {
+                c->bytes.clear();
+                q_.finish(c);
+            }
+        }
+        inflateEnd(&z);
+        return good;
+    }
+};
+
 // The decompressed bytes of one file.
 class ByteSource {
 public:
@@ -347,8 +772,29 @@ private:
         }
         queue_.close();
     }
+    // A regular gzip file of some size goes to the many-threaded decoder; BL_PGZIP=0 keeps it off, BL_PGZIP_PART (bytes) sets
+    // the size of the parts (tests: small parts make many seams).
+    bool inflate_parallel()
+    {
+        const char* off = std::getenv("BL_PGZIP");
+        if (threads_ < 2 || (off && off[0] == '0')) return false;
+        struct stat st;
+        if (fstat(fileno(f_), &st) != 0 || !S_ISREG(st.st_mode)) return false;
+        size_t part = (size_t)2 << 20;
+        if (const char* e = std::getenv("BL_PGZIP_PART")) {
+            const long v = std::atol(e);
+            if (v >= 1024) part = (size_t)v;
+        }
+        if ((uint64_t)st.st_size < 2 * (uint64_t)part) return false;
+        ParallelGzip pg(fileno(f_), (uint64_t)st.st_size, threads_, part, queue_, spare_);
+        return pg.run();
+    }
     void inflate_stream()
     {
+        if (inflate_parallel()) {
+            queue_.close();
+            return;
+        }
         z_stream z;
         std::memset(&z, 0, sizeof(z));
         bool ok = inflateInit2(&z, 15 + 32) == Z_OK;  // gzip or zlib wrapper, detected
