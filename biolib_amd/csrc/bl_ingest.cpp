@@ -5,8 +5,10 @@
 //        plain file      one read-ahead thread
 //        BGZF            (bgzip: gzip members of <= 64 KiB whose header says how long they are) — the members are cut out
 //                        by one thread and inflated by a pool, results delivered in file order: inflate scales with cores
-//        other gzip      one inflate thread running ahead of the parser (a deflate stream has no entry points; concatenated
-//                        members are followed)
+//        other gzip      a deflate stream has no entry points, but a block start can be FOUND and the text decoded from there with
+//                        place holders for what matches copy from the unknown 32 KiB before: ParallelGzip (pieces: bl_pgzip.hpp)
+//                        has a pool decode the file in parts and puts them together in file order; pipes and small files: one
+//                        zlib thread running ahead of the parser.  Concatenated members are followed either way.
 //   2. RecordParser: a line-oriented state machine over the chunks (memchr for line ends, no per-byte loop) that returns
 //      what the reader biolib's tools use returns — the reference's tests/kseq.h:185-234 is the behaviour to match and
 //      tests/test_ingest.py + tests/ingest_fuzz.py (the reference reader as judge) are the gate:
@@ -499,8 +501,12 @@ private:
     bool accept(const std::shared_ptr<PartSlot>& ref)
     {
         const blpg::Part& part = ref->part;
-        auto window = std::make_shared<std::vector<uint8_t>>(window_, window_ + blpg::WINDOW);
-        const uint32_t known = known_;
+        auto table = std::make_shared<blpg::SymbolTable>();
+        table->set(window_);
+        if (known_ < blpg::WINDOW && !blpg::markers_known(part.sym.p, part.n, known_)) {  // (the first 32 KiB of the stream only)
+            failed_ = true;
+            return false;
+        }
         uint64_t at = 0;
         size_t next_end = 0;
         while (at < part.n || next_end < part.ends.size()) {
@@ -521,15 +527,14 @@ private:
             auto piece = std::make_shared<Piece>();
             piece->len = stop - at;
             const uint64_t from = at;
-            auto job = [this, ref, window, known, c, piece, from] {
-                const bool good = blpg::resolve(ref->part.sym.p + from, piece->len, window->data(), known, c->bytes.data());
+            auto job = [this, ref, table, c, piece, from] {
+                blpg::resolve(ref->part.sym.p + from, piece->len, *table, c->bytes.data());
                 const uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), c->bytes.data(), (uInt)piece->len);
-                c->ok = good;
                 q_.finish(c);
                 {
                     std::lock_guard<std::mutex> lk(m_);
                     piece->crc = crc;
-                    piece->state = good ? 1 : 2;
+                    piece->state = 1;
                 }
                 cv_done_.notify_all();
             };
@@ -544,14 +549,14 @@ private:
         // the window behind this part: its last 32 KiB as text
         if (part.n >= blpg::WINDOW) {
             uint8_t tail[blpg::WINDOW];
-            if (!blpg::resolve(part.sym.p + (part.n - blpg::WINDOW), blpg::WINDOW, window_, known_, tail)) failed_ = true;
+            blpg::resolve(part.sym.p + (part.n - blpg::WINDOW), blpg::WINDOW, *table, tail);
             push_window(tail, blpg::WINDOW);
         } else if (part.n) {
             std::vector<uint8_t> text(part.n);
-            if (!blpg::resolve(part.sym.p, part.n, window_, known_, text.data())) failed_ = true;
+            blpg::resolve(part.sym.p, part.n, *table, text.data());
             push_window(text.data(), part.n);
         }
-        return !failed_;
+        return true;
     }
     // zlib from pos_ on, block by block, until a block begins at or beyond `target` (or the stream ends: done = true).
     // false: the stream is damaged (failed_) or the consumer has left (gone_).

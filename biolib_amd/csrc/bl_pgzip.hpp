@@ -476,41 +476,34 @@ private:
     }
 };
 
-// Symbols -> bytes; window[i] = byte i of the 32 KiB before the part (the last byte is window[32767]), of which only the last
-// `known` bytes exist.  false: a marker points before them.
-inline bool resolve(const uint16_t* sym, uint64_t n, const uint8_t* window, uint32_t known, uint8_t* dst)
+// Symbols -> bytes through one table: a byte stands for itself, the marker 0x8000 | i for byte i of the 32 KiB before the part
+// (window[32767] is the last byte before it).
+struct SymbolTable {
+    uint8_t byte[65536];
+    void set(const uint8_t* window)
+    {
+        for (int i = 0; i < 256; ++i) byte[i] = (uint8_t)i;
+        std::memcpy(byte + MARK, window, WINDOW);
+    }
+};
+inline void resolve(const uint16_t* sym, uint64_t n, const SymbolTable& t, uint8_t* dst)
 {
-    const uint32_t first_known = WINDOW - known;
-    bool good = true;
     uint64_t i = 0;
-    for (; i + 16 <= n; i += 16) {
-        uint16_t any = 0;
-        for (int k = 0; k < 16; ++k) any |= sym[i + k];
-        if (!(any & MARK)) {
-            for (int k = 0; k < 16; ++k) dst[i + k] = (uint8_t)sym[i + k];
-        } else {
-            for (int k = 0; k < 16; ++k) {
-                const uint16_t s = sym[i + k];
-                if (s & MARK) {
-                    const uint32_t w = s & 0x7fffu;
-                    good = good && w >= first_known;
-                    dst[i + k] = window[w];
-                } else {
-                    dst[i + k] = (uint8_t)s;
-                }
-            }
-        }
+    for (; i + 4 <= n; i += 4) {
+        const uint8_t a = t.byte[sym[i]], b = t.byte[sym[i + 1]], c = t.byte[sym[i + 2]], d = t.byte[sym[i + 3]];
+        dst[i] = a;
+        dst[i + 1] = b;
+        dst[i + 2] = c;
+        dst[i + 3] = d;
     }
-    for (; i < n; ++i) {
-        const uint16_t s = sym[i];
-        if (s & MARK) {
-            const uint32_t w = s & 0x7fffu;
-            good = good && w >= first_known;
-            dst[i] = window[w];
-        } else {
-            dst[i] = (uint8_t)s;
-        }
-    }
+    for (; i < n; ++i) dst[i] = t.byte[sym[i]];
+}
+// Near the start of the stream only the last `known` bytes of the window exist: does every marker point at one of them?
+inline bool markers_known(const uint16_t* sym, uint64_t n, uint32_t known)
+{
+    const uint16_t first = (uint16_t)(MARK | (WINDOW - known));
+    bool good = true;
+    for (uint64_t i = 0; i < n; ++i) good = good && (sym[i] < MARK || sym[i] >= first);
     return good;
 }
 

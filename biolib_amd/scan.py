@@ -521,7 +521,7 @@ class Reader:
     """FASTA / FASTQ (plain or gzip) reader of the library (bl_reader_*): host records or device batches."""
 
     def __init__(self, path, threads=0, shard=None):
-        """threads: inflate workers for BGZF input (0 = one per core, at most 16); other inputs use one read-ahead thread.
+        """threads: inflate workers for gzip and BGZF input (0 = one per core, at most 16); plain files use one read-ahead thread.
         shard=(rank, world): this reader takes part `rank` of a BGZF file that `world` readers read between them (device
         batches only; the parts' records in rank order are the file's records)"""
         self._lib = capi.lib()

@@ -179,7 +179,9 @@ int bl_ctx_kernel_time(bl_ctx* ctx, double* total_ms, uint64_t* launches);
  * everything but ACGTUacgtu as a break, exactly as the reference table does (constants.hpp:12-21). */
 typedef struct bl_reader bl_reader;
 /* The file is decompressed by background threads that run ahead of the parser: BGZF (bgzip) members are inflated in parallel
- * by `threads` workers (0 = one per core, at most 16), any other gzip stream by one thread, plain files are read ahead. */
+ * by `threads` workers (0 = one per core, at most 16); any other gzip file by the same number of workers that each decode a
+ * part of the ONE deflate stream from a block start they find by themselves, without the 32 KiB of text before it, which is
+ * filled in when the part before is done (pipes and files of a few MiB: one zlib thread); plain files are read ahead. */
 int bl_reader_open(const char* path, bl_reader** out);
 int bl_reader_open_threads(const char* path, int threads, bl_reader** out);
 /* One part of a BGZF file, for several readers (GPUs, ranks) that take one file between them: part `rank` of `world` holds the

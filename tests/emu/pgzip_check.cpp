@@ -64,6 +64,7 @@ int main(int argc, char** argv)
 
     blpg::SymbolDecoder decoder;
     blpg::Part part;
+    static blpg::SymbolTable table;
     const uint64_t n_parts = ((uint64_t)size + part_bytes - 1) / part_bytes;
     uint64_t found = 0, truly = 0, checked = 0;
     std::vector<uint8_t> got;
@@ -92,7 +93,9 @@ int main(int argc, char** argv)
         std::memcpy(window + (blpg::WINDOW - known), text.data() + (off - known), known);
         got.resize(part.n);
         if (off + part.n > text.size()) { std::printf("bad: part %llu runs past zlib's text\n", (unsigned long long)i); return 1; }
-        if (!blpg::resolve(part.sym.p, part.n, window, known, got.data())) { std::printf("bad: part %llu points before the text\n", (unsigned long long)i); return 1; }
+        if (!blpg::markers_known(part.sym.p, part.n, known)) { std::printf("bad: part %llu points before the text\n", (unsigned long long)i); return 1; }
+        table.set(window);
+        blpg::resolve(part.sym.p, part.n, table, got.data());
         if (std::memcmp(got.data(), text.data() + off, part.n) != 0) { std::printf("bad: part %llu differs from zlib's text\n", (unsigned long long)i); return 1; }
         if (!part.at_eof && !starts.count(part.end_bit)) { std::printf("bad: part %llu ends where no block begins\n", (unsigned long long)i); return 1; }
         if (part.at_eof && off + part.n != text.size()) { std::printf("bad: part %llu claims the end of the stream too early\n", (unsigned long long)i); return 1; }

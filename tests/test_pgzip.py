@@ -186,3 +186,21 @@ def test_reader_records_through_many_threads(tmp_path):
     lines = text.split(b"\n")
     assert len(recs) == len(lines) // 4
     assert all(recs[i][1] == lines[4 * i + 1] and recs[i][0] == lines[4 * i][1:].split(b" ")[0].decode() for i in range(0, len(recs), 97))
+
+
+def test_reader_closed_early(tmp_path):
+    """the consumer leaves after the first span: the decoder's threads notice and wind down"""
+    import biolib_amd as B
+
+    _, packed, text = CASES[2]
+    path = tmp_path / "e.fq.gz"
+    path.write_bytes(packed)
+    os.environ["BL_PGZIP_PART"] = "8192"
+    try:
+        for _ in range(5):
+            r = B.Reader(str(path), threads=4)
+            first = next(iter(r.text_spans(1 << 16)))
+            assert text.startswith(first)
+            r.close()
+    finally:
+        os.environ.pop("BL_PGZIP_PART", None)
