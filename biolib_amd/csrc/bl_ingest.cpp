@@ -50,6 +50,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include "../../include/biolib_amd.h"
+#include "bl_crc32.hpp"
 #include "bl_pgzip.hpp"
 
 extern int bl_set_error(int code, const char* msg);  // bl_capi.hip
@@ -211,7 +212,7 @@ private:
         const int rc = inflate(&z, Z_FINISH);
         const bool good = (rc == Z_STREAM_END) && z.total_out == isize;
         inflateEnd(&z);
-        return good && (uint32_t)crc32(crc32(0L, Z_NULL, 0), out.data() + at, isize) == want_crc;
+        return good && bl_crc32(0, out.data() + at, isize) == want_crc;
     }
     void run()
     {
@@ -289,7 +290,11 @@ public:
             }
             PartSlot* s = flying.front();
             flying.pop_front();
-            wait_decoded(s);
+            {
+                const uint64_t t0 = now_us();
+                wait_decoded(s);
+                us_wait_part_ += now_us() - t0;
+            }
             std::shared_ptr<PartSlot> ref(s, [this](PartSlot* x) { give_part(x); });
             if (!s->found || s->part.start_bit < pos_) {  // nothing found in this part, or the stream is past it already
                 ++(s->found ? n_missed_ : n_none_);
@@ -329,11 +334,16 @@ public:
             std::fprintf(stderr, "[pgzip] %llu parts of %zu bytes: %llu taken as found, %llu without a find, %llu not reached; text by the pool %llu bytes, by zlib %llu bytes\n",
                          (unsigned long long)n_parts, part_bytes_, (unsigned long long)n_taken_, (unsigned long long)n_none_, (unsigned long long)n_missed_,
                          (unsigned long long)pool_bytes_, (unsigned long long)zlib_bytes_);
+        if (std::getenv("BL_INGEST_TRACE"))
+            std::fprintf(stderr, "[pgzip] pool: find %.3f s, decode %.3f s, text + crc %.3f s; this thread waited %.3f s for parts, %.3f s for room in the queue\n",
+                         us_find_ * 1e-6, us_decode_ * 1e-6, us_text_ * 1e-6, us_wait_part_ * 1e-6, us_wait_queue_ * 1e-6);
         return true;
     }
 
 private:
     uint64_t n_taken_ = 0, n_none_ = 0, n_missed_ = 0, pool_bytes_ = 0, zlib_bytes_ = 0;  // (trace)
+    std::atomic<uint64_t> us_find_{0}, us_decode_{0}, us_text_{0}, us_wait_part_{0}, us_wait_queue_{0};
+    static uint64_t now_us() { return (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
     struct PartSlot {
         blpg::Part part;
         bool found = false;
@@ -429,9 +439,14 @@ private:
             static thread_local blpg::SymbolDecoder decoder;
             constexpr uint64_t MAX_SYMBOLS = 48ull << 20;
             if (!cancel_) {
+                uint64_t t0 = now_us();
                 uint64_t at = index == 0 ? first : blpg::find_block(map_, size_, first, limit);
+                us_find_ += now_us() - t0;
                 for (int tries = 0; at != blpg::NPOS && tries < 16 && !cancel_; ++tries) {
-                    if (decoder.run(map_, size_, at, limit, MAX_SYMBOLS, s->part)) {
+                    t0 = now_us();
+                    const bool good = decoder.run(map_, size_, at, limit, MAX_SYMBOLS, s->part);
+                    us_decode_ += now_us() - t0;
+                    if (good) {
                         s->found = true;
                         break;
                     }
@@ -517,19 +532,23 @@ private:
             if (at >= part.n) break;
             uint64_t stop = at + CHUNK_BYTES < part.n ? at + CHUNK_BYTES : part.n;
             if (next_end < part.ends.size() && part.ends[next_end].out_off < stop) stop = part.ends[next_end].out_off;
+            const uint64_t t0 = now_us();
             auto c = q_.reserve();
+            us_wait_queue_ += now_us() - t0;
             if (!c) {
                 gone_ = true;
                 return false;
             }
-            c->bytes = spare_.take();
-            c->bytes.resize(stop - at);
             auto piece = std::make_shared<Piece>();
             piece->len = stop - at;
             const uint64_t from = at;
             auto job = [this, ref, table, c, piece, from] {
+                const uint64_t t0 = now_us();
+                c->bytes = spare_.take();
+                c->bytes.resize(piece->len);  // (clears it: better here than on the one thread that orders the parts)
                 blpg::resolve(ref->part.sym.p + from, piece->len, *table, c->bytes.data());
-                const uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), c->bytes.data(), (uInt)piece->len);
+                const uint32_t crc = bl_crc32(0, c->bytes.data(), piece->len);
+                us_text_ += now_us() - t0;
                 q_.finish(c);
                 {
                     std::lock_guard<std::mutex> lk(m_);
@@ -581,7 +600,7 @@ private:
             c->bytes.resize(n);
             auto piece = std::make_shared<Piece>();
             piece->len = n;
-            piece->crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), c->bytes.data(), (uInt)n);
+            piece->crc = bl_crc32(0, c->bytes.data(), n);
             piece->state = 1;
             zlib_bytes_ += n;
             push_window(c->bytes.data(), n);

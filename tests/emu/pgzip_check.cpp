@@ -12,12 +12,39 @@
 #include <cstdio>
 #include <cstdlib>
 #include <map>
+#include <string>
 #include <vector>
 
+#include "../../biolib_amd/csrc/bl_crc32.hpp"
 #include "../../biolib_amd/csrc/bl_pgzip.hpp"
+
+// pgzip_check --crc: bl_crc32 against zlib's crc32 on every short length, start offset and two start values, and on long buffers
+static int check_crc()
+{
+    std::vector<uint8_t> d((1u << 22) + 64);
+    uint64_t s = 88172645463325252ull;
+    for (auto& b : d) {
+        s ^= s << 13; s ^= s >> 7; s ^= s << 17;
+        b = (uint8_t)s;
+    }
+    for (size_t n = 0; n < 600; ++n)
+        for (size_t off = 0; off < 17; ++off)
+            for (uint32_t c : {0u, 0xdeadbeefu})
+                if ((uint32_t)crc32(c, d.data() + off, (uInt)n) != bl_crc32(c, d.data() + off, n)) { std::printf("bad: crc of %zu bytes at offset %zu\n", n, off); return 1; }
+    for (size_t n : {1000ul, 4096ul, 65536ul, 1000003ul, (1ul << 22)})
+        for (size_t off : {0ul, 1ul, 15ul})
+            if ((uint32_t)crc32(7, d.data() + off, (uInt)n) != bl_crc32(7, d.data() + off, n)) { std::printf("bad: crc of %zu bytes\n", n); return 1; }
+#if defined(__x86_64__)
+    std::printf("ok crc clmul=%d\n", (int)blcrc::have_clmul());
+#else
+    std::printf("ok crc clmul=0\n");
+#endif
+    return 0;
+}
 
 int main(int argc, char** argv)
 {
+    if (argc == 2 && std::string(argv[1]) == "--crc") return check_crc();
     if (argc < 3) return 2;
     FILE* f = std::fopen(argv[1], "rb");
     if (!f) return 2;

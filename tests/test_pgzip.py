@@ -95,6 +95,11 @@ def test_pieces_against_zlib(checker, tmp_path, name, packed, text):
             assert int(fields["text"]) > 0.9 * len(text)  # nearly all of it was decoded by parts
 
 
+def test_crc32_by_carryless_multiplication_equals_zlib(checker):
+    out = subprocess.run([checker, "--crc"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and out.stdout.startswith("ok crc"), out.stdout + out.stderr[-2000:]
+
+
 def test_pieces_survive_damage(checker, tmp_path):
     rng = np.random.default_rng(11)
     _, packed, _ = CASES[1]
