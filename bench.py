@@ -350,7 +350,8 @@ def other_configs(ctx, args, model):
 
 def next_rows(ctx):
     """Driver-timed numbers for the rows SURVEY.md §8(f) marks "next" (they are not the headline and cannot fail it): the
-    partitioned k-mer counter's chain on one GPU and the device-side BGZF inflate, each on a small synthetic workload."""
+    partitioned k-mer counter's chain on one GPU, the device-side BGZF inflate and the ingest of a plain gzip file, each on a small
+    synthetic workload."""
     import struct, zlib
     import numpy as np
     import torch
@@ -420,6 +421,28 @@ def next_rows(ctx):
                                "workload": "FASTQ text (binned qualities), zlib level 6, 65280-byte BGZF members, inflate + CRC-32 on the device"}
     except Exception as e:
         res["bgzf_inflate"] = {"error": repr(e)[:200]}
+    try:  # a plain gzip file (ONE deflate stream per member, no BGZF) -> device batches: the host decodes the stream in parts on all its cores
+        import tempfile
+        packed = zlib.compressobj(6, zlib.DEFLATED, 31)
+        packed = packed.compress(text) + packed.flush()
+        times = 6  # the member six times over (gzip members concatenate): ~370 MB of text
+        with tempfile.TemporaryDirectory() as d:
+            path = os.path.join(d, "reads.fq.gz")
+            with open(path, "wb") as f:
+                f.write(packed * times)
+            r = B.Reader(path)
+            ctx.sync(); t0 = time.perf_counter()
+            n_seqs = n_bases = 0
+            for batch in r.device_batches(ctx):
+                n_seqs += batch.n_seqs; n_bases += batch.n_bases
+                batch.close()
+            ctx.sync(); dt = time.perf_counter() - t0
+            r.close()
+        res["gzip_ingest"] = {"value": round(n_bases / dt / 1e9, 2), "unit": "Gbp/s", "text_GB_per_s": round(len(text) * times / dt / 1e9, 2), "host_threads": min(16, os.cpu_count() or 4),
+                              "reads_and_bases_as_written": bool(n_seqs == n_reads * times and n_bases == n_reads * L * times),
+                              "workload": f"{n_reads * times} reads x {L} bp FASTQ as one `zlib level 6` gzip file of {times} members ({len(packed) * times / 1e6:.0f} MB), decoded by the host's cores in parts, parsed on the device"}
+    except Exception as e:
+        res["gzip_ingest"] = {"error": repr(e)[:200]}
     return res
 
 
