@@ -84,6 +84,15 @@ public:
         v.clear();
         return v;
     }
+    // the same with its old contents and size: a resize() to about that size then writes nothing
+    std::vector<unsigned char> take_as_is()
+    {
+        std::lock_guard<std::mutex> lk(m_);
+        if (spare_.empty()) return {};
+        std::vector<unsigned char> v = std::move(spare_.back());
+        spare_.pop_back();
+        return v;
+    }
     void give(std::vector<unsigned char>&& v)
     {
         if (v.capacity() == 0) return;
@@ -544,8 +553,8 @@ private:
             const uint64_t from = at;
             auto job = [this, ref, table, c, piece, from] {
                 const uint64_t t0 = now_us();
-                c->bytes = spare_.take();
-                c->bytes.resize(piece->len);  // (clears it: better here than on the one thread that orders the parts)
+                c->bytes = spare_.take_as_is();
+                c->bytes.resize(piece->len);  // (a new buffer is cleared by this: better here than on the one thread that orders the parts)
                 blpg::resolve(ref->part.sym.p + from, piece->len, *table, c->bytes.data());
                 const uint32_t crc = bl_crc32(0, c->bytes.data(), piece->len);
                 us_text_ += now_us() - t0;
