@@ -742,18 +742,29 @@ public:
     // a plain file whose chunk threads have not been started can be read straight into the caller's buffer (the text spans
     // do: one copy less on the path of an uncompressed file).  -1 on a read error.
     bool can_read_direct() const { return kind_[0] == 'p' && !started_; }
+    // a plain file of which only the bytes [first, end) are this reader's (bl_reader_open_shard); before the first read
+    void set_range(uint64_t first, uint64_t end)
+    {
+        range_first_ = first;
+        range_end_ = end;
+    }
     long read_direct(void* dst, size_t want)
     {
         // large requests are cut in four and read side by side (pread at explicit offsets): one thread copies out of the page
         // cache at ~10 GB/s, which is less than the H2D link takes
         if (direct_off_ == (uint64_t)-1) {
             struct stat st;
-            if (fstat(fileno(f_), &st) != 0 || !S_ISREG(st.st_mode)) direct_size_ = 0;  // not a regular file: plain fread below
-            else direct_size_ = (uint64_t)st.st_size;
-            direct_off_ = 0;
+            direct_regular_ = fstat(fileno(f_), &st) == 0 && S_ISREG(st.st_mode);  // anything else: plain fread below
+            direct_size_ = !direct_regular_ ? 0 : ((uint64_t)st.st_size < range_end_ ? (uint64_t)st.st_size : range_end_);
+            direct_off_ = range_first_;
         }
-        if (direct_size_ == 0 || want < ((size_t)8 << 20)) {
-            if (direct_size_ && std::fseek(f_, (long)direct_off_, SEEK_SET) != 0) return -1;
+        if (!direct_regular_ || want < ((size_t)8 << 20)) {
+            if (direct_regular_) {
+                const uint64_t left = direct_off_ < direct_size_ ? direct_size_ - direct_off_ : 0;
+                if (want > left) want = (size_t)left;
+                if (want == 0) return 0;
+                if (std::fseek(f_, (long)direct_off_, SEEK_SET) != 0) return -1;
+            }
             const size_t n = std::fread(dst, 1, want, f_);
             if (n < want && std::ferror(f_)) return -1;
             direct_off_ += n;
@@ -791,14 +802,21 @@ public:
 private:
     void read_plain()
     {
+        uint64_t left = ~0ULL;  // (a reader of one part of the file: its bytes only)
+        if (range_first_ || range_end_ != ~0ULL) {
+            left = range_end_ > range_first_ ? range_end_ - range_first_ : 0;
+            if (std::fseek(f_, (long)range_first_, SEEK_SET) != 0) left = 0;
+        }
         for (;;) {
             auto c = queue_.reserve();
             if (!c) return;
             c->bytes = spare_.take();
             c->bytes.resize(CHUNK_BYTES);
-            const size_t n = std::fread(c->bytes.data(), 1, CHUNK_BYTES, f_);
+            const size_t want = left < CHUNK_BYTES ? (size_t)left : CHUNK_BYTES;
+            const size_t n = want ? std::fread(c->bytes.data(), 1, want, f_) : 0;
             c->bytes.resize(n);
-            if (n < CHUNK_BYTES && std::ferror(f_)) c->ok = false;
+            if (n < want && std::ferror(f_)) c->ok = false;
+            left -= n;
             const bool last = n < CHUNK_BYTES;
             queue_.finish(c);
             if (last) break;
@@ -918,7 +936,9 @@ private:
     const char* kind_ = "plain";
     int threads_;
     bool started_ = false;
-    uint64_t direct_off_ = (uint64_t)-1, direct_size_ = 0;  // read_direct: where the next read starts, size of the (regular) file
+    uint64_t direct_off_ = (uint64_t)-1, direct_size_ = 0;  // read_direct: where the next read starts, where the reads end (regular file)
+    bool direct_regular_ = false;
+    uint64_t range_first_ = 0, range_end_ = ~0ULL;          // the reader's part of a plain file
 };
 
 inline bool is_blank(int c) { return c == ' ' || (c >= '\t' && c <= '\r'); }  // isspace() of the C locale
@@ -1738,14 +1758,47 @@ int bl_reader_open_shard(const char* path, uint32_t rank, uint32_t world, bl_rea
         *out = nullptr;
         return bl_set_error(BL_ERR_INVALID, msg);
     };
-    if (r->source->kind()[0] != 'b') return fail_close("reading a file in parts needs BGZF (bgzip): its members are the entry points");
+    if (r->source->kind()[0] == 'g') return fail_close("reading a file in parts needs plain text or BGZF (bgzip): one gzip stream has no entry points");
     const int fd = open(path, O_RDONLY);
     struct stat st;
-    if (fd < 0 || fstat(fd, &st) != 0) {
+    if (fd < 0 || fstat(fd, &st) != 0 || !S_ISREG(st.st_mode)) {
         if (fd >= 0) close(fd);
-        return fail_close("cannot stat the file");
+        return fail_close("cannot stat the file (a regular file is needed)");
     }
     const uint64_t size = (uint64_t)st.st_size;
+    if (r->source->kind()[0] == 'p') {
+        // plain text: the parts are byte ranges that meet where a record begins — the first one a reader can recognise from
+        // the text behind size / world * rank alone (first_record_start), which both neighbours work out the same way
+        char first = 0;
+        const bool has_text = pread(fd, &first, 1, 0) == 1;
+        const char fmt = first == '@' ? 'q' : 'a';
+        bool io_ok = true;
+        auto boundary = [&](uint64_t from) -> uint64_t {
+            if (from == 0) return 0;
+            std::vector<char> w;
+            for (size_t look = (size_t)1 << 20; from < size; look *= 4) {
+                const size_t n = (size_t)(size - from < look ? size - from : look);
+                w.resize(n);
+                size_t got = 0;
+                while (got < n) {
+                    const ssize_t g = pread(fd, w.data() + got, n - got, (off_t)(from + got));
+                    if (g <= 0) { io_ok = false; return size; }
+                    got += (size_t)g;
+                }
+                const size_t at = first_record_start(w.data(), n, fmt);
+                if (at != 0 && at != (size_t)-1) return from + at;
+                if (n == size - from) break;  // the rest of the file holds no further record start
+            }
+            return size;
+        };
+        r->shard_start = has_text ? boundary(size / world * rank) : 0;
+        r->shard_end = !has_text ? 0 : (rank + 1 == world ? size : boundary(size / world * (rank + 1)));
+        close(fd);
+        if (!io_ok) return fail_close("cannot read the file");
+        r->shard_first = rank == 0;
+        r->source->set_range(r->shard_start, r->shard_end);
+        return BL_OK;
+    }
     r->sharded = true;
     r->shard_first = rank == 0;
     r->shard_start = rank == 0 ? 0 : member_boundary_from(fd, size / world * rank, size);

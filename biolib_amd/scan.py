@@ -522,8 +522,8 @@ class Reader:
 
     def __init__(self, path, threads=0, shard=None):
         """threads: inflate workers for gzip and BGZF input (0 = one per core, at most 16); plain files use one read-ahead thread.
-        shard=(rank, world): this reader takes part `rank` of a BGZF file that `world` readers read between them (device
-        batches only; the parts' records in rank order are the file's records)"""
+        shard=(rank, world): this reader takes part `rank` of a plain or BGZF file that `world` readers read between them (BGZF:
+        device batches only; the parts' records in rank order are the file's records)"""
         self._lib = capi.lib()
         h = C.c_void_p()
         if shard is not None:

@@ -18,7 +18,7 @@ def shard_reads(n_reads, world_size, rank):
 
 
 def file_shard_reader(path, rank=None, world_size=None):
-    """A Reader of this rank's part of a bgzip'ed FASTA / FASTQ file that all ranks read between them (bl_reader_open_shard): no
+    """A Reader of this rank's part of a plain or bgzip'ed FASTA / FASTQ file that all ranks read between them (bl_reader_open_shard): no
     rank reads the whole file, none talks to another, and the parts' records in rank order are the file's records.  rank /
     world_size default to the initialised torch.distributed group (1 rank otherwise)."""
     from .scan import Reader

@@ -184,12 +184,14 @@ typedef struct bl_reader bl_reader;
  * filled in when the part before is done (pipes and files of a few MiB: one zlib thread); plain files are read ahead. */
 int bl_reader_open(const char* path, bl_reader** out);
 int bl_reader_open_threads(const char* path, int threads, bl_reader** out);
-/* One part of a BGZF file, for several readers (GPUs, ranks) that take one file between them: part `rank` of `world` holds the
+/* One part of a file, for several readers (GPUs, ranks) that take one file between them.  A PLAIN text file: part `rank` is the
+ * byte range from the first record start that can be recognised in the text behind byte size / world * rank (a line that opens a
+ * record, a newline in front of it) to the next part's; every call of the reader works on such a part.  A BGZF file: part `rank` holds the
  * members from the first member boundary at or behind byte size / world * rank to the next part's, and delivers the records that
  * BEGIN in its text — from the first record start that can be recognised there (a line that opens a record, a newline in front of
  * it inside the part's text) to the place where the next part's reader finds its own, found by inflating into the next part.
  * The parts' records, in rank order, are the file's records; the readers do not talk to each other.  Device batches only
- * (bl_reader_next_batch_device); BL_ERR_INVALID for anything but BGZF.  This is how north_star's "shard by read" reaches the
+ * (bl_reader_next_batch_device) from a BGZF part.  BL_ERR_INVALID for a gzip file that is not BGZF (one stream, no entry points).  This is how north_star's "shard by read" reaches the
  * file: the reference's drivers read one file per process (tests/test_kmer_view.cpp:23-42). */
 int bl_reader_open_shard(const char* path, uint32_t rank, uint32_t world, bl_reader** out);
 /* the bytes of the file whose members are the reader's own: [first_byte, end_byte), end_byte = UINT64_MAX for the last part

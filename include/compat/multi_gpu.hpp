@@ -86,7 +86,7 @@ class multi_gpu
                 return bl_scan_minimizers(c, b, first, n, unit, w, hash_seed, canonical ? (uint32_t)BL_FLAG_CANONICAL : 0u, nullptr, nullptr, nullptr, 0, r);
             });
         }
-        // the same scans over a bgzip'ed FASTA / FASTQ FILE that the devices read between them: every device thread opens its own
+        // the same scans over a plain or bgzip'ed FASTA / FASTQ FILE that the devices read between them: every device thread opens its own
         // part(s) of the file (bl_reader_open_shard: parts begin and end at record starts that each reader recognises by itself),
         // inflates and parses them on its GPU and scans batch after batch.  xor_pos is folded over positions relative to each
         // batch and means nothing here; count, xor_value and xor_hash do not depend on how the file was cut.

@@ -469,16 +469,8 @@ def test_shard_ranges_are_member_boundaries(tmp_path):
         biolib_amd.Reader(tmp_path / "g.gz", shard=(0, 2))
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("kind", ["fastq", "fasta", "fastq_long"])
-def test_bgzf_file_read_in_parts(tmp_path, kind):
-    """one BGZF file read by `world` readers that take a part each (bl_reader_open_shard): the parts' sequences, in rank order,
-    are the file's sequences — whatever the number of parts (more parts than members included), the span size, and wherever the
-    member boundaries fall inside the records; the readers never see each other"""
-    import biolib_amd
-
-    ctx = biolib_amd.Context(0)
-    rng = np.random.default_rng(31)
+def _parts_text(kind, rng):
+    """(sequences, file text) of the files that are read in parts"""
     if kind == "fastq":
         seqs = [O.synth(500 + i, int(n)).tobytes() for i, n in enumerate(rng.integers(1, 400, 6000))]
         first = [b"@", b"+", b"I", b"@", b">"]
@@ -491,6 +483,55 @@ def test_bgzf_file_read_in_parts(tmp_path, kind):
         lens = [1, 69, 70, 71, 5000, 400_000, 3, 150_000, 12] + [int(x) for x in rng.integers(1, 3000, 300)]
         seqs = [O.synth(700 + i, n).tobytes() for i, n in enumerate(lens)]
         text = b"".join(b">c%d x>y\n" % i + b"\n".join(s[j:j + 70] for j in range(0, len(s), 70)) + b"\n" for i, s in enumerate(seqs))
+    return seqs, text
+
+
+@pytest.mark.parametrize("kind", ["fastq", "fasta", "fastq_long"])
+def test_plain_file_read_in_parts(tmp_path, kind):
+    """CPU: a plain FASTA / FASTQ file read by `world` readers that take a byte range each (bl_reader_open_shard): the ranges
+    follow each other, meet at record starts, and the parts' records and text, in rank order, are the file's"""
+    import biolib_amd
+
+    seqs, text = _parts_text(kind, np.random.default_rng(31))
+    path = tmp_path / "plain.txt"
+    path.write_bytes(text)
+    line_starts = {0} | {i + 1 for i in range(len(text)) if text[i:i + 1] == b"\n"} if len(text) < 3_000_000 else None
+    for world in (1, 2, 3, 5, 8, 40, 5000):
+        recs, spans, prev_end = [], [], 0
+        for rank in range(world):
+            r = biolib_amd.Reader(path, shard=(rank, world))
+            a, b = r.shard_range
+            assert a == prev_end and b >= a and (rank + 1 < world or b == len(text)), (world, rank, a, b)
+            assert a == len(text) or text[a:a + 1] == (b"@" if kind != "fasta" else b">")
+            if line_starts is not None:
+                assert a in line_starts or a == len(text)
+            prev_end = b
+            if world <= 40:
+                recs += [s for _, s in r.records()]
+                r.close()
+                r = biolib_amd.Reader(path, shard=(rank, world))
+                spans += list(r.text_spans(1 << 16))
+            r.close()
+        if world <= 40:
+            assert recs == seqs and b"".join(spans) == text, (kind, world)
+    (tmp_path / "empty.fa").write_bytes(b"")
+    for rank in range(3):
+        r = biolib_amd.Reader(tmp_path / "empty.fa", shard=(rank, 3))
+        assert r.shard_range == (0, 0) and list(r.records()) == []
+        r.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["fastq", "fasta", "fastq_long"])
+def test_bgzf_file_read_in_parts(tmp_path, kind):
+    """one BGZF file read by `world` readers that take a part each (bl_reader_open_shard): the parts' sequences, in rank order,
+    are the file's sequences — whatever the number of parts (more parts than members included), the span size, and wherever the
+    member boundaries fall inside the records; the readers never see each other"""
+    import biolib_amd
+
+    ctx = biolib_amd.Context(0)
+    rng = np.random.default_rng(31)
+    seqs, text = _parts_text(kind, rng)
     whole = b"".join(seqs)
     for block, eof in ((60000, True), (7001, False)):
         path = tmp_path / f"parts_{block}.gz"
@@ -512,12 +553,22 @@ def test_bgzf_file_read_in_parts(tmp_path, kind):
             assert n_seqs == len(seqs) and sum(sizes) == len(whole)
             if world in (2, 3) and kind == "fastq":  # (short reads: the parts are cut close to the byte targets)
                 assert min(sizes) > 0.5 * len(whole) / world  # the parts are about equal
-    # a sharded reader refuses the host calls; anything but BGZF refuses to be read in parts
+    # a reader of one part of a BGZF file refuses the host calls
     r = biolib_amd.Reader(path, shard=(0, 2))
     with pytest.raises(biolib_amd.BiolibError):
         list(r.records())
-    plain = tmp_path / "plain.fq"
-    plain.write_bytes(text[:1000])
-    with pytest.raises(biolib_amd.BiolibError):
-        biolib_amd.Reader(plain, shard=(0, 2))
+    r.close()
+    # the same file as plain text, read in parts into device batches
+    plain = tmp_path / "plain.txt"
+    plain.write_bytes(text)
+    for world, limit in ((1, 0), (3, 256 << 10), (8, 0), (40, 64 << 10)):
+        got, n_seqs = [], 0
+        for rank in range(world):
+            r = biolib_amd.Reader(plain, shard=(rank, world))
+            for b in r.device_batches(ctx, limit):
+                got.append(bytes(b.download()))
+                n_seqs += b.n_seqs
+                b.close()
+            r.close()
+        assert b"".join(got) == whole and n_seqs == len(seqs), (kind, world)
     ctx.close()
