@@ -112,6 +112,20 @@ int main()
                   (unsigned long long)node.bases_read());
         }
         std::remove(path.c_str());
+        // the same reads as a plain file: the parts are byte ranges that meet at record starts
+        const std::string plain = "/tmp/bl_multi_gpu_test.fq";
+        {
+            FILE* f = std::fopen(plain.c_str(), "wb");
+            CHECK(f && std::fwrite(text.data(), 1, text.size(), f) == text.size(), "write %s", plain.c_str());
+            if (f) std::fclose(f);
+        }
+        for (int parts : {1, 4}) {
+            auto got = node.minimizers_file(plain, 31, 11, 42, true, parts);
+            CHECK(got.count == dg[0] && got.xor_value == dg[1] && got.xor_hash == dg[2] && node.bases_read() == n_reads * L,
+                  "plain file in %d part(s) per device: %llu minimizers vs %llu, %llu bases", parts, (unsigned long long)got.count, (unsigned long long)dg[0],
+                  (unsigned long long)node.bases_read());
+        }
+        std::remove(plain.c_str());
     }
     // synthetic shards on the devices (BASELINE C5's shape, small): per-device counts add up; device 0's shard = the oracle's seed
     {
