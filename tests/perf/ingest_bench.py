@@ -28,11 +28,33 @@ n_reads = int(sys.argv[1]) if len(sys.argv) > 1 else 4_000_000
 threads = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 repeat = int(sys.argv[3]) if len(sys.argv) > 3 else 4  # the files hold the reads this many times over (records, gzip and BGZF members
                                                         # all concatenate): a few GB, so that the readers' start-up does not dominate
-seq = O.synth(42, n_reads * 150).reshape(n_reads, 150)
-res = {"workload": f"{n_reads * repeat} reads x 150 bp FASTQ ({n_reads * repeat * 150 / 1e6:.0f} Mbp: {n_reads} reads, {repeat} times over)",
-       "inflate_threads": threads or "one per core (max 16)", "Gbp_per_s": {}}
-with tempfile.TemporaryDirectory() as d:
+LONG = len(sys.argv) > 4 and sys.argv[4] == "long"     # long reads instead: log-normal lengths (median 8 kbp, a tail beyond 100 kbp),
+                                                        # qualities over the whole printable range, one base in 2,000 an N
+if LONG:
+    rng = np.random.default_rng(7)
+    total = n_reads * 150
+    lens = []
+    while sum(lens) < total:
+        lens += [int(x) for x in np.clip(rng.lognormal(np.log(8000), 0.9, 4096), 200, 400_000)]
+    cut = int(np.searchsorted(np.cumsum(lens), total))  # the first read that reaches the total: shortened to end there
+    lens = lens[:cut + 1]
+    lens[-1] -= sum(lens) - total
+    flat = O.synth(42, total)
+    flat[rng.integers(0, total, total // 2000)] = ord("N")
+    offs = np.concatenate([[0], np.cumsum(lens)])
+    text = b"".join(b"@read%d runid=0123456789abcdef ch=%d\n" % (i, i % 512) + flat[offs[i]:offs[i + 1]].tobytes() + b"\n+\n" +
+                    rng.integers(33, 91, lens[i], dtype=np.uint8).tobytes() + b"\n" for i in range(len(lens)))
+    n_bases_file = total
+    res = {"workload": f"{len(lens) * repeat} long reads ({total * repeat / 1e6:.0f} Mbp: log-normal lengths, median {int(np.median(lens))} bp, longest {max(lens)} bp; "
+                       f"{len(lens)} reads, {repeat} times over), random qualities, 0.05 % N",
+           "inflate_threads": threads or "one per core (max 16)", "Gbp_per_s": {}}
+else:
+    seq = O.synth(42, n_reads * 150).reshape(n_reads, 150)
     text = b"".join(b"@r%d\n" % i + seq[i].tobytes() + b"\n+\n" + b"I" * 150 + b"\n" for i in range(n_reads))
+    n_bases_file = n_reads * 150
+    res = {"workload": f"{n_reads * repeat} reads x 150 bp FASTQ ({n_reads * repeat * 150 / 1e6:.0f} Mbp: {n_reads} reads, {repeat} times over)",
+           "inflate_threads": threads or "one per core (max 16)", "Gbp_per_s": {}}
+with tempfile.TemporaryDirectory() as d:
     files = {"plain": os.path.join(d, "r.fq"), "gzip": os.path.join(d, "r.fq.gz"), "bgzf": os.path.join(d, "r.bgzf.gz")}
     with open(files["plain"], "wb") as f:
         for _ in range(repeat):
@@ -53,7 +75,7 @@ with tempfile.TemporaryDirectory() as d:
                 cnt += batch.minimizers_raw(31, 11, 42, B.FLAG_CANONICAL | B.FLAG_SYNC).count
                 batch.close()
             dt = time.perf_counter() - t0
-            assert nb == n_reads * repeat * 150
+            assert nb == n_bases_file * repeat
             want = cnt if want is None else want
             assert cnt == want
             res["Gbp_per_s"][f"{form}/{mode}"] = round(nb / dt / 1e9, 3)
