@@ -152,7 +152,8 @@ constexpr int CT_SLOTS = 1024;  // table slots of ONE WAVE
 constexpr int CT_CAP = 700;     // k-mers a bucket may hold to be counted in the table (load <= 0.68)
 constexpr int CT_RECS = 64;     // records a bucket may hold (one per lane)
 constexpr int CT_WIDE = 2;      // k-mers a lane inserts per round
-constexpr int CT_WAVES = 2;     // waves per workgroup (14.4 KB of LDS per wave: 5 workgroups = 10 waves per CU)
+constexpr int CT_WAVES = 2;     // waves per workgroup (12.4 KB of LDS per wave: 6 workgroups = 12 waves per CU)
+static_assert(CT_CAP < 65536, "counts are kept in 16 bits");
 constexpr unsigned long long CT_EMPTY = ~0ULL;  // never a k-mer for k < 32, nor a canonical 32-mer (its reverse complement is 0)
 
 __device__ __forceinline__ unsigned long long mmer_at(unsigned long long hi, unsigned long long lo, int pos, int m)
@@ -208,7 +209,7 @@ __device__ unsigned long long bl_count_stamps[8];
 
 struct WaveTable {
     unsigned long long keys[CT_SLOTS];
-    unsigned int cnt[CT_SLOTS];
+    unsigned int cnt[CT_SLOTS / 2];  // 16 bits per slot (a bucket holds at most CT_CAP k-mers): slot h is half h & 1 of word h >> 1
     ulonglong2 recs[CT_RECS];
     unsigned short work[CT_CAP + 4];  // k-mer j of the bucket = k-mer (entry & 31) of record (entry >> 5)
 };
@@ -251,7 +252,7 @@ __device__ __forceinline__ void table_insert_many(WaveTable& t, const unsigned l
     }
 #pragma unroll
     for (int i = 0; i < W; ++i)
-        if (live[i]) atomicAdd(&t.cnt[h[i]], 1u);
+        if (live[i]) atomicAdd(&t.cnt[h[i] >> 1], 1u << (16 * (h[i] & 1u)));
 }
 
 __device__ __forceinline__ unsigned long long kmer_of(ulonglong2 r, int q, int k, int canonical, unsigned long long kmask)
@@ -337,7 +338,7 @@ __device__ __forceinline__ void count_one_bucket(WaveTable& t, int lane, uint32_
 #pragma unroll
     for (int i = 0; i < CT_SLOTS / 64; ++i) {
         t.keys[i * 64 + lane] = CT_EMPTY;
-        t.cnt[i * 64 + lane] = 0;
+        if (i < CT_SLOTS / 128) t.cnt[i * 64 + lane] = 0;
     }
     unsigned int size = 0;
     if ((uint32_t)lane < n_rec) {
@@ -377,18 +378,28 @@ __device__ __forceinline__ void count_one_bucket(WaveTable& t, int lane, uint32_
     }
     wave_lds_sync();
     STAMP(3);  // k-mers inserted
-    // occupied slots (lane l owns slots 16 l .. 16 l + 15)
-    unsigned int occ = 0;
+    // occupied slots, 64 consecutive ones per round (lane l looks at slot 64 i + l: no bank conflict), ranked by ballot: the
+    // bucket's k-mers leave in slot order and the lanes of a round write NEIGHBOURING output positions
+    unsigned int cnt[CT_SLOTS / 64];
+    unsigned long long key[CT_SLOTS / 64];
+    unsigned long long occupied[CT_SLOTS / 64];
+    unsigned int d = 0;
 #pragma unroll
-    for (int i = 0; i < CT_SLOTS / 64; ++i) occ += t.cnt[lane * (CT_SLOTS / 64) + i] != 0;
-    const unsigned int oincl = wave_incl_scan(occ, lane);
+    for (int i = 0; i < CT_SLOTS / 64; ++i) {
+        cnt[i] = (t.cnt[(i * 64 + lane) >> 1] >> (16 * (lane & 1))) & 0xffffu;
+        if (WRITE) key[i] = t.keys[i * 64 + lane];  // (all of them, now: the reads overlap, and the loop below is stores only)
+    }
+#pragma unroll
+    for (int i = 0; i < CT_SLOTS / 64; ++i) {
+        occupied[i] = __ballot(cnt[i] != 0);
+        d += (unsigned int)__popcll(occupied[i]);
+    }
     STAMP(4);  // occupied slots counted
     if (!WRITE) {
-        if (lane == 63) distinct[bucket] = oincl;
+        if (lane == 0) distinct[bucket] = d;
         return;
     }
     // the bucket's distinct k-mers go to the rest of this wave's chunk and, when they do not fit, on into a fresh one
-    const unsigned int d = (unsigned int)__shfl((int)oincl, 63, 64);
     const unsigned long long room = chunk.end - chunk.at;
     unsigned long long fresh = 0;
     if (d > room) {
@@ -396,14 +407,27 @@ __device__ __forceinline__ void count_one_bucket(WaveTable& t, int lane, uint32_
         if (lane == 0) got = atomicAdd(&out.cursor[0], (unsigned long long)CT_CHUNK);
         fresh = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(got >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)got);
     }
-    unsigned int idx = oincl - occ;
+    unsigned int before = 0;  // occupied slots of the rounds done (wave-uniform)
+    if (d <= room && chunk.at + d <= out.capacity) {  // the usual case: one base address for the whole bucket, 32-bit offsets
+        unsigned long long* __restrict__ kp = out.keys + chunk.at;
+        unsigned int* __restrict__ cp = out.counts + chunk.at;
 #pragma unroll
-    for (int i = 0; i < CT_SLOTS / 64; ++i) {
-        const int slot = lane * (CT_SLOTS / 64) + i;
-        const unsigned int c = t.cnt[slot];
-        if (c) {
-            put_counted(out, idx < room ? chunk.at + idx : fresh + (idx - room), t.keys[slot], c);
-            ++idx;
+        for (int i = 0; i < CT_SLOTS / 64; ++i) {
+            if (cnt[i]) {
+                const unsigned int idx = before + __builtin_amdgcn_mbcnt_hi((uint32_t)(occupied[i] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)occupied[i], 0u));
+                kp[idx] = key[i];
+                cp[idx] = cnt[i];
+            }
+            before += (unsigned int)__popcll(occupied[i]);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < CT_SLOTS / 64; ++i) {
+            if (cnt[i]) {
+                const unsigned int idx = before + __builtin_amdgcn_mbcnt_hi((uint32_t)(occupied[i] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)occupied[i], 0u));
+                put_counted(out, idx < room ? chunk.at + idx : fresh + (idx - room), key[i], cnt[i]);
+            }
+            before += (unsigned int)__popcll(occupied[i]);
         }
     }
     if (d > room) {
@@ -689,7 +713,7 @@ int bl_count_super_kmers(bl_ctx* ctx, const uint64_t* d_records, uint64_t n_grou
         recs_sorted = const_cast<ulonglong2*>(recs);
     }
     const uint32_t want = (n_buckets + CT_WAVES - 1) / CT_WAVES;
-    const uint32_t grid = want < 256u * 5u ? want : 256u * 5u;  // 5 workgroups of 2 waves per CU by LDS (14.4 KB per wave): all resident, grid-stride over the buckets
+    const uint32_t grid = want < 256u * 6u ? want : 256u * 6u;  // 6 workgroups of 2 waves per CU by LDS (12.4 KB per wave): all resident, grid-stride over the buckets
     const uint32_t n_waves = grid * CT_WAVES;
     const bool write = d_kmers && d_counts;
     unsigned long long cur[3] = {0, 0, 0};  // [0] distinct k-mers of the table buckets, [1] buckets left to the fallback, [2] end of the chunks handed out
