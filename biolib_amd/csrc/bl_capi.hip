@@ -898,6 +898,20 @@ int bl_scan_super_kmers(bl_ctx* c, const bl_batch* b, uint64_t first, uint64_t n
     return end_scan(c, (1u << 0) | (1u << 4), result, wants, capacity, flags);
 }
 
+int bl_scan_super_kmer_records(bl_ctx* c, const bl_batch* b, uint64_t first, uint64_t n, uint32_t k, uint32_t m, uint64_t seed, uint32_t flags,
+                               uint64_t* d_records, uint64_t* d_hashes, uint64_t capacity, bl_result* result)
+{
+    if (m < 1 || k < m || k > 32 || 2 * k - m > 59) return fail(BL_ERR_INVALID, "need 1 <= m <= k <= 32 and 2k - m <= 59 (bases per packed record)");
+    if (!c) return fail(BL_ERR_INVALID, "ctx is NULL");
+    bl::ScanParams p{};
+    p.out_records = d_records;
+    p.out_hash = d_hashes;
+    const bool wants = d_records || d_hashes;
+    int rc = scan_windows(bl::MODE_SUPERKMER, c, b, first, n, m, k - m + 1, seed, flags, p, wants ? capacity : 0, result);
+    if (rc != BL_OK || p.n_tiles == 0) return rc;
+    return end_scan(c, (1u << 0) | (1u << 4), result, wants, capacity, flags);
+}
+
 int bl_scan_syncmers(bl_ctx* c, const bl_batch* b, uint64_t first, uint64_t n, uint32_t k, uint32_t s, uint32_t start_offset,
                      uint32_t end_offset, uint64_t seed, uint32_t flags, uint64_t* d_positions, uint64_t capacity, bl_result* result)
 {

@@ -214,8 +214,11 @@ __device__ __forceinline__ void emit_tile(const ScanParams& p, uint32_t* codes, 
         const Record rec = emit_prepare<MODE>(p, codes, q0, ent, ent_j, dg);
         if (fits) emit_store<MODE, false>(p, rec, base_s + r);
         else emit_store<MODE, true>(p, rec, base_s + r);
-        if (MODE == MODE_SUPERKMER && p.out_size && (fits || base_s + r < p.capacity))
-            p.out_size[base_s + r] = (uint8_t)(end_position(p, L, tile, q0, r + d, n_e) - (int64_t)rec.first + 1);
+        if (MODE == MODE_SUPERKMER && (p.out_size || p.out_records) && (fits || base_s + r < p.capacity)) {
+            const int size = (int)(end_position(p, L, tile, q0, r + d, n_e) - (int64_t)rec.first + 1);
+            if (p.out_size) p.out_size[base_s + r] = (uint8_t)size;
+            if (p.out_records) emit_record(p, codes, needed - 1, q0, rec, size, base_s + r);
+        }
     };
     if ((uint32_t)tid < n_s) one(tid, a0, j0);
     if ((uint32_t)(TPB + tid) < n_s) one(TPB + tid, a1, j1);

@@ -69,6 +69,7 @@ struct ScanParams {
     uint64_t* out_first;         // super-k-mer: position of the first k-mer of the group
     uint8_t* out_mmpos;          // super-k-mer: minimizer offset inside the first k-mer
     uint8_t* out_size;           // super-k-mer: number of k-mers of the group (last k-mer - first k-mer + 1, super_kmer_view.hpp:133)
+    uint64_t* out_records;       // super-k-mer: the group's bases packed into 16 bytes (bl_superkmer.hip's record), two words per group
     uint64_t capacity;           // records the output arrays can hold
     // two-pass ordered compaction (no inter-workgroup communication inside a kernel):
     //   pass 1 (scan_count_kernel) writes per tile its record counts and its compacted u16 lists,
@@ -356,6 +357,28 @@ BL_DEV uint64_t extract_unit(const uint32_t* codes, int pos, int unit, int canon
     uint64_t rc = pairrev64(fwd) >> (64 - 2 * unit);
     rc ^= unit == 32 ? ~0ULL : ((1ULL << (2 * unit)) - 1);
     return rc < fwd ? rc : fwd;  // numeric min, kmer_view.hpp:196
+}
+
+// The `nb` <= 59 bases from tile-relative base `pos` on, as the 16-byte super-k-mer record of bl_superkmer.hip: x = bases 0..31
+// (first base in the two top bits), y = bases 32..58 in its 54 top bits | mm_pos << 5 | size - 1.  Straight from the staged
+// codes; chunks beyond `last_chunk` are not looked at (their bases would be masked anyway).
+BL_DEV void pack_group(const uint32_t* codes, int last_chunk, int pos, int nb, uint32_t mm_pos, int size, uint64_t& x, uint64_t& y)
+{
+    const int ch = pos >> 4, off = pos & 15;
+    uint64_t c[5];
+    BL_UNROLL
+    for (int i = 0; i < 5; ++i) c[i] = codes[ch + i <= last_chunk ? ch + i : last_chunk];
+    const uint64_t A = (c[0] << 32) | c[1], B = (c[2] << 32) | c[3], D = c[4] << 32;
+    uint64_t hi = A, lo = B;
+    if (off) {
+        hi = (A << (2 * off)) | (B >> (64 - 2 * off));
+        lo = (B << (2 * off)) | (D >> (64 - 2 * off));
+    }
+    if (nb < 32) hi &= nb > 0 ? ~0ULL << (64 - 2 * nb) : 0ULL;
+    if (nb <= 32) lo = 0;
+    else if (nb < 64) lo &= ~0ULL << (64 - 2 * (nb - 32));
+    x = hi;
+    y = (lo & ~0x3ffULL) | ((uint64_t)(mm_pos & 31u) << 5) | (uint64_t)((size - 1) & 31);
 }
 
 // ------------------------------------------------------------------------------------------------

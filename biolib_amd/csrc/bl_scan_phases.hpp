@@ -762,6 +762,16 @@ BL_DEV void emit_store(const ScanParams& p, const Record& rec, uint64_t g)
     }
 }
 
+// super-k-mer scans that hand out packed records: the group's bases come from the tile's staged codes (a group begins in the
+// tile and is at most 2k - m <= 59 bases long: inside what the tile staged for its own windows)
+BL_DEV void emit_record(const ScanParams& p, const uint32_t* codes, int last_chunk, int64_t q0, const Record& rec, int size, uint64_t g)
+{
+    uint64_t x, y;
+    pack_group(codes, last_chunk, (int)((int64_t)rec.first - q0), size + p.unit + p.w - 2, rec.mmpos, size, x, y);
+    stream_store(&p.out_records[2 * g], x);
+    stream_store(&p.out_records[2 * g + 1], y);
+}
+
 // whole phase for one thread: records tid, tid + TPB, ...
 template <int MODE>
 BL_DEV void phase_emit(const ScanParams& p, const TileLists& L, uint32_t tile, int tid, int64_t q0, uint32_t n_s, uint32_t n_e, uint64_t base_s, uint64_t base_e,
@@ -773,8 +783,11 @@ BL_DEV void phase_emit(const ScanParams& p, const TileLists& L, uint32_t tile, i
         const Record rec = emit_prepare<MODE>(p, L.codes, q0, L.list_a[r], MODE == MODE_SUPERKMER ? L.list_j[r] : 0u, dg);
         if (fits) emit_store<MODE, false>(p, rec, base_s + r);
         else emit_store<MODE, true>(p, rec, base_s + r);
-        if (MODE == MODE_SUPERKMER && p.out_size && base_s + r < p.capacity)
-            p.out_size[base_s + r] = (uint8_t)(end_position(p, L, tile, q0, r + d, n_e) - (int64_t)rec.first + 1);
+        if (MODE == MODE_SUPERKMER && (p.out_size || p.out_records) && base_s + r < p.capacity) {
+            const int size = (int)(end_position(p, L, tile, q0, r + d, n_e) - (int64_t)rec.first + 1);
+            if (p.out_size) p.out_size[base_s + r] = (uint8_t)size;
+            if (p.out_records) emit_record(p, L.codes, staged_chunks(p) - 1, q0, rec, size, base_s + r);
+        }
     }
 }
 

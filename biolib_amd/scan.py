@@ -452,16 +452,28 @@ class Batch:
             out.update(values=_host_u64(v, cnt), positions=_host_u64(p, cnt), hashes=_host_u64(h, cnt))
         return out
 
-    def super_kmer_records(self, k, m, seed=0, canonical=False, first=0, n=0):
-        """(records int64[n,2], minimizer hashes int64[n]) on the device: the packed super-k-mers of the range"""
+    def super_kmer_records(self, k, m, seed=0, canonical=False, first=0, n=0, fused=True):
+        """(records int64[n,2], minimizer hashes int64[n]) on the device: the packed super-k-mers of the range, straight from the
+        scan (bl_scan_super_kmer_records; fused=False: bl_scan_super_kmers + bl_pack_super_kmers, the same records)"""
         import torch
 
         span = self._span(first, n)
         c = self.ctx
 
         def run(cap):
-            fp, hs, sz, mp = c.empty_u64(cap), c.empty_u64(cap), c.empty_u8(cap), c.empty_u8(cap)
+            hs = c.empty_u64(cap)
             r = Result()
+            if fused:
+                recs = torch.empty((max(cap, 1), 2), dtype=torch.int64, device=c.torch_device)
+                c._hold(r, _flags(canonical, False, True))
+                try:
+                    check(self._lib.bl_scan_super_kmer_records(c._h, self._h, int(first), int(n), int(k), int(m), int(seed), _flags(canonical, False, True),
+                                                               C.c_void_p(recs.data_ptr()), C.c_void_p(hs.data_ptr()), int(cap), C.byref(r)))
+                finally:
+                    self._last_count = r.count
+                cnt = int(r.count)
+                return recs[:cnt], hs[:cnt]
+            fp, sz, mp = c.empty_u64(cap), c.empty_u8(cap), c.empty_u8(cap)
             try:
                 self.super_kmers_raw(k, m, seed, _flags(canonical, False, True), first, n, None, fp, mp, sz, hs, cap, r)
             finally:

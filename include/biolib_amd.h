@@ -254,6 +254,12 @@ int bl_count_allreduce(bl_ctx* const* ctxs, int n_gpu, uint64_t* counters, int n
  *   BL_ERR_CAPACITY with *n_kmers = need when d_kmers is too small. */
 int bl_pack_super_kmers(bl_ctx* ctx, const bl_batch* batch, const uint64_t* d_first_pos, const uint8_t* d_sizes, const uint8_t* d_mm_pos, uint64_t n_groups,
                         uint32_t k, uint32_t m, uint64_t* d_records);
+/* bl_scan_super_kmer_records: bl_scan_super_kmers + bl_pack_super_kmers in one scan — the groups leave the scan as packed records
+ *   (d_records[2r], d_records[2r+1] as above, with mm_pos) beside the hashes of their minimizers (d_hashes[r]: the owner of the
+ *   record), built from the 2-bit codes the scan holds anyway: no position / size arrays written and read back, no second pass
+ *   over the bases.  Needs 2k - m <= 59.  result as bl_scan_super_kmers. */
+int bl_scan_super_kmer_records(bl_ctx* ctx, const bl_batch* batch, uint64_t first, uint64_t n, uint32_t k, uint32_t m, uint64_t seed, uint32_t flags,
+                               uint64_t* d_records, uint64_t* d_hashes, uint64_t capacity, bl_result* result);
 /* bl_count_super_kmers: the exact multiplicity of every (canonical) k-mer of the packed records WITHOUT a global sort: records are
  *   grouped by the hash of their minimizer (found again through mm_pos; `m`, `seed` and the canonical flag as given to the scan)
  *   into buckets of a few thousand k-mers, and every bucket is expanded and counted in an LDS hash table by one workgroup (buckets

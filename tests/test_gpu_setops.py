@@ -229,6 +229,41 @@ def test_super_kmer_records_pack_and_expand(ctx, k, m, canon):
             assert np.array_equal(a[np.lexsort((a[:, 1], a[:, 0]))], e[np.lexsort((e[:, 1], e[:, 0]))])
 
 
+@pytest.mark.parametrize("layout", ["reads150", "ragged", "one_contig"])
+@pytest.mark.parametrize("k,m,canon", [(31, 15, True), (31, 15, False), (32, 5, True), (21, 11, True), (9, 9, True), (27, 3, False)])
+def test_super_kmer_records_from_the_scan_equal_scan_then_pack(ctx, layout, k, m, canon):
+    """bl_scan_super_kmer_records (records built inside the scan from its 2-bit codes) against bl_scan_super_kmers +
+    bl_pack_super_kmers and against the oracle's groups, on the read-tiled layout, on ragged reads with breaks and on one sequence"""
+    rng = np.random.default_rng(k * 100 + m)
+    if layout == "reads150":
+        n = 150 * 40_000
+        offs = O.fixed_offsets(n, 150)
+    elif layout == "ragged":
+        lens = rng.integers(1, 700, 9000)
+        offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+        n = int(offs[-1])
+    else:
+        n = 3_000_017
+        offs = np.array([0, n], np.uint64)
+    seq = O.synth(77, n)
+    seq[rng.integers(0, n, n // 3000)] = ord("N")
+    b = ctx.upload(seq, offs)
+    fused, h1 = b.super_kmer_records(k, m, seed=5, canonical=canon)
+    plain, h2 = b.super_kmer_records(k, m, seed=5, canonical=canon, fused=False)
+    assert fused.shape == plain.shape and bool((fused == plain).all()) and bool((h1 == h2).all())
+    mn, fp, mp, sz, hs = O.super_kmers(seq, offs, k, m, 5, canon)
+    assert fused.shape[0] == len(mn) and np.array_equal(h1.cpu().numpy().view(np.uint64), hs)
+    assert np.array_equal(fused.cpu().numpy().view(np.uint64)[:2000], _np_pack(seq, fp[:2000], sz[:2000], k, mp[:2000]))
+    # a sub-range, and a capacity that is too small
+    first, cnt = (150 * 1000, 150 * 5000) if layout == "reads150" else (int(offs[len(offs) // 3]), int(offs[-1] - offs[len(offs) // 3]) // 2 if layout != "one_contig" else n // 2)
+    if layout != "one_contig":
+        cnt = int(offs[np.searchsorted(offs, first + cnt)] - first)  # (ranges end where a sequence ends)
+    f2, _ = b.super_kmer_records(k, m, seed=5, canonical=canon, first=first, n=cnt)
+    p2, _ = b.super_kmer_records(k, m, seed=5, canonical=canon, first=first, n=cnt, fused=False)
+    assert f2.shape == p2.shape and bool((f2 == p2).all())
+    b.close()
+
+
 def test_super_kmer_record_limits(ctx):
     import biolib_amd as B
 
