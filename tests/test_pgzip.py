@@ -69,6 +69,10 @@ def cases():
     third = len(smooth) // 3 // 2400 * 2400
     yield ("members", member(smooth[:third], 6, name=b"a") + member(b"", 6) + member(smooth[third:2 * third], 1) + member(smooth[2 * third:], 9, name=b"c"),
            smooth)
+    # what pigz writes: the stream flushed every so often (an empty stored block each time), here every 70,000 bytes of text
+    c = zlib.compressobj(6, zlib.DEFLATED, -15)
+    body = b"".join(c.compress(smooth[a:a + 70_000]) + c.flush(zlib.Z_SYNC_FLUSH if (a // 70_000) % 2 else zlib.Z_FULL_FLUSH) for a in range(0, len(smooth), 70_000)) + c.flush()
+    yield "flushes", b"\x1f\x8b\x08\0\0\0\0\0\0\x03" + body + struct.pack("<II", zlib.crc32(smooth) & 0xffffffff, len(smooth) & 0xffffffff), smooth
     yield "mixed", member(fq[:300_000], 0) + member(fq[300_000:900_000], 6, zlib.Z_FIXED) + member(fq[900_000:], 6), fq
 
 
