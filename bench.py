@@ -18,7 +18,8 @@ Prints ONE JSON line on rank 0, including
                  C2 canonical 31-mer + hash64 over 10 Gbp, C4 super-k-mers k=31 m=15 over 50 Gbp of 10-kbp reads,
                  C5 syncmers k=31 s=11 over 50 Gbp of 10-kbp reads — Gbp/s, kernel ms, roofline fraction
   next_rows      (1 GPU) the rows SURVEY.md §8(f) marks "next", each on a small workload: the partitioned k-mer counter's
-                 chain (scan -> records -> owner split -> count) in Gbp/s and the device BGZF inflate in GB/s of text
+                 chain (scan -> records -> owner split -> count) in Gbp/s, the device BGZF inflate in GB/s of text and a
+                 plain gzip file (one deflate stream per member, decoded in parts by the host's cores) to device batches
   cpu_baseline   the CPU oracle (port of the reference algorithm) timed on this box's host cores on a bounded sample
                  of the same reads, a bit-exact check of the GPU result on it, and the reference itself on C2's path
 """
