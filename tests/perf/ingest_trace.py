@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Where the time of the compressed (BGZF -> device inflate) ingest path goes: one pass over a synthetic bgzip'ed FASTQ with
-BL_INGEST_TRACE=1 (the reader prints its own phase times), with and without the scan behind each batch."""
+"""Where the time of the ingest paths goes: passes over a synthetic FASTQ as BGZF (inflated on the device), plain text and plain
+gzip (decoded in parts by the host's cores) with BL_INGEST_TRACE=1 (the reader prints its own phase times), with and without the
+scan behind each batch."""
 import os, struct, sys, tempfile, time, zlib
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
@@ -36,9 +37,13 @@ with tempfile.TemporaryDirectory() as d:
     with open(plain, "wb") as f:
         for _ in range(repeat):
             f.write(text)
+    gz = os.path.join(d, "r.fq.gz")  # ONE deflate stream per member (zlib level 1): the host's many-threaded decoder, [pgzip] lines
+    one = zlib.compressobj(1, zlib.DEFLATED, 31)
+    one = one.compress(text) + one.flush()
+    open(gz, "wb").write(one * repeat)
     ctx = B.Context(0)
-    for what, scan in (("bgzf", False), ("bgzf", True), ("bgzf", True), ("plain", True), ("plain", True)):
-        path = plain if what == "plain" else os.path.join(d, "r.bgzf.gz")
+    for what, scan in (("bgzf", False), ("bgzf", True), ("bgzf", True), ("plain", True), ("plain", True), ("gzip", True), ("gzip", True)):
+        path = plain if what == "plain" else gz if what == "gzip" else os.path.join(d, "r.bgzf.gz")
         t0 = time.perf_counter(); nb = 0
         t_next = t_scan = t_close = 0.0
         r = B.Reader(path)
