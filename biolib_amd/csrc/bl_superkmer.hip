@@ -134,8 +134,9 @@ __global__ __launch_bounds__(256) void expand_kernel(const ulonglong2* __restric
 // ---------------------------------------------------------------------------------------------------------
 // Counting without a global sort of the k-mers (bl_count_super_kmers).
 //   1. bucket_id_kernel   per record: the minimizer m-mer (at mm_pos of the first k-mer), canonical as the scan took it, hashed as
-//                         the scan hashed it; bucket = top bits of a multiplicative remix of that hash (independent of the
-//                         low bits used to pick the owner rank)
+//                         the scan hashed it; bucket = the top 32 bits of a multiplicative remix of that hash (independent of
+//                         the low bits used to pick the owner rank) scaled to the number of buckets, which is whatever
+//                         makes a bucket ~36 records: the per-bucket costs are spread over as many keys for every input size
 //   2. rocprim::radix_sort_pairs (bucket id -> the 16-byte record itself): library plumbing, <= 26 key bits; the records of
 //                         a bucket end up contiguous
 //   3. bucket_starts_kernel  where each bucket begins in the sorted order (one thread per bucket, independent binary searches)
@@ -164,8 +165,8 @@ __device__ __forceinline__ unsigned long long mmer_at(unsigned long long hi, uns
     return top >> (64 - 2 * m);
 }
 
-__global__ __launch_bounds__(256) void bucket_id_kernel(const ulonglong2* __restrict__ recs, unsigned long long n, int m, int canonical, uint32_t seed, int bits,
-                                                        uint32_t* __restrict__ ids)
+__global__ __launch_bounds__(256) void bucket_id_kernel(const ulonglong2* __restrict__ recs, unsigned long long n, int m, int canonical, uint32_t seed,
+                                                        uint32_t n_buckets, uint32_t* __restrict__ ids)
 {
     const unsigned long long g = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= n) return;
@@ -178,7 +179,8 @@ __global__ __launch_bounds__(256) void bucket_id_kernel(const ulonglong2* __rest
         v = rc < v ? rc : v;
     }
     const unsigned long long h = bl::murmur64(v, seed);
-    ids[g] = bits ? (uint32_t)((h * 0x9E3779B97F4A7C15ULL) >> (64 - bits)) : 0u;
+    // 32 well-mixed bits of the hash, scaled to [0, n_buckets): any number of buckets, not only powers of two
+    ids[g] = (uint32_t)((((h * 0x9E3779B97F4A7C15ULL) >> 32) * (unsigned long long)n_buckets) >> 32);
 }
 
 // starts[b] = first position of the sorted ids holding a value >= b, for b = 0 .. n_buckets
@@ -673,10 +675,12 @@ int bl_count_super_kmers(bl_ctx* ctx, const uint64_t* d_records, uint64_t n_grou
     SK_HIP(hipSetDevice(bl_ctx_device(ctx)));
     hipStream_t s = bl_ctx_stream(ctx);
     const uint32_t n = (uint32_t)n_groups;
-    // buckets of ~20-40 records (170-340 k-mers at k = 31, m = 15), one wave each: a power of two, at most 2^26
-    int bits = 0;
-    while (bits < 26 && (n_groups >> bits) > 40) ++bits;
-    const uint32_t n_buckets = 1u << bits;
+    // buckets of ~36 records (about 300 k-mers at k = 31, m = 15), one wave each; at most 2^26 of them
+    unsigned long long want_buckets = (n_groups + 35) / 36;
+    if (want_buckets > (1ull << 26)) want_buckets = 1ull << 26;
+    const uint32_t n_buckets = (uint32_t)(want_buckets ? want_buckets : 1);
+    int bits = 0;  // of a bucket number (what the radix sort looks at)
+    while ((1ull << bits) < n_buckets) ++bits;
     const uint32_t max_overflow = n_buckets < 65536u ? n_buckets : 65536u;
     // scratch kept by the context between calls (hipMalloc / hipFree of gigabytes cost more than the kernels)
     auto up16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
@@ -696,7 +700,7 @@ int bl_count_super_kmers(bl_ctx* ctx, const uint64_t* d_records, uint64_t n_grou
     const ulonglong2* recs = reinterpret_cast<const ulonglong2*>(d_records);
     hipError_t e = hipMemsetAsync(cursor, 0, 4 * sizeof(unsigned long long), s);
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(bucket_id_kernel, dim3((n + 255) / 256), dim3(256), 0, s, recs, (unsigned long long)n, (int)m, canonical, (uint32_t)seed, bits, ids);
+        hipLaunchKernelGGL(bucket_id_kernel, dim3((n + 255) / 256), dim3(256), 0, s, recs, (unsigned long long)n, (int)m, canonical, (uint32_t)seed, n_buckets, ids);
         e = hipGetLastError();
     }
     if (e == hipSuccess && bits > 0) {
