@@ -681,7 +681,7 @@ int bl_count_super_kmers(bl_ctx* ctx, const uint64_t* d_records, uint64_t n_grou
     const uint32_t n_buckets = (uint32_t)(want_buckets ? want_buckets : 1);
     int bits = 0;  // of a bucket number (what the radix sort looks at)
     while ((1ull << bits) < n_buckets) ++bits;
-    const uint32_t max_overflow = n_buckets < 65536u ? n_buckets : 65536u;
+    const uint32_t max_overflow = n_buckets;  // every bucket may be oversized (reads of high coverage: few minimizers, many occurrences each)
     // scratch kept by the context between calls (hipMalloc / hipFree of gigabytes cost more than the kernels)
     auto up16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
     const size_t ids_bytes = up16(2ull * n * sizeof(uint32_t)), recs_bytes = (size_t)n * sizeof(ulonglong2), starts_bytes = up16(((size_t)n_buckets + 2) * sizeof(uint32_t));

@@ -264,6 +264,26 @@ def test_super_kmer_records_from_the_scan_equal_scan_then_pack(ctx, layout, k, m
     b.close()
 
 
+@pytest.mark.parametrize("copies,distinct", [(40, 4000), (3, 4000), (40, 40_000)])
+def test_count_super_kmers_on_reads_of_high_coverage(ctx, copies, distinct):
+    """reads that repeat (sequencing coverage): few distinct minimizers, each many times over, so that most buckets hold more
+    records than one wave's table takes and go to the sort-and-count path — every one of them, however many there are"""
+    k, m, L = 31, 15, 150  # (the largest case lists some 10^5 buckets: more than the list of oversized buckets used to hold)
+    base = O.synth(123, distinct * L).reshape(distinct, L)
+    order = np.random.default_rng(5).permutation(distinct * copies) % distinct
+    seq = np.ascontiguousarray(base[order]).reshape(-1)
+    offs = O.fixed_offsets(seq.size, L)
+    b = ctx.upload(seq, offs)
+    recs, _ = b.super_kmer_records(k, m, seed=42, canonical=True)
+    u, c = ctx.count_super_kmers(recs, k, m, seed=42, canonical=True)
+    vals, ok = O.units(base.reshape(-1), O.fixed_offsets(distinct * L, L), k, True)
+    eu, ec = np.unique(vals[ok != 0], return_counts=True)
+    got_u = u.cpu().numpy().view(np.uint64)
+    at = np.argsort(got_u)
+    assert np.array_equal(got_u[at], eu) and np.array_equal(c.cpu().numpy().astype(np.int64)[at], ec * copies)
+    b.close()
+
+
 def test_super_kmer_record_limits(ctx):
     import biolib_amd as B
 
