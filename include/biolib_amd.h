@@ -10,6 +10,7 @@
  *   bl_scan_minimizers   wrapper::minimizer_view<K,M,hash64,It>           include/minimizer_view.hpp:14-98 (intended semantics)
  *                        sampler::minimizer_sampler<It,Hash>              include/minimizer_sampler.hpp:12-70
  *   bl_scan_super_kmers  wrapper::super_kmer_view<K,M,hash64>             include/super_kmer_view.hpp:11-58, 121-135
+ *   bl_scan_super_kmer_records  the same groups as self-contained records  include/super_kmer_view.hpp:20-24 (the record), §8f rank 4
  *   bl_scan_syncmers     sampler::syncmer_sampler<It,minimizer_position_extractor>
  *                                                                         include/syncmer_sampler.hpp:9-137, include/kmer_view.hpp:250-283
  *   bl_hash64_u64        hash::hash64::hash<uint64_t>                     include/hash.hpp:55-59 (host-side convenience, bit-exact)
