@@ -144,7 +144,7 @@ __device__ __forceinline__ void count_tile(const ScanParams& p, TileShared<MODE,
 }
 
 // Pass 1 of one tile in the read-tiled layout (fixed-length short reads, bl_scan_frl.hpp): same outputs as count_tile.
-template <int MODE, int W, int NS>
+template <int MODE, int W, int NS, int LIM_LAST>
 __device__ __forceinline__ void count_tile_frl(const ScanParams& p, TileShared<MODE, W>& sh, uint32_t tile, int tid)
 {
     const int64_t q0 = tile_q0(p, tile);
@@ -157,13 +157,13 @@ __device__ __forceinline__ void count_tile_frl(const ScanParams& p, TileShared<M
 
     ThreadState st;
     phase_hash_frl<MODE, W, NS>(p, sh, tid, q0, tile, st);
-    phase_window_frl_a<MODE, W, NS>(p, sh, tid, st, nullptr);
+    phase_window_frl_a<MODE, W, NS, LIM_LAST>(p, sh, tid, st, nullptr);
     const uint32_t packed = phase_window_frl_b<MODE, W, NS>(p, tid, st, nullptr);
 
     uint32_t total;
     const uint32_t excl = block_excl_scan(packed, sh.wave_tot, tid, total);
     const uint32_t n_s = total & 0xffffu, n_e = total >> 16;
-    phase_list_frl<MODE, W>(sh, st, excl & 0xffffu, excl >> 16);
+    phase_list_frl<MODE, W, NS>(sh, st, excl & 0xffffu, excl >> 16);
     if (tid == 0) p.tile_counts[tile] = (unsigned long long)n_s | ((unsigned long long)n_e << 32);
     __syncthreads();  // lists complete
     const size_t slot = (size_t)tile * p.stride;  // stride is a multiple of 4 entries: dword aligned
@@ -269,7 +269,10 @@ __global__ __launch_bounds__(TPB, (W <= 11 ? 5 : 4)) void scan_count_frl_kernel(
         p.stride = NWAVE * rpw * L;
         p.slot_chunks = (15 + NWAVE * rpw * L + 15) / 16 + 3;
     }
-    if (blockIdx.x < g.count) count_tile_frl<MODE, W, NS>(p, sh, g.first + blockIdx.x, threadIdx.x);
+    // compile-time geometry: every lane of a read owns NS windows but the last one (the launcher checks what this assumes)
+    constexpr int LIM_LAST = L != 0 ? (L - U + 1 - W + 1) - ((L - U + 1 + S - 1) / S - 1) * NS : 0;
+    static_assert(L == 0 || (LIM_LAST >= 1 && LIM_LAST <= NS), "read-tiled geometry: the last lane of a read must own 1..NS windows");
+    if (blockIdx.x < g.count) count_tile_frl<MODE, W, NS, LIM_LAST>(p, sh, g.first + blockIdx.x, threadIdx.x);
 }
 
 template <int MODE>

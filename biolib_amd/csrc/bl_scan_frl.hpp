@@ -188,12 +188,53 @@ BL_DEV uint32_t frl_good_mask(const ScanParams& p, const uint32_t* flags, int ba
 }
 
 // ------------------------------------------------------------------------------------------------
-// Phase 3a: window argmins of the lane's NS windows and which of them exist.
+// ELEMENT-CENTRIC decisions (minimizer scans).  A minimizer occurrence is one ELEMENT (unit start) that is the argmin of at
+// least one valid window: the valid windows that choose an element are consecutive (leftmost minimum: if windows i < j
+// choose e, every window between them lies inside their union and chooses e too, and it is valid because its bases are
+// theirs), and argmins never move left as the window slides, so the records of a scan — "one each time the occurrence
+// changes or a run starts", minimizer_view.hpp:193-208 — are exactly the chosen elements in position order.  A lane
+// therefore ORs one bit per window into a mask indexed by element (v_lshl_or_b32: the element index is the low bits of the
+// packed minimum), hands the bits of elements >= NS to the lane that owns them (one DPP move: valid windows never leave
+// the read, W - 1 <= NS) and lists its own set bits.  No per-window comparison with the previous window, no byte-packed
+// argmins, no start/end masks.  Applies when the mask fits a dword.
 template <int MODE, int W, int NS>
+constexpr bool frl_occ_form() { return MODE == MODE_MINIMIZER && W > 1 && W - 1 <= NS && NS + W - 1 <= 32; }
+
+// Phase 3a: window argmins of the lane's NS windows and which of them exist.
+// LIM_LAST != 0 (the compile-time geometry of scan_count_frl_kernel): every lane of a read owns NS windows but the last,
+// which owns LIM_LAST (1..NS); 0: any geometry.
+template <int MODE, int W, int NS, int LIM_LAST = 0>
 BL_DEV void phase_window_frl_a(const ScanParams& p, TileShared<MODE, W>& sh, int tid, ThreadState& st, const ThreadState* all)
 {
     uint32_t a[S];
     lane_window_argmin_frl<NS, (W > 1 ? W : 2)>(all, tid, st, st.jlane >= 0, a);
+    // windows of the read: window index j * NS + s must be below nwin; breaks only where the tile holds one
+    uint32_t vmask = 0;
+    if (st.jlane >= 0) {
+        int lim = p.nwin - st.jlane * NS;
+        lim = lim < 0 ? 0 : (lim > NS ? NS : lim);
+        vmask = (1u << lim) - 1u;
+    }
+    const uint32_t tile_bad = sh.wave_bad[0] | sh.wave_bad[1] | sh.wave_bad[2] | sh.wave_bad[3];
+    if (BL_COLD(tile_bad)) vmask &= frl_good_mask<NS>(p, sh.flags, st.lane_base, p.unit + (W > 0 ? W : p.w) - 1);
+    st.vmask = vmask;
+    if (frl_occ_form<MODE, W, NS>()) {
+        uint32_t occ = 0;
+        if (LIM_LAST == 0 || BL_COLD(tile_bad)) {
+            BL_UNROLL
+            for (int s = 0; s < NS; ++s) occ |= ((vmask >> s) & 1u) << (a[s] & 31u);
+        } else {
+            BL_UNROLL
+            for (int s = 0; s < NS; ++s) occ |= 1u << (a[s] & 31u);
+            // windows that do not exist (the read's last lane) set bits too, none below the argmin of the last window
+            // that does (argmins never move left): clear everything above it
+            const uint32_t a_sel = st.jlane == p.lpr - 1 ? a[LIM_LAST > 0 ? LIM_LAST - 1 : 0] : a[NS - 1];
+            occ &= (2u << (a_sel & 31u)) - 1u;
+            if (st.jlane < 0) occ = 0;
+        }
+        st.occ = occ;
+        return;
+    }
     BL_UNROLL
     for (int s = NS; s < S; ++s) a[s] = 0;
     uint32_t apk[4];
@@ -207,22 +248,24 @@ BL_DEV void phase_window_frl_a(const ScanParams& p, TileShared<MODE, W>& sh, int
     st.apk1 = ((uint64_t)apk[3] << 32) | apk[2];
     st.a_first = a[0] & 63u;
     st.a_last = a[NS - 1] & 63u;
-    // windows of the read: window index j * NS + s must be below nwin; breaks only where the tile holds one
-    uint32_t vmask = 0;
-    if (st.jlane >= 0) {
-        int lim = p.nwin - st.jlane * NS;
-        lim = lim < 0 ? 0 : (lim > NS ? NS : lim);
-        vmask = (1u << lim) - 1u;
-    }
-    const uint32_t tile_bad = sh.wave_bad[0] | sh.wave_bad[1] | sh.wave_bad[2] | sh.wave_bad[3];
-    if (BL_COLD(tile_bad)) vmask &= frl_good_mask<NS>(p, sh.flags, st.lane_base, p.unit + (W > 0 ? W : p.w) - 1);
-    st.vmask = vmask;
 }
 
 // Phase 3b: start / end decisions.  Returns starts | ends << 16.
 template <int MODE, int W, int NS>
 BL_DEV uint32_t phase_window_frl_b(const ScanParams& p, int tid, ThreadState& st, const ThreadState* all)
 {
+    if (frl_occ_form<MODE, W, NS>()) {  // take over the bits the previous lane found for this lane's elements
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(BL_CPU_EMU)
+        (void)all;
+        (void)tid;
+        const uint32_t prev = dpp_prev32(st.occ);
+#else
+        const uint32_t prev = (tid & 63) > 0 ? all[tid - 1].occ : 0u;
+#endif
+        st.endm = 0;
+        st.emit = (st.occ | (prev >> NS)) & ((1u << NS) - 1u);
+        return (uint32_t)__builtin_popcount(st.emit);
+    }
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(BL_CPU_EMU)
     (void)all;
     (void)tid;
@@ -264,11 +307,20 @@ BL_DEV uint32_t phase_window_frl_b(const ScanParams& p, int tid, ThreadState& st
 // ------------------------------------------------------------------------------------------------
 // Phase 4: tile-local compaction.  List entries are FLAT positions relative to the tile's first staged chunk
 // (< 16 * NCHUNK), not (wave, wave-relative position) pairs: pass 2 tells the two apart by p.frl.
-template <int MODE, int W>
+template <int MODE, int W, int NS = 0>
 BL_DEV void phase_list_frl(TileShared<MODE, W>& sh, const ThreadState& st, uint32_t excl_s, uint32_t excl_e)
 {
     uint32_t m = st.emit;
     uint32_t r = excl_s;
+    if (NS != 0 && frl_occ_form<MODE, W, (NS ? NS : 1)>()) {  // bit s: the lane's own element s is a minimizer occurrence
+        while (m) {
+            const int s = __builtin_ctz(m);
+            m &= m - 1;
+            sh.list_a[r] = (uint16_t)(st.lane_base + s);
+            ++r;
+        }
+        return;
+    }
     while (m) {
         const int s = __builtin_ctz(m);
         m &= m - 1;

@@ -57,6 +57,7 @@ struct ThreadState {
     int32_t jlane;        // index of the lane inside its read, -1: the lane has no read
     uint32_t a_first, a_last;  // argmin index of the lane's first / last window
     uint32_t vmask;       // bit s: window s exists and is valid
+    uint32_t occ;         // element-centric minimizer scans: bit e = element e (own or, from NS on, the next lane's) is the argmin of a valid window
 };
 
 // ------------------------------------------------------------------------------------------------

@@ -112,7 +112,7 @@ void run_tiles(ScanParams p, unsigned long long* result)
 }
 
 // the read-tiled pass 1 (scan_count_frl_kernel), then the common prefix scan and pass 2
-template <int MODE, int W, int NS>
+template <int MODE, int W, int NS, int LIM_LAST = 0>
 void run_tiles_frl(ScanParams p, unsigned long long* result)
 {
     const size_t nt = (size_t)p.n_tiles;
@@ -130,7 +130,7 @@ void run_tiles_frl(ScanParams p, unsigned long long* result)
             for (int tid = 0; tid < TPB; ++tid) phase_load_frl<MODE, W>(p, *sh, tid, q0);
             for (int c = 0; c < p.slot_chunks; ++c) sc[tile * p.slot_chunks + c] = sh->codes[c];
             for (int tid = 0; tid < TPB; ++tid) phase_hash_frl<MODE, W, NS>(p, *sh, tid, q0, (uint32_t)tile, st[tid]);
-            for (int tid = 0; tid < TPB; ++tid) phase_window_frl_a<MODE, W, NS>(p, *sh, tid, st[tid], st.data());
+            for (int tid = 0; tid < TPB; ++tid) phase_window_frl_a<MODE, W, NS, LIM_LAST>(p, *sh, tid, st[tid], st.data());
             for (int tid = 0; tid < TPB; ++tid) packed[tid] = phase_window_frl_b<MODE, W, NS>(p, tid, st[tid], st.data());
             uint32_t run = 0;
             for (int tid = 0; tid < TPB; ++tid) {
@@ -138,7 +138,7 @@ void run_tiles_frl(ScanParams p, unsigned long long* result)
                 run += packed[tid];
             }
             const uint32_t n_s = run & 0xffffu, n_e = run >> 16;
-            for (int tid = 0; tid < TPB; ++tid) phase_list_frl<MODE, W>(*sh, st[tid], excl[tid] & 0xffffu, excl[tid] >> 16);
+            for (int tid = 0; tid < TPB; ++tid) phase_list_frl<MODE, W, NS>(*sh, st[tid], excl[tid] & 0xffffu, excl[tid] >> 16);
             counts[tile] = (unsigned long long)n_s | ((unsigned long long)n_e << 32);
             for (uint32_t r = 0; r < n_s; ++r) {
                 sa[tile * p.stride + r] = sh->list_a[r];
@@ -186,7 +186,7 @@ void run_tiles_frl(ScanParams p, unsigned long long* result)
 template <int MODE>
 void run_mode_frl(const ScanParams& p, unsigned long long* result)
 {
-    if (MODE == MODE_MINIMIZER && p.ns == 15) { run_tiles_frl<MODE_MINIMIZER, 11, 15>(p, result); return; }
+    if (MODE == MODE_MINIMIZER && p.ns == 15) { run_tiles_frl<MODE_MINIMIZER, 11, 15, 5>(p, result); return; }  // the BASELINE C3 kernel
     if (MODE == MODE_MINIMIZER) {
         switch (p.w) {
             case 5: run_tiles_frl<MODE_MINIMIZER, 5, S>(p, result); return;

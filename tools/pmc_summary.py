@@ -3,7 +3,7 @@
 import csv, glob, sys, collections
 kern = sys.argv[1]
 for path in sys.argv[2:]:
-    for f in glob.glob(path + "/*/*counter_collection.csv"):
+    for f in (glob.glob(path + "/*/*counter_collection.csv") + glob.glob(path + "/*counter_collection.csv")):
         acc = collections.defaultdict(list)
         for row in csv.DictReader(open(f)):
             if kern in row["Kernel_Name"]:
