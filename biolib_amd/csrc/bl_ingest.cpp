@@ -658,6 +658,13 @@ private:
                     done = true;
                     break;
                 }
+                // what follows a complete member and does not open with the gzip magic is trailing garbage (tape / block padding):
+                // the end of the stream, as for gzread, which the reference's drivers read through (tests/kseq.h over gzFile)
+                if (in_at + 2 > size_ || map_[in_at] != 0x1f || map_[in_at + 1] != 0x8b) {
+                    pos_ = 8 * size_;
+                    done = true;
+                    break;
+                }
                 const uint64_t data = blpg::skip_member_header(map_, size_, in_at);
                 if (data == blpg::NPOS || inflateReset(&z) != Z_OK) {
                     failed_ = true;
@@ -850,7 +857,7 @@ private:
         std::memset(&z, 0, sizeof(z));
         bool ok = inflateInit2(&z, 15 + 32) == Z_OK;  // gzip or zlib wrapper, detected
         std::vector<unsigned char> in(1u << 20);
-        bool input_done = false, member_open = false;
+        bool input_done = false, member_open = false, at_boundary = false;  // at_boundary: a member has just ended
         while (ok) {
             auto c = queue_.reserve();
             if (!c) break;
@@ -866,15 +873,32 @@ private:
                     z.next_in = in.data();
                     z.avail_in = (uInt)n;
                 }
+                if (at_boundary && z.avail_in == 1 && !input_done) {  // the magic may straddle two reads: keep the byte, read on
+                    in[0] = *z.next_in;
+                    const size_t n = std::fread(in.data() + 1, 1, in.size() - 1, f_);
+                    if (n < in.size() - 1) input_done = true;
+                    z.next_in = in.data();
+                    z.avail_in = (uInt)(n + 1);
+                }
                 if (z.avail_in == 0 && input_done) {  // no more input: fine between members, a truncation inside one
                     if (member_open) c->ok = false;
                     finished = true;
                     break;
                 }
+                if (at_boundary) {
+                    // behind a complete member: another member, or trailing garbage, which ends the stream as it does for
+                    // gzread (the reference's drivers read through it: tests/kseq.h over gzFile)
+                    if (z.avail_in < 2 || z.next_in[0] != 0x1f || z.next_in[1] != 0x8b) {
+                        finished = true;
+                        break;
+                    }
+                    at_boundary = false;
+                }
                 member_open = true;
                 const int rc = inflate(&z, Z_NO_FLUSH);
                 if (rc == Z_STREAM_END) {  // end of a member: another may follow (concatenated gzip)
                     member_open = false;
+                    at_boundary = true;
                     if (inflateReset(&z) != Z_OK) { c->ok = false; finished = true; break; }
                 } else if (rc != Z_OK && rc != Z_BUF_ERROR) {
                     c->ok = false;
@@ -896,7 +920,7 @@ private:
     }
     void cut_bgzf()
     {
-        bool more = true;
+        bool more = true, any_member = false;
         while (more) {
             auto c = queue_.reserve();
             if (!c) break;
@@ -908,6 +932,7 @@ private:
                 unsigned char head[18];
                 const size_t got = std::fread(head, 1, sizeof(head), f_);
                 if (got == 0) { more = false; break; }  // clean end of file
+                if (any_member && (got < 2 || head[0] != 0x1f || head[1] != 0x8b)) { more = false; break; }  // trailing garbage: the end, as for gzread
                 const bool good = got == 18 && head[0] == 0x1f && head[1] == 0x8b && head[2] == 8 && (head[3] & 4) && head[12] == 'B' && head[13] == 'C' &&
                                   head[14] == 2 && head[15] == 0 && (head[10] | (head[11] << 8)) >= 6;
                 const size_t bsize = good ? ((size_t)head[16] | ((size_t)head[17] << 8)) + 1 : 0;
@@ -921,6 +946,7 @@ private:
                     more = false;
                     break;
                 }
+                any_member = true;
             }
             if (!c->ok) job.packed.clear();
             pool_->submit(std::move(job));
@@ -1428,6 +1454,17 @@ private:
                 for (;;) {  // the whole members that are here
                     bl_bgzf_member m;
                     uint64_t got = 0, used = 0, tb = 0;
+                    if (seen_member_ && filled > walked) {
+                        // behind a complete member, bytes that do not open with the gzip magic are trailing garbage: the end of
+                        // the stream, as for gzread (the reference's drivers read through it: tests/kseq.h over gzFile)
+                        const unsigned char* q = reinterpret_cast<const unsigned char*>(b->p) + walked;
+                        const size_t have = filled - walked;
+                        if (q[0] != 0x1f || (have >= 2 ? q[1] != 0x8b : eof)) {
+                            filled = walked;
+                            eof = true;
+                            break;
+                        }
+                    }
                     if (bl_bgzf_walk(b->p + walked, filled - walked, walked, text, &m, 1, &got, &used, &tb) != BL_OK) { verdict = -1; break; }
                     if (got == 0) break;
                     // a span is full when its text would pass the limit — or when it holds as many members as the inflate kernel
@@ -1437,6 +1474,7 @@ private:
                     if (!b->members.empty() && (text + m.isize > limit_ || b->members.size() >= max_members_)) { full = true; break; }
                     if (!own && borrowed >= 16) { full = true; break; }  // (members of the neighbour's part: a few at a time)
                     b->members.push_back(m);
+                    seen_member_ = true;
                     walked += used;
                     text += m.isize;
                     if (own) own_text = text;
@@ -1470,6 +1508,7 @@ private:
     }
 
     FILE* f_;
+    bool seen_member_ = false;  // produce(): at least one whole member has been read
     const size_t limit_;
     const size_t max_members_ = (limit_ >> 16) ? (limit_ >> 16) : 1;
     const SpanMemory mem_;

@@ -171,6 +171,35 @@ def test_fuzz_host_reader_vs_reference_reader(tmp_path):
         assert got == exp, (i, text)
 
 
+@pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref not built")
+def test_padded_gzip_files_read_like_the_reference_reader(tmp_path):
+    """block / tape padding behind the last gzip member (zeros, arbitrary bytes): the reference's reader (kseq over gzread)
+    returns the records and no error, and so does the library's — plain gzip through both decoders, and BGZF"""
+    import gzip
+
+    import biolib_amd
+
+    rng = np.random.default_rng(5)
+    reads = [bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), 150)) for _ in range(400)]
+    text = b"".join(b"@r%d\n" % i + s + b"\n+\n" + b"I" * 150 + b"\n" for i, s in enumerate(reads))
+    files = {"one.fq.gz": gzip.compress(text), "two.fq.gz": gzip.compress(text[: len(text) // 2 // 304 * 304]) + gzip.compress(text[len(text) // 2 // 304 * 304:]),
+             "b.fq.gz": _bgzf(text, 9000)}
+    for name, packed in files.items():
+        for j, tail in enumerate((b"", b"\0" * 512, b"garbage!", b"\x1f")):
+            path = tmp_path / ("%d_%s" % (j, name))
+            path.write_bytes(packed + tail)
+            exp = _ref_read(path)
+            assert exp == reads, (name, j)
+            for env in ({"BL_PGZIP": "1", "BL_PGZIP_PART": "4096"}, {"BL_PGZIP": "0"}):
+                os.environ.update(env)
+                try:
+                    got = [s for _, s in biolib_amd.Reader(path, threads=4).records()]
+                finally:
+                    for k in env:
+                        os.environ.pop(k, None)
+                assert got == exp, (name, j, env)
+
+
 @pytest.mark.gpu
 @pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref not built")
 def test_fuzz_device_parser_vs_reference_reader(tmp_path):
@@ -373,9 +402,9 @@ def test_bgzf_device_path_awkward_files(tmp_path):
     ctx = biolib_amd.Context(0)
     rng = np.random.default_rng(12)
 
-    def check(text, limit, eof=True, block=60000):
+    def check(text, limit, eof=True, block=60000, tail=b""):
         path = tmp_path / "t.gz"
-        path.write_bytes(_bgzf(text, block=block, eof=eof))
+        path.write_bytes(_bgzf(text, block=block, eof=eof) + tail)
         want = [s for _, s in biolib_amd.Reader(path).records()]
         r = biolib_amd.Reader(path)
         assert r.kind == "bgzf"
@@ -399,6 +428,9 @@ def test_bgzf_device_path_awkward_files(tmp_path):
         fq = b"".join(b"@r%d a@b" % i + nl + s + nl + b"+" + nl + (first[i % 5] + b"@" * (len(s) - 1))[:len(s)] + nl for i, s in enumerate(seqs))
         check(fq, 64 << 10)
         check(fq, 64 << 10, eof=False, block=9000)
+        for tail in (b"\0" * 512, b"garbage!", b"\x1f"):  # padding behind the last member: the end of the stream, as for gzread
+            check(fq, 64 << 10, tail=tail)
+            check(fq, 64 << 10, eof=False, block=9000, tail=tail)
     # long reads (nanopore-like): records from 1 kbp to 600 kbp with noisy quality strings, spans of 256 KiB — most records are
     # longer than the window of text that is looked at first for the cut, some are longer than a span
     lens = [int(x) for x in rng.integers(1000, 60_000, 60)] + [600_000, 5, 300_000]

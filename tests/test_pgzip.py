@@ -166,7 +166,7 @@ def test_reader_many_threads_reports_damage(tmp_path):
         elif trial % 3 == 1:
             del b[int(rng.integers(len(b) // 2, len(b) - 1)):]
         else:
-            b += b"trailing bytes that are no gzip member"
+            b += b"\x1f\x8b trailing bytes that open like a gzip member and are none"
         path.write_bytes(bytes(b))
         got_p, err_p = read_text(path, True)
         got_z, err_z = read_text(path, False)
@@ -176,6 +176,28 @@ def test_reader_many_threads_reports_damage(tmp_path):
         else:
             seen += 1
     assert seen >= 8
+
+
+TAILS = [b"\0" * 512, b"garbage!", b"\x1f", b"\x1f\x00\x8b", b"\0", b"\n" * 70000]
+
+
+@pytest.mark.parametrize("case", [1, 2], ids=[CASES[1][0], CASES[2][0]])
+def test_trailing_garbage_behind_the_last_member_is_the_end_of_the_stream(tmp_path, case):
+    """zero padding / any bytes that do not open with the gzip magic, behind a complete member: read cleanly, as gzread does
+    (the reference's drivers read gzFile through kseq); both decoders, parts small enough that the tail has parts of its own"""
+    _, packed, text = CASES[case]
+    for i, tail in enumerate(TAILS):
+        path = tmp_path / ("t%d.fq.gz" % i)
+        path.write_bytes(packed + tail)
+        for parallel, part in ((True, 8192), (True, 100_000), (False, 8192)):
+            got, err = read_text(path, parallel, part)
+            assert err is None and got == text, (i, parallel, part, err)
+    # a truncation INSIDE a member stays an error
+    path = tmp_path / "cut.fq.gz"
+    path.write_bytes(packed[: len(packed) - 9])
+    for parallel in (True, False):
+        got, err = read_text(path, parallel)
+        assert err is not None, parallel
 
 
 def test_reader_records_through_many_threads(tmp_path):
