@@ -177,59 +177,36 @@ __device__ __forceinline__ void count_tile_frl(const ScanParams& p, TileShared<M
 // Pass 2 of one tile: reload the tile's 2-bit codes (spilled by pass 1) into LDS, rebuild each record from its u16 list entry
 // (unit value, hash, position) and store it at the tile's global offset with coalesced stores.  The list entries are read
 // straight from the tile's global slots — each exactly once, by the thread that builds the record — so the kernel's LDS
-// footprint is the codes alone and its residency is set by launch_scan_emit's padding (it used to stage up to three 8 KB
-// lists per tile, which, beside a hashing kernel that needs 12 KB per workgroup, decided who got the CU).
-// A workgroup handles EMIT_TILES consecutive tiles: everything a tile needs from memory — counts, offsets, codes, the first
-// 2 * TPB list entries (speculatively: a tile of 150-bp reads holds ~600) — is loaded while the tile before it is being
-// worked on, and the digest words are folded across the wave once per workgroup instead of once per tile.
-constexpr int EMIT_TILES = 4;
-
-struct EmitLoads {
-    unsigned long long cnt, base;
-    uint32_t c0, c1, a0, a1, j0, j1;
-};
-
+// footprint is the 2 KB of codes and its residency is set by launch_scan_emit's padding alone (it used to stage up to
+// three 8 KB lists per tile, which, beside a hashing kernel that needs 12 KB per workgroup, decided who got the CU).
 template <int MODE>
-__device__ __forceinline__ EmitLoads emit_load(const ScanParams& p, uint32_t tile, int tid)
+__device__ __forceinline__ void emit_tile(const ScanParams& p, uint32_t* codes, uint32_t tile, int tid, Digest& dg)
 {
-    EmitLoads L;
-    const size_t slot = (size_t)tile * p.stride;
-    L.cnt = p.tile_counts[tile];
-    L.base = p.tile_base[tile] + p.block_base[tile / SCAN_BLK];
-    const int needed = staged_chunks(p);
-    const uint32_t* sc = p.slots_c + (size_t)tile * p.slot_chunks;
-    L.c0 = tid < needed ? sc[tid] : 0;
-    L.c1 = TPB + tid < needed ? sc[TPB + tid] : 0;
-    const uint16_t* la = p.slots_a + slot;
-    const bool in0 = tid < p.stride, in1 = TPB + tid < p.stride;  // inside the slot (its tail past n_s holds stale entries: never used)
-    L.a0 = in0 ? la[tid] : 0;
-    L.a1 = in1 ? la[TPB + tid] : 0;
-    L.j0 = L.j1 = 0;
-    if (MODE == MODE_SUPERKMER) {
-        const uint16_t* lj = p.slots_j + slot;
-        L.j0 = in0 ? lj[tid] : 0;
-        L.j1 = in1 ? lj[TPB + tid] : 0;
-    }
-    return L;
-}
-
-template <int MODE>
-__device__ __forceinline__ void emit_tile(const ScanParams& p, uint32_t* codes, uint32_t tile, int tid, const EmitLoads& ld, Digest& dg)
-{
+    // one memory round trip for the common case: every load of the tile — counts, offsets, codes, the first 2 * TPB list entries
+    // (speculatively: a tile of 150-bp reads holds ~600) — is issued before the first one is consumed
     const int64_t q0 = tile_q0(p, tile);
     const size_t slot = (size_t)tile * p.stride;
+    const unsigned long long cnt = p.tile_counts[tile];
+    const unsigned long long base = p.tile_base[tile] + p.block_base[tile / SCAN_BLK];
     const int needed = staged_chunks(p);
+    const uint32_t* sc = p.slots_c + (size_t)tile * p.slot_chunks;
+    const uint32_t c0 = tid < needed ? sc[tid] : 0;
+    const uint32_t c1 = TPB + tid < needed ? sc[TPB + tid] : 0;
     const uint16_t* la = p.slots_a + slot;
     const uint16_t* lj = MODE == MODE_SUPERKMER ? p.slots_j + slot : nullptr;
-    const uint32_t n_s = (uint32_t)ld.cnt, n_e = (uint32_t)(ld.cnt >> 32);
-    if (n_s == 0 && n_e == 0) {  // uniform for the workgroup
-        __syncthreads();  // keeps the tiles of a workgroup one barrier apart: what makes alternating two code buffers safe
-        return;
+    const bool in0 = tid < p.stride, in1 = TPB + tid < p.stride;  // inside the slot (its tail past n_s holds stale entries: never used)
+    const uint32_t a0 = in0 ? la[tid] : 0, a1 = in1 ? la[TPB + tid] : 0;
+    uint32_t j0 = 0, j1 = 0;
+    if (MODE == MODE_SUPERKMER) {
+        j0 = in0 ? lj[tid] : 0;
+        j1 = in1 ? lj[TPB + tid] : 0;
     }
-    const uint64_t base_s = ld.base & 0xffffffffull, base_e = ld.base >> 32;
-    if (tid < needed) codes[tid] = ld.c0;
-    if (TPB + tid < needed) codes[TPB + tid] = ld.c1;
-    __syncthreads();  // the one barrier of a tile: the caller alternates between two code buffers
+    const uint32_t n_s = (uint32_t)cnt, n_e = (uint32_t)(cnt >> 32);
+    if (n_s == 0 && n_e == 0) return;  // uniform for the workgroup
+    const uint64_t base_s = base & 0xffffffffull, base_e = base >> 32;
+    if (tid < needed) codes[tid] = c0;
+    if (TPB + tid < needed) codes[TPB + tid] = c1;
+    __syncthreads();
     const bool fits = !BL_COLD(base_s + n_s > p.capacity);
     TileLists L{codes, la, lj, MODE == MODE_SUPERKMER ? p.slots_e + slot : nullptr, MODE == MODE_SUPERKMER ? p.slots_e + slot + p.stride : nullptr};
     const uint32_t d = (uint32_t)(base_s - base_e);  // 0 or 1 (see end_position)
@@ -243,8 +220,8 @@ __device__ __forceinline__ void emit_tile(const ScanParams& p, uint32_t* codes, 
             if (p.out_records) emit_record(p, codes, needed - 1, q0, rec, size, base_s + r);
         }
     };
-    if ((uint32_t)tid < n_s) one(tid, ld.a0, ld.j0);
-    if ((uint32_t)(TPB + tid) < n_s) one(TPB + tid, ld.a1, ld.j1);
+    if ((uint32_t)tid < n_s) one(tid, a0, j0);
+    if ((uint32_t)(TPB + tid) < n_s) one(TPB + tid, a1, j1);
 #pragma unroll 1
     for (uint32_t r = 2 * TPB + tid; r < n_s; r += TPB) one(r, la[r], MODE == MODE_SUPERKMER ? lj[r] : 0u);  // rarely any
 }
@@ -301,19 +278,11 @@ __global__ __launch_bounds__(TPB, (W <= 11 ? 5 : 4)) void scan_count_frl_kernel(
 template <int MODE>
 __global__ __launch_bounds__(TPB) void scan_emit_kernel(const ScanParams p, GroupRange g)
 {
-    __shared__ uint32_t codes[2][NCHUNK];
+    __shared__ uint32_t codes[NCHUNK];
     const int tid = threadIdx.x;
-    const uint32_t t0 = blockIdx.x * EMIT_TILES;  // < g.count by the grid's size
-    const uint32_t t1 = t0 + EMIT_TILES < g.count ? t0 + EMIT_TILES : g.count;
+    if (blockIdx.x >= g.count) return;
     Digest dg{0, 0, 0};
-    EmitLoads cur = emit_load<MODE>(p, g.first + t0, tid);
-#pragma unroll 1
-    for (uint32_t t = t0; t < t1; ++t) {
-        EmitLoads nxt = cur;
-        if (t + 1 < t1) nxt = emit_load<MODE>(p, g.first + t + 1, tid);  // in flight while this tile is worked on
-        emit_tile<MODE>(p, codes[t & 1], g.first + t, tid, cur, dg);
-        cur = nxt;
-    }
+    emit_tile<MODE>(p, codes, g.first + blockIdx.x, tid, dg);
 
     // digest: wave reduce (DPP xor-scan), then one set of atomics per WAVE into a shard line.  Measured alternatives: an LDS stage
     // with two more barriers per tile (no gain); folding the 256 threads' words with LDS atomics on three addresses (-30 % on the
@@ -601,9 +570,9 @@ hipError_t launch_scan_count(int mode, const ScanParams& p, GroupRange g, hipStr
 template <int MODE>
 static void launch_emit_mode(const ScanParams& p, GroupRange g, hipStream_t stream, uint32_t lds_per_wg)
 {
-    const uint32_t have = (uint32_t)(2 * NCHUNK * sizeof(uint32_t));
+    const uint32_t have = (uint32_t)(NCHUNK * sizeof(uint32_t));
     const uint32_t pad = lds_per_wg > have ? lds_per_wg - have : 0;
-    hipLaunchKernelGGL((scan_emit_kernel<MODE>), dim3((g.count + EMIT_TILES - 1) / EMIT_TILES), dim3(TPB), pad, stream, p, g);
+    hipLaunchKernelGGL((scan_emit_kernel<MODE>), dim3(g.count), dim3(TPB), pad, stream, p, g);
 }
 
 hipError_t launch_scan_emit(int mode, const ScanParams& p, GroupRange g, hipStream_t stream, uint32_t lds_per_wg)

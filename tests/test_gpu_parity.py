@@ -338,3 +338,25 @@ def test_random_parameters_vs_oracle(ctx):
         gs = b.syncmers(kk, s, a, e, canonical=canon, drop_last=drop)
         assert gs["count"] == cnt and np.array_equal(gs["positions"], pos), (it, flavour, n, kk, s, a, e, canon, drop)
         b.close()
+
+
+@pytest.mark.gpu
+def test_read_tiled_scan_on_tiles_of_repeats(ctx):
+    """C3's kernel pair on a batch in which whole tiles are low-complexity reads — nearly every window starts an occurrence,
+    3,520 records in a tile instead of ~614 — beside ordinary tiles, with breaks, against the oracle."""
+    rng = np.random.default_rng(77)
+    L, n_reads = 150, 32 * 9 + 5  # nine full tiles of 32 reads and a partial one
+    n = L * n_reads
+    seq = O.synth(7, n).copy()
+    for t in (1, 4, 5, 8):  # whole tiles of repeats: 32 reads x 110 windows > 1024 records
+        motif = np.frombuffer([b"A", b"AC", b"AAAT", b"ACGTT"][t % 4], np.uint8)
+        seq[t * 32 * L:(t + 1) * 32 * L] = np.resize(motif, 32 * L)
+    seq[rng.integers(0, n, 25)] = ord("N")
+    offs = O.fixed_offsets(n, L)
+    b = ctx.upload(seq, offs)  # equal-length offsets: a fixed-length batch, scanned by the read-tiled kernels
+    for canonical in (True, False):
+        v, p, h = O.minimizers(seq, offs, 31, 11, 42, canonical, brute=False)
+        got = b.minimizers(31, 11, seed=42, canonical=canonical)
+        assert got["count"] == len(v)
+        assert np.array_equal(got["values"], v) and np.array_equal(got["positions"], p) and np.array_equal(got["hashes"], h)
+    b.close()
