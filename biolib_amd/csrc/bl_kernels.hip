@@ -5,6 +5,10 @@
 #include "bl_scan_frl.hpp"
 #include "bl_launch.hpp"
 
+#ifndef BL_CS_WAVES
+#define BL_CS_WAVES 4  // waves per SIMD the closed-syncmer kernel is compiled for
+#endif
+
 namespace bl {
 
 // ------------------------------------------------------------------------------------------------
@@ -100,7 +104,7 @@ __device__ __forceinline__ void fill_list(uint16_t* dst, const uint16_t* src, ui
 // Pass 1 of one tile: hash, window minimum, start/end decisions, tile-local compaction; leaves the
 // tile's record counts and u16 lists in global scratch.  Tiles are independent: no ticket, no
 // inter-workgroup wait, any dispatch order.
-template <int MODE, int W>
+template <int MODE, int W, bool CS = false>
 __device__ __forceinline__ void count_tile(const ScanParams& p, TileShared<MODE, W>& sh, uint32_t tile, int tid)
 {
     const int64_t q0 = p.origin + (int64_t)tile * p.stride;
@@ -117,7 +121,16 @@ __device__ __forceinline__ void count_tile(const ScanParams& p, TileShared<MODE,
     phase_hash<MODE, W>(p, sh, tid, st);
 
     uint32_t packed;
-    if (MODE == MODE_SYNCMER) {
+    if (MODE == MODE_SYNCMER && CS) {  // closed syncmers: sliding minima of the high dwords, no argmin
+        bool undecided;
+        packed = phase_sync_closed<MODE, (W > 1 ? W : 2)>(p, reinterpret_cast<TileShared<MODE, (W > 1 ? W : 2)>&>(sh), tid, q0, st, nullptr, undecided);
+        if (BL_COLD(wave_any(undecided))) {  // equal high dwords somewhere in the wave: the exact form, on hashes computed again
+            phase_hash<MODE, W>(p, sh, tid, st);
+            uint32_t af[S + 1];
+            phase_sync_fwd<MODE, W>(p, sh, tid, st, nullptr, af);
+            packed = phase_sync_rev<MODE, W>(p, sh, tid, q0, st, nullptr, af);
+        }
+    } else if (MODE == MODE_SYNCMER) {
         uint32_t af[S + 1];
         phase_sync_fwd<MODE, W>(p, sh, tid, st, nullptr, af);
         packed = phase_sync_rev<MODE, W>(p, sh, tid, q0, st, nullptr, af);
@@ -234,8 +247,9 @@ __device__ __forceinline__ void emit_tile(const ScanParams& p, uint32_t* codes, 
 // U (unit length) and C (canonical flag) specialise the BASELINE configurations at compile time: the
 // parameter block is copied and the fields overwritten with constants, which the inlined phases fold
 // (constant shifts and masks in the roller, no strand selects).  U = 0 / C = -1: taken from the arguments.
-template <int MODE, int W, int U, int C>
-__global__ __launch_bounds__(TPB, (MODE == MODE_SYNCMER || (MODE == MODE_SUPERKMER && W == -32) ? 2 : (W == -32 || (W < 0 && MODE == MODE_SUPERKMER) ? 3 : (W == -16 ? 5 : (W < 0 ? 4 : (W <= 11 ? 5 : 4)))))) void scan_count_kernel(const ScanParams pin, GroupRange g)
+// CS: closed syncmers (offsets {0, W - 1}; phase_sync_closed)
+template <int MODE, int W, int U, int C, bool CS = false>
+__global__ __launch_bounds__(TPB, (CS ? BL_CS_WAVES : (MODE == MODE_SYNCMER || (MODE == MODE_SUPERKMER && W == -32) ? 2 : (W == -32 || (W < 0 && MODE == MODE_SUPERKMER) ? 3 : (W == -16 ? 5 : (W < 0 ? 4 : (W <= 11 ? 5 : 4))))))) void scan_count_kernel(const ScanParams pin, GroupRange g)
 {
     __shared__ TileShared<MODE, W> sh;
     ScanParams p = pin;
@@ -245,7 +259,7 @@ __global__ __launch_bounds__(TPB, (MODE == MODE_SYNCMER || (MODE == MODE_SUPERKM
         p.stride = NWAVE * (64 * S - 16 * ((W + 15) / 16));  // plan_scan's value, as a constant
     }
     if (C >= 0) p.canonical = C;
-    if (blockIdx.x < g.count) count_tile<MODE, W>(p, sh, g.first + blockIdx.x, threadIdx.x);
+    if (blockIdx.x < g.count) count_tile<MODE, W, CS>(p, sh, g.first + blockIdx.x, threadIdx.x);
 }
 
 // Read-tiled pass 1.  L (read length) and U, C specialise the headline configuration as in scan_count_kernel; L fixes
@@ -521,7 +535,10 @@ static hipError_t launch_count_mode(const ScanParams& p, GroupRange g, hipStream
         return hipGetLastError();
     }
     if (MODE == MODE_SYNCMER && p.w == 21 && p.unit == 11 && p.canonical) {
-        hipLaunchKernelGGL((scan_count_kernel<MODE, 21, 11, 1>), grid, block, 0, stream, p, g);
+        const bool closed = (p.soff == 0 && p.eoff == 20) || (p.soff == 20 && p.eoff == 0);
+        static const bool no_cs = std::getenv("BL_NO_CLOSED") != nullptr;  // A/B runs: the argmin form
+        if (closed && !no_cs) hipLaunchKernelGGL((scan_count_kernel<MODE_SYNCMER, 21, 11, 1, true>), grid, block, 0, stream, p, g);  // BASELINE C5
+        else hipLaunchKernelGGL((scan_count_kernel<MODE, 21, 11, 1>), grid, block, 0, stream, p, g);
         return hipGetLastError();
     }
     if (MODE != MODE_SYNCMER) {

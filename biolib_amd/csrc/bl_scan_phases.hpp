@@ -640,6 +640,125 @@ BL_DEV uint32_t phase_sync_rev(const ScanParams& p, TileShared<MODE, W>& sh, int
 }
 
 // ------------------------------------------------------------------------------------------------
+// CLOSED syncmers — offsets {0, W - 1}, the BASELINE C5 configuration (k = 31, s = 11, offsets 0 and 20).  Whether the
+// minimum s-mer sits at the k-mer's first or last position needs no argmin, only the minimum VALUE of the other W - 1 s-mers:
+//   forward strand canonical (leftmost minimum wins, kmer_view.hpp:274-281):
+//       offset 0      <=>  Hf[p] <= min Hf[p+1 .. p+W-1]          offset W-1  <=>  Hf[p+W-1] <  min Hf[p .. p+W-2]
+//   reverse strand canonical (positions mirror, the leftmost becomes the rightmost):
+//       offset 0      <=>  Hr[p+W-1] <= min Hr[p .. p+W-2]        offset W-1  <=>  Hr[p] <  min Hr[p+1 .. p+W-1]
+// so one sliding minimum of width W - 1 per strand over the hashes' HIGH DWORDS (no position tags, one v_min_u32 per step, no
+// tie bookkeeping inside the windows) and four comparisons per k-mer decide.  A comparison whose two high dwords are EQUAL is
+// undecided; the caller then runs the exact argmin form for the wave (phase_sync_fwd / phase_sync_rev).
+
+// m[i] = min(key[i .. i+WW-1]) for i < NW, over key[0 .. NW+WW-2] (van Herk / Gil-Werman on values)
+template <int NW, int WW>
+BL_DEV void window_min(const uint32_t* key, uint32_t* m)
+{
+    BL_UNROLL
+    for (int base = 0; base < NW; base += WW) {
+        uint32_t sv[WW];
+        sv[WW - 1] = key[base + WW - 1];
+        BL_UNROLL
+        for (int i = WW - 2; i >= 0; --i) sv[i] = key[base + i] < sv[i + 1] ? key[base + i] : sv[i + 1];
+        m[base] = sv[0];
+        uint32_t pv = 0;
+        BL_UNROLL
+        for (int i = 1; i < WW; ++i) {
+            if (base + i >= NW) break;
+            const uint32_t x = key[base + WW - 1 + i];
+            pv = (i == 1 || x < pv) ? x : pv;
+            m[base + i] = pv < sv[i] ? pv : sv[i];
+        }
+    }
+}
+
+// key[S .. S+NE-1] = the first NE values of the lanes that follow (16 per hop); the last lanes of a wave get values that no
+// owned k-mer looks at
+template <int NE, bool SECOND>
+BL_DEV void gather_halo_hi(const ThreadState* all, int tid, uint32_t* key)
+{
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(BL_CPU_EMU)
+    (void)all;
+    (void)tid;
+    uint32_t cur[S];
+    BL_UNROLL
+    for (int x = 0; x < S; ++x) cur[x] = key[x];
+    BL_UNROLL
+    for (int hop = 0; hop * S < NE; ++hop) {
+        BL_UNROLL
+        for (int x = 0; x < S; ++x) {
+            if (hop * S + x < NE || (hop + 1) * S + x < NE || (hop + 2) * S + x < NE || (hop + 3) * S + x < NE)
+                cur[x] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cur[x], 0x130, 0xf, 0xf, false);  // wave_shl:1
+            if (hop * S + x < NE) key[(hop + 1) * S + x] = cur[x];
+        }
+    }
+#else
+    const int lane = tid & 63;
+    for (int x = 0; x < NE; ++x) {
+        const int nb = lane + 1 + (x >> 4);
+        key[S + x] = nb < 64 ? (uint32_t)((SECOND ? all[tid + 1 + (x >> 4)].h2[x & 15] : all[tid + 1 + (x >> 4)].h[x & 15]) >> 32) : 0xDEADBEEFu;
+    }
+#endif
+}
+
+// Returns the number of syncmers the lane reports; `undecided` = true when one of the lane's comparisons met equal high dwords.
+template <int MODE, int W>
+BL_DEV uint32_t phase_sync_closed(const ScanParams& p, TileShared<MODE, W>& sh, int tid, int64_t q0, ThreadState& st, const ThreadState* all, bool& undecided)
+{
+    static_assert(W >= 2, "closed syncmers need at least two s-mers per k-mer");
+    const int wv = wave_index(tid), lane = tid & 63;
+    constexpr int NE = W - 1;        // halo elements
+    constexpr int WW = W - 1;        // width of the sliding minimum
+    uint32_t kf[S + NE], kr[S + NE], mf[S + 1], mr[S + 1];
+    BL_UNROLL
+    for (int s = 0; s < S; ++s) {
+        kf[s] = (uint32_t)(st.h[s] >> 32);
+        kr[s] = (uint32_t)(st.h2[s] >> 32);
+    }
+    gather_halo_hi<NE, false>(all, tid, kf);
+    window_min<S + 1, WW>(kf, mf);
+    if (p.canonical) {
+        gather_halo_hi<NE, true>(all, tid, kr);
+        window_min<S + 1, WW>(kr, mr);
+    }
+    uint32_t hit = 0, closest = ~0u;
+    BL_UNROLL
+    for (int s = 0; s < S; ++s) {
+        const uint32_t a1 = kf[s], m1 = mf[s + 1], a2 = kf[s + W - 1], m2 = mf[s];
+        bool h = a1 <= m1 || a2 < m2;
+        uint32_t d = (a1 ^ m1) < (a2 ^ m2) ? (a1 ^ m1) : (a2 ^ m2);
+        if (p.canonical) {
+            const uint32_t a3 = kr[s + W - 1], m3 = mr[s], a4 = kr[s], m4 = mr[s + 1];
+            const bool hr = a3 <= m3 || a4 < m4;
+            const uint32_t dr = (a3 ^ m3) < (a4 ^ m4) ? (a3 ^ m3) : (a4 ^ m4);
+            const bool rev = (st.strand >> s) & 1;
+            h = rev ? hr : h;
+            d = rev ? dr : d;
+        }
+        if (h) hit |= 1u << s;
+        closest = d < closest ? d : closest;
+    }
+    Bits128 good, start;
+    gather_flags(sh.flags + wave_chunk0(p, wv), lane, good, start);
+    const int k = p.unit + W - 1;
+    const uint32_t valid = window_valid_mask(good, start, k) & 0xffffu;
+    const int64_t j0 = wave_origin(p, q0, wv) + 16 * (int64_t)lane;
+    const int64_t wj0 = wave_origin(p, q0, wv);
+    uint32_t inrange = 0x1ffffu;
+    if (!(wj0 >= p.win_first && wj0 + WH + 1 <= p.win_end)) inrange = range_mask(p.win_first - j0, p.win_end - j0);
+    uint32_t emit = hit & valid & owned_mask(p, lane) & inrange;
+    if (p.drop_last) {  // the k-mer that ends its sequence is never examined by the idiom (Q1)
+        uint32_t last = (uint32_t)b128_shr(start, k).lo & 0xffffu;  // a sequence starts right behind the k-mer at s
+        last |= range_mask(p.n_bases - k - j0, S + 1);              // ... or the batch ends there
+        emit &= ~last;
+    }
+    st.emit = emit;
+    st.endm = 0;
+    undecided = closest == 0 && owned_mask(p, lane) != 0;
+    return (uint32_t)__builtin_popcount(emit);
+}
+
+// ------------------------------------------------------------------------------------------------
 // Phase 4: tile-local compaction into LDS lists (position-ordered: rank = exclusive prefix + local index)
 template <int MODE, int W>
 BL_DEV void phase_list(TileShared<MODE, W>& sh, int tid, const ThreadState& st, uint32_t excl_s, uint32_t excl_e)

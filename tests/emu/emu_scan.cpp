@@ -35,7 +35,7 @@ std::vector<uint32_t> make_start_bits(uint64_t n_bases, const uint64_t* offsets,
 }
 
 // pass 1 (scan_count_kernel) for every tile, the tile-count prefix scan, pass 2 (scan_emit_kernel)
-template <int MODE, int W>
+template <int MODE, int W, bool CS = false>
 void run_tiles(ScanParams p, unsigned long long* result)
 {
     const size_t nt = (size_t)p.n_tiles;
@@ -54,7 +54,16 @@ void run_tiles(ScanParams p, unsigned long long* result)
             for (int tid = 0; tid < TPB; ++tid) phase_load<MODE, W>(p, *sh, tid, q0);
             for (int c = 0; c < staged_chunks(p); ++c) sc[tile * p.slot_chunks + c] = sh->codes[c];  // codes spill
             for (int tid = 0; tid < TPB; ++tid) phase_hash<MODE, W>(p, *sh, tid, st[tid]);
-            if (MODE == MODE_SYNCMER) {
+            if (MODE == MODE_SYNCMER && CS) {  // closed syncmers: count_tile's order, the exact form where a lane is undecided
+                for (int tid = 0; tid < TPB; ++tid) {
+                    bool undecided;  // (the phases read only the hashes of other lanes, which they do not change)
+                    packed[tid] = phase_sync_closed<MODE, (W > 1 ? W : 2)>(p, reinterpret_cast<TileShared<MODE, (W > 1 ? W : 2)>&>(*sh), tid, q0, st[tid], st.data(), undecided);
+                    if (undecided) {
+                        phase_sync_fwd<MODE, W>(p, *sh, tid, st[tid], st.data(), &af[tid * (S + 1)]);
+                        packed[tid] = phase_sync_rev<MODE, W>(p, *sh, tid, q0, st[tid], st.data(), &af[tid * (S + 1)]);
+                    }
+                }
+            } else if (MODE == MODE_SYNCMER) {
                 for (int tid = 0; tid < TPB; ++tid) phase_sync_fwd<MODE, W>(p, *sh, tid, st[tid], st.data(), &af[tid * (S + 1)]);
                 for (int tid = 0; tid < TPB; ++tid)
                     packed[tid] = phase_sync_rev<MODE, W>(p, *sh, tid, q0, st[tid], st.data(), &af[tid * (S + 1)]);
@@ -210,7 +219,13 @@ void run_mode(const ScanParams& p, unsigned long long* result)
         case 19: if (MODE != MODE_SYNCMER) { run_tiles<MODE, 19>(p, result); break; } run_tiles<MODE, -16>(p, result); break;
         case 11: run_tiles<MODE, 11>(p, result); break;
         case 17: run_tiles<MODE, 17>(p, result); break;
-        case 21: run_tiles<MODE, 21>(p, result); break;
+        case 21:
+            if (MODE == MODE_SYNCMER && p.unit == 11 && p.canonical && ((p.soff == 0 && p.eoff == 20) || (p.soff == 20 && p.eoff == 0))) {
+                run_tiles<MODE_SYNCMER, 21, true>(p, result);  // the BASELINE C5 kernel (launch_count_mode)
+                break;
+            }
+            run_tiles<MODE, 21>(p, result);
+            break;
         default:
             if (p.w <= 16) run_tiles<MODE, -8>(p, result);
             else if (p.w <= 32) run_tiles<MODE, -16>(p, result);
