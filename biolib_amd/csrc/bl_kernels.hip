@@ -108,7 +108,6 @@ template <int MODE, int W, bool CS = false>
 __device__ __forceinline__ void count_tile(const ScanParams& p, TileShared<MODE, W>& sh, uint32_t tile, int tid)
 {
     const int64_t q0 = p.origin + (int64_t)tile * p.stride;
-    BL_MARK("start");
     phase_load<MODE, W>(p, sh, tid, q0);
     {   // hand the packed codes to pass 2 (0.26 B/base instead of re-reading and re-encoding 1 B/base there)
         const int needed = staged_chunks(p);
@@ -118,10 +117,8 @@ __device__ __forceinline__ void count_tile(const ScanParams& p, TileShared<MODE,
     }
     __syncthreads();
 
-    BL_MARK("load");
     ThreadState st;
     phase_hash<MODE, W>(p, sh, tid, st);
-    BL_MARK("hash");
 
     uint32_t packed;
     if (MODE == MODE_SYNCMER && CS) {  // closed syncmers: sliding minima of the high dwords, no argmin
@@ -141,14 +138,11 @@ __device__ __forceinline__ void count_tile(const ScanParams& p, TileShared<MODE,
         packed = phase_window<MODE, W>(p, sh, tid, q0, st, nullptr);
     }
 
-    BL_MARK("window");
     uint32_t total;
     const uint32_t excl = block_excl_scan(packed, sh.wave_tot, tid, total);
-    BL_MARK("scan");
     const uint32_t n_s = total & 0xffffu, n_e = total >> 16;  // a tile owns fewer than H positions: 16 bits suffice
     phase_list<MODE, W>(sh, tid, st, excl & 0xffffu, excl >> 16);
     if (tid == 0) p.tile_counts[tile] = (unsigned long long)n_s | ((unsigned long long)n_e << 32);
-    BL_MARK("list");
     __syncthreads();  // lists complete
 
     // spill the compacted lists: two u16 entries per 32-bit store (sub-dword global stores are not
