@@ -123,6 +123,7 @@ struct bl_batch {
     uint64_t n_bases = 0;
     uint64_t n_seqs = 0;
     uint64_t read_len = 0;           // != 0: every sequence has this length (the last one may be shorter)
+    uint64_t origin = 0;             // position of base 0 in the caller's whole (bl_batch_set_origin): added to reported positions
 };
 
 namespace {
@@ -641,6 +642,13 @@ int bl_batch_from_device(bl_ctx* c, const void* d_bases, uint64_t n_bases, const
     return BL_OK;
 }
 
+int bl_batch_set_origin(bl_batch* b, uint64_t origin)
+{
+    if (!b) return fail(BL_ERR_INVALID, "batch is NULL");
+    b->origin = origin;
+    return BL_OK;
+}
+
 int bl_batch_synth(bl_ctx* c, uint64_t seed, uint64_t n_bases, uint64_t read_len, bl_batch** out)
 {
     bl_batch* b = nullptr;
@@ -784,6 +792,7 @@ static int scan_windows(int mode, bl_ctx* c, const bl_batch* b, uint64_t first, 
     if (end <= first) return zero_result(c, result, flags);
     p.bases = b->bases;
     p.n_bases = (int64_t)b->n_bases;
+    p.pos_base = (int64_t)b->origin;
     bl::plan_scan(mode, (int64_t)first, (int64_t)end, (int)w, p);
     // fixed-length short reads, range aligned to reads: the read-tiled layout (no start bits, no hashing of positions
     // that cannot start a unit) when it pays; BL_NO_FRL=1 keeps the position-tiled kernels (A/B measurements)

@@ -53,6 +53,7 @@ struct ScanParams {
     const uint32_t* start_bits;  // bit p set <=> p is the first base of a sequence (nullptr: one sequence)
     int64_t win_first, win_end;  // only windows whose first base lies in [win_first, win_end) are reported
     int64_t origin;              // first hashed position of wave 0 of tile 0 (multiple of 16, may be negative)
+    int64_t pos_base;            // added to every reported position: where base 0 of the batch lies in the caller's whole (bl_batch_set_origin)
     int32_t n_tiles;
     int32_t stride;              // owned positions per workgroup tile = NWAVE * (1024 - 16*ceil(w/16))
     int32_t unit, w;

@@ -836,8 +836,8 @@ BL_DEV Record emit_prepare(const ScanParams& p, const uint32_t* codes, int64_t q
     Record rec{0, 0, 0, 0, 0};
     const int wv = p.frl ? 0 : ent >> 12, ap = p.frl ? ent : ent & 0xfff;
     const int64_t wq0 = p.frl ? q0 : wave_origin(p, q0, wv);
-    rec.pos = (uint64_t)(wq0 + ap);
-    dg.xp ^= rec.pos;
+    rec.pos = (uint64_t)(wq0 + ap);  // inside the batch; p.pos_base is added where positions leave the kernel (digest, stores)
+    dg.xp ^= rec.pos + (uint64_t)p.pos_base;
     if (MODE != MODE_SYNCMER) {
         rec.v = extract_unit(p.frl ? codes : codes + wave_chunk0(p, wv), ap, p.unit, p.canonical);
         rec.h = murmur64(rec.v, p.seed);
@@ -870,14 +870,14 @@ BL_DEV void emit_store(const ScanParams& p, const Record& rec, uint64_t g)
 {
     if (CHECK && g >= p.capacity) return;
     if (MODE == MODE_SYNCMER) {
-        if (p.out_pos) stream_store(&p.out_pos[g], rec.pos);
+        if (p.out_pos) stream_store(&p.out_pos[g], rec.pos + (uint64_t)p.pos_base);
         return;
     }
     if (p.out_value) stream_store(&p.out_value[g], rec.v);
     if (p.out_hash) stream_store(&p.out_hash[g], rec.h);
-    if (p.out_pos) stream_store(&p.out_pos[g], rec.pos);
+    if (p.out_pos) stream_store(&p.out_pos[g], rec.pos + (uint64_t)p.pos_base);
     if (MODE == MODE_SUPERKMER) {
-        if (p.out_first) stream_store(&p.out_first[g], rec.first);
+        if (p.out_first) stream_store(&p.out_first[g], rec.first + (uint64_t)p.pos_base);
         if (p.out_mmpos) p.out_mmpos[g] = (uint8_t)rec.mmpos;
     }
 }

@@ -349,6 +349,12 @@ class Batch:
     def n_seqs(self):
         return int(self._lib.bl_batch_n_seqs(self._h))
 
+    def set_origin(self, origin):
+        """This batch is a piece of a longer concatenation whose base `origin` is the batch's base 0: every position a scan reports
+        (and folds into xor_pos) becomes origin + position inside the batch (bl_batch_set_origin; biolib_amd.shard cuts contigs with it)."""
+        check(self._lib.bl_batch_set_origin(self._h, int(origin)))
+        return self
+
     def download(self, first=0, n=None):
         n = self.n_bases - first if n is None else n
         out = np.empty(n, dtype=np.uint8)

@@ -46,6 +46,124 @@ def shard_ranges(offsets, world_size, rank):
     return lo, max(hi, lo)
 
 
+# ---- cutting ONE concatenation of sequences across ranks by BASES: a contig longer than a shard is split (SURVEY.md §8e) ----------
+#
+# The reference streams a contig of any length through one view (kmer_view.hpp:46-54, 181-202); a chromosome must therefore be
+# able to use every GPU.  Rank r OWNS the windows (k-mers) whose FIRST base lies in [lo, hi) = its share of the bases.  To decide
+# them it uploads the PIECE [lo - 1, hi + unit + w - 2): the (unit-1)+(w-1) bases behind hi that its last window reads, and the
+# one base in front of lo, because whether the window at lo OPENS a minimizer occurrence depends on the window before it
+# (the scan's range rule: a record belongs to the range that holds the first window of its occurrence).  The piece is an
+# ordinary batch — sequence starts inside it keep their meaning, its first base counts as a start — whose origin is set to
+# piece_lo (bl_batch_set_origin), so every reported position is a position in the whole and the ranks' records, concatenated
+# in rank order, ARE the records of one scan over the whole.  No rank talks to another.
+
+def base_range(total, world_size, rank):
+    """[lo, hi) of the `total` bases of the concatenation that `rank` owns: contiguous, balanced to one base."""
+    total, world_size, rank = int(total), int(world_size), int(rank)
+    return total * rank // world_size, total * (rank + 1) // world_size
+
+
+def contig_piece(offsets, lo, hi, unit, w, guard=0, tail=0):
+    """What a rank uploads and scans to own the windows that start in [lo, hi).  offsets: uint64[n_seqs + 1] of the whole
+    concatenation.  guard: windows scanned in front of lo and behind hi as well (super-k-mers: a range cuts groups, so groups
+    are scanned whole and kept by their first window, see super_kmers_of_shard).
+    tail: bases kept behind the last window's last base (1 for scans that drop the k-mer that ENDS its sequence, quirk Q1: the
+    piece's own end must not look like the end of the sequence to the last owned k-mer).  Returns a dict:
+      piece_lo, piece_hi   bases [piece_lo, piece_hi) of the whole form the batch; piece_lo is its origin
+      offsets              uint64 sequence offsets of the batch (local; the piece's first base opens a sequence)
+      first, n             the range of the batch to scan (local): the windows starting in [lo - guard, hi + guard)"""
+    offsets = np.asarray(offsets, dtype=np.uint64)
+    total = int(offsets[-1])
+    lo, hi = int(lo), int(hi)
+    span = int(unit) + int(w) - 1                       # bases of one window
+    scan_lo, scan_hi = max(0, lo - int(guard)), min(total, hi + int(guard))
+    piece_lo = max(0, scan_lo - 1)                      # the window in front of the first one decides whether that one opens an occurrence
+    piece_hi = min(total, scan_hi + span - 1 + int(tail))
+    if hi <= lo:
+        piece_lo = piece_hi = scan_lo = scan_hi = min(lo, total)
+    a = int(np.searchsorted(offsets, np.uint64(piece_lo), side="right"))
+    b = int(np.searchsorted(offsets, np.uint64(piece_hi), side="left"))
+    inner = offsets[a:b].astype(np.int64) - piece_lo     # sequence starts strictly inside the piece
+    local = np.concatenate([[0], inner, [piece_hi - piece_lo]]).astype(np.uint64)
+    return dict(piece_lo=piece_lo, piece_hi=piece_hi, offsets=local, first=scan_lo - piece_lo, n=scan_hi - scan_lo)
+
+
+_RANGE = 1_500_000_000  # positions per scan call (a range holds at most 2^31)
+
+
+def _piece_batch(ctx, bases, plan):
+    """the rank's piece as a batch with its origin set; bases: the whole concatenation (uint8 array) or a callable(lo, hi) -> array"""
+    piece = bases(plan["piece_lo"], plan["piece_hi"]) if callable(bases) else np.asarray(bases)[plan["piece_lo"]:plan["piece_hi"]]
+    return ctx.upload(piece, plan["offsets"]).set_origin(plan["piece_lo"])
+
+
+def _ranges(plan):
+    a, end = plan["first"], plan["first"] + plan["n"]
+    while a < end:
+        yield a, min(_RANGE, end - a)
+        a += _RANGE
+
+
+def _cat(parts, keys):
+    if not parts:
+        return {k: np.zeros(0, np.uint8 if k in ("mm_pos", "sizes") else np.uint64) for k in keys} | {"count": 0}
+    out = {k: np.concatenate([p[k] for p in parts]) for k in keys}
+    out["count"] = int(sum(int(p["count"]) for p in parts))
+    return out
+
+
+def minimizers_of_shard(ctx, bases, offsets, unit, w, seed=0, canonical=False, rank=0, world_size=1):
+    """This rank's minimizer records of the whole concatenation (values, positions — global —, hashes): rank order = position order."""
+    lo, hi = base_range(int(np.asarray(offsets)[-1]), world_size, rank)
+    plan = contig_piece(offsets, lo, hi, unit, w)
+    if plan["n"] == 0:
+        return _cat([], ("values", "positions", "hashes"))
+    b = _piece_batch(ctx, bases, plan)
+    parts = [b.minimizers(unit, w, seed=seed, canonical=canonical, first=a, n=n) for a, n in _ranges(plan)]
+    b.close()
+    return _cat(parts, ("values", "positions", "hashes"))
+
+
+def syncmers_of_shard(ctx, bases, offsets, k, s, start_offset, end_offset, canonical=False, drop_last=False, rank=0, world_size=1):
+    """This rank's syncmer positions (global).  A k-mer is decided by its own k bases: unit = s, w = k - s + 1 give the same piece."""
+    lo, hi = base_range(int(np.asarray(offsets)[-1]), world_size, rank)
+    plan = contig_piece(offsets, lo, hi, s, k - s + 1, tail=1 if drop_last else 0)
+    if plan["n"] == 0:
+        return _cat([], ("positions",))
+    b = _piece_batch(ctx, bases, plan)
+    parts = [b.syncmers(k, s, start_offset, end_offset, canonical=canonical, drop_last=drop_last, first=a, n=n) for a, n in _ranges(plan)]
+    b.close()
+    return _cat(parts, ("positions",))
+
+
+def super_kmers_of_shard(ctx, bases, offsets, k, m, seed=0, canonical=False, rank=0, world_size=1):
+    """This rank's super-k-mers (minimizers, first_pos — global —, mm_pos, sizes, hashes).  A scan range CUTS the groups at its
+    ends (include/biolib_amd.h), so the rank scans w = k - m + 1 windows beyond both ends of its share — no group is longer —
+    and keeps the groups whose first k-mer starts inside [lo, hi): every group is then whole on exactly one rank."""
+    w = k - m + 1
+    lo, hi = base_range(int(np.asarray(offsets)[-1]), world_size, rank)
+    plan = contig_piece(offsets, lo, hi, m, w, guard=w)
+    keys = ("minimizers", "first_pos", "mm_pos", "sizes", "hashes")
+    if hi <= lo:
+        return _cat([], keys)
+    b = _piece_batch(ctx, bases, plan)
+    # one call per <= 1.5 G positions would cut groups between the calls as well: overlap the calls by w and keep by first k-mer
+    parts = []
+    a, end = plan["first"], plan["first"] + plan["n"]
+    while a < end:
+        n = min(_RANGE, end - a)
+        g = b.super_kmers(k, m, seed=seed, canonical=canonical, first=a, n=n)
+        own_lo = max(lo, plan["piece_lo"] + a + (w if a > plan["first"] else 0))
+        own_hi = min(hi, plan["piece_lo"] + a + n - (w if a + n < end else 0))
+        keep = (g["first_pos"] >= np.uint64(own_lo)) & (g["first_pos"] < np.uint64(max(own_hi, own_lo)))
+        parts.append({key: g[key][keep] for key in keys} | {"count": int(keep.sum())})
+        if a + n >= end:
+            break
+        a += n - 2 * w
+    b.close()
+    return _cat(parts, keys)
+
+
 def reduce_digests(local, device=None, group=None):
     """local: dict with integer 'count' (and optionally other *_count / sum_* keys, summed) and xor_* keys
     (folded with XOR).  Returns the whole-job digest on every rank.  Without an initialised process

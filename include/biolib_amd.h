@@ -112,6 +112,12 @@ int bl_batch_destroy(bl_batch* batch);
 uint64_t bl_batch_n_bases(const bl_batch* batch);
 uint64_t bl_batch_n_seqs(const bl_batch* batch);
 const void* bl_batch_device_bases(const bl_batch* batch);
+/* A batch that is a PIECE of a longer concatenation (one GPU's part of a contig that was cut across GPUs, SURVEY.md §8e;
+ * the reference streams a contig of any length through one view, kmer_view.hpp:46-54): `origin` is the position its base 0 has
+ * in the whole.  Every position a scan of this batch reports (d_positions, d_first_pos) and folds into xor_pos is then
+ * origin + the position inside the batch, so the records of the pieces concatenate to the records of the whole; the
+ * ranges [first, first+n) of the scan calls stay relative to the batch.  Default 0. */
+int bl_batch_set_origin(bl_batch* batch, uint64_t origin);
 /* Copy bases [first, first+n) back to the host (synchronous). */
 int bl_batch_download(bl_batch* batch, uint64_t first, uint64_t n, char* out);
 

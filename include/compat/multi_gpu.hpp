@@ -1,12 +1,17 @@
 // multi_gpu.hpp — the host side of the path on the GPUs of one node, in C++ (north_star: "host side stays C++ ... input
 // sequences shard by read/contig across the 8 GPUs of one node, with RCCL over xGMI used only for the optional final k-mer-count
-// reduction").  No counterpart in biolib, which is single-threaded; the unit of sharding is the reference's own: one view per
-// sequence (tests/test_kmer_view.cpp:35-36), so whole reads go to one GPU and no window ever spans two shards.
+// reduction").  No counterpart in biolib, which is single-threaded and streams a contig of any length through one view
+// (kmer_view.hpp:46-54, 181-202).
 //
-// biolib_amd::multi_gpu owns one context and one host thread per device.  A scan call splits the reads into contiguous
-// shards balanced by bases, every thread uploads (or synthesises) its shard, scans it in ranges of <= 1.5 Gbp and folds the
-// per-range digests; counts are then summed across the devices with bl_count_allreduce (ncclAllReduce over RCCL), XOR digests
-// — for which RCCL has no reduction — are folded on the host.  Shards are independent: there is no data-path collective.
+// biolib_amd::multi_gpu owns one context and one host thread per device.  Host sequences are cut BY BASES: device
+// g owns the windows whose first base lies in its share [lo, hi) of the concatenation, whether that cuts a contig or not.  It
+// uploads the piece [lo - 1, hi + (unit-1)+(w-1)) — the halo its last window reads, and the one base in front that decides
+// whether its first window opens a minimizer occurrence — tells the batch where the piece lies in the whole
+// (bl_batch_set_origin: reported positions are global) and scans the range of the piece that is its own in calls of <= 1.5 Gbp.
+// The devices' records, in device order, are the records of one scan over the whole; the digests say so: count, xor_value,
+// xor_hash AND xor_pos equal the single-device ones for any number of devices.  Counts are summed across the devices with
+// bl_count_allreduce (ncclAllReduce over RCCL), XOR digests — for which RCCL has no reduction — are folded on the host.
+// There is no data-path collective.
 #ifndef BIOLIB_AMD_COMPAT_MULTI_GPU_HPP
 #define BIOLIB_AMD_COMPAT_MULTI_GPU_HPP
 
@@ -57,10 +62,19 @@ class multi_gpu
             return {lo, hi};
         }
 
-        // minimizer scan (unit-mers, window w) of host sequences; digest over all shards, positions relative to each shard's first base
+        // [lo, hi) of `total` bases for piece g of n: contiguous, balanced to one base
+        static std::pair<uint64_t, uint64_t> base_range(uint64_t total, int g, int n)
+        {
+            auto cut = [&](int i) -> uint64_t { return total / (uint64_t)n * (uint64_t)i + total % (uint64_t)n * (uint64_t)i / (uint64_t)n; };
+            return {cut(g), g + 1 >= n ? total : cut(g + 1)};
+        }
+        // pieces every device cuts its share into (default 1).  More than one exercises the cutting on a box with a single GPU.
+        void set_pieces_per_device(int pieces) noexcept {ppd = pieces < 1 ? 1 : pieces;}
+
+        // minimizer scan (unit-mers, window w) of host sequences; digest over the whole, positions global
         scan_digest minimizers(char const* bases, uint64_t const* offsets, uint64_t n_seqs, uint32_t unit, uint32_t w, uint64_t seed, bool canonical)
         {
-            return run(bases, offsets, n_seqs, [=](bl_ctx* c, bl_batch* b, uint64_t first, uint64_t n, bl_result* r) {
+            return run(bases, offsets, n_seqs, unit + w - 1, 0, [=](bl_ctx* c, bl_batch* b, uint64_t first, uint64_t n, bl_result* r) {
                 return bl_scan_minimizers(c, b, first, n, unit, w, seed, canonical ? (uint32_t)BL_FLAG_CANONICAL : 0u, nullptr, nullptr, nullptr, 0, r);
             });
         }
@@ -68,7 +82,7 @@ class multi_gpu
         scan_digest syncmers(char const* bases, uint64_t const* offsets, uint64_t n_seqs, uint32_t k, uint32_t s, uint32_t start_offset, uint32_t end_offset,
                              bool canonical)
         {
-            return run(bases, offsets, n_seqs, [=](bl_ctx* c, bl_batch* b, uint64_t first, uint64_t n, bl_result* r) {
+            return run(bases, offsets, n_seqs, k, 0, [=](bl_ctx* c, bl_batch* b, uint64_t first, uint64_t n, bl_result* r) {
                 return bl_scan_syncmers(c, b, first, n, k, s, start_offset, end_offset, 0, canonical ? (uint32_t)BL_FLAG_CANONICAL : 0u, nullptr, 0, r);
             });
         }
@@ -111,16 +125,17 @@ class multi_gpu
         std::vector<bl_ctx*> ctxs;
         std::vector<scan_digest> last;
         uint64_t file_bases = 0;
+        int ppd = 1;
 
-        // scan a whole batch in ranges that end on sequence boundaries where offsets are known (fixed read length otherwise)
-        static scan_digest scan_batch(bl_ctx* c, bl_batch* b, uint64_t n_bases, uint64_t align, scan_fn const& scan)
+        // scan the range [first, first + n_bases) of a batch in calls that end on read boundaries for fixed-length reads
+        static scan_digest scan_batch(bl_ctx* c, bl_batch* b, uint64_t n_bases, uint64_t align, scan_fn const& scan, uint64_t first = 0)
         {
             std::vector<bl_result> res;
             const uint64_t step = align ? std::max<uint64_t>(align, RANGE / align * align) : RANGE;
             res.reserve(n_bases / step + 1);
             for (uint64_t a = 0; a < n_bases; a += step) {
                 res.emplace_back();
-                check(scan(c, b, a, std::min(step, n_bases - a), &res.back()), "scan");
+                check(scan(c, b, first + a, std::min(step, n_bases - a), &res.back()), "scan");
             }
             check(bl_ctx_sync(c), "bl_ctx_sync");
             scan_digest d;
@@ -163,19 +178,35 @@ class multi_gpu
             for (auto const& e : errors)
                 if (e) std::rethrow_exception(e);
         }
-        scan_digest run(char const* bases, uint64_t const* offsets, uint64_t n_seqs, scan_fn scan)
+        // span: bases of one window (unit + w - 1; k for k-mer scans); tail: 1 for scans that drop the k-mer that ends its sequence
+        scan_digest run(char const* bases, uint64_t const* offsets, uint64_t n_seqs, uint64_t span, uint64_t tail, scan_fn scan)
         {
-            const int n = devices();
+            const int n = devices(), pieces = n * ppd;
+            const uint64_t total = offsets[n_seqs];
             last.assign(n, scan_digest());
             in_parallel([&](int g) {
-                auto [lo, hi] = shard_of(offsets, n_seqs, g, n);
-                if (hi == lo) return;
-                std::vector<uint64_t> local(hi - lo + 1);
-                for (uint64_t q = lo; q <= hi; ++q) local[q - lo] = offsets[q] - offsets[lo];
-                bl_batch* b = nullptr;
-                check(bl_batch_upload(ctxs[g], bases + offsets[lo], local.back(), local.data(), hi - lo, &b), "bl_batch_upload");
-                try { last[g] = scan_batch(ctxs[g], b, local.back(), 0, scan); } catch (...) { bl_batch_destroy(b); throw; }
-                bl_batch_destroy(b);
+                for (int piece = g * ppd; piece < (g + 1) * ppd; ++piece) {
+                    auto [lo, hi] = base_range(total, piece, pieces);
+                    if (hi <= lo) continue;
+                    // the piece: one base in front of lo (does the window at lo open an occurrence?), the last window's bases behind hi
+                    const uint64_t piece_lo = lo ? lo - 1 : 0, piece_hi = std::min(total, hi + span - 1 + tail);
+                    std::vector<uint64_t> local = {0};  // sequence starts strictly inside the piece; its first base opens a sequence
+                    for (uint64_t const* q = std::upper_bound(offsets, offsets + n_seqs + 1, piece_lo); q < offsets + n_seqs + 1 && *q < piece_hi; ++q)
+                        local.push_back(*q - piece_lo);
+                    local.push_back(piece_hi - piece_lo);
+                    bl_batch* b = nullptr;
+                    check(bl_batch_upload(ctxs[g], bases + piece_lo, piece_hi - piece_lo, local.data(), local.size() - 1, &b), "bl_batch_upload");
+                    scan_digest d;
+                    try {
+                        check(bl_batch_set_origin(b, piece_lo), "bl_batch_set_origin");
+                        d = scan_batch(ctxs[g], b, hi - lo, 0, scan, lo - piece_lo);
+                    } catch (...) { bl_batch_destroy(b); throw; }
+                    bl_batch_destroy(b);
+                    last[g].count += d.count;
+                    last[g].xor_value ^= d.xor_value;
+                    last[g].xor_hash ^= d.xor_hash;
+                    last[g].xor_pos ^= d.xor_pos;
+                }
             });
             return reduce();
         }

@@ -65,8 +65,45 @@ int main()
             CHECK(expect_lo == 1000, "shards cover the reads");
         }
     }
-    // host reads: ragged lengths, the digest equals the oracle's over the whole input when one device takes everything,
-    // and count / XOR(value) / XOR(hash) equal it for any number of devices (positions are shard-relative)
+    // base_range: contiguous, covering, balanced to one base
+    for (uint64_t total : {0ull, 1ull, 1000ull, 400000000007ull})
+        for (int n : {1, 2, 3, 8}) {
+            uint64_t expect_lo = 0, least = ~0ull, most = 0;
+            for (int g = 0; g < n; ++g) {
+                auto [lo, hi] = biolib_amd::multi_gpu::base_range(total, g, n);
+                CHECK(lo == expect_lo && hi >= lo, "piece %d of %d", g, n);
+                least = std::min(least, hi - lo); most = std::max(most, hi - lo);
+                expect_lo = hi;
+            }
+            CHECK(expect_lo == total && most - least <= 1, "pieces cover %llu bases evenly", (unsigned long long)total);
+        }
+    // ONE contig with breaks, cut by bases into 1, 3 and 7 pieces per device (halo of (unit-1)+(w-1) bases, windows
+    // owned by the piece that holds their first base, positions global): all four digests, the position digest included, equal
+    // the oracle's over the whole contig
+    {
+        const uint64_t n = 5000000;
+        std::string s(n, 'A');
+        blo_synth(21, 0, n, s.data());
+        for (uint64_t p = 777; p < n; p += 10007) s[p] = "NnRY-"[p % 5];
+        const uint64_t offs[2] = {0, n};
+        uint64_t dg[4];
+        blo_minimizer_digest(s.data(), offs, 1, 31, 11, 42, 1, 1, dg);
+        std::vector<uint64_t> pos(n);
+        const uint64_t cnt = blo_syncmers(s.data(), offs, 1, 31, 11, 0, 20, 1, 0, 1, pos.data(), pos.size());
+        uint64_t xp = 0;
+        for (uint64_t i = 0; i < cnt; ++i) xp ^= pos[i];
+        for (int pieces : {1, 3, 7}) {
+            node.set_pieces_per_device(pieces);
+            auto got = node.minimizers(s.data(), offs, 1, 31, 11, 42, true);
+            CHECK(got.count == dg[0] && got.xor_value == dg[1] && got.xor_hash == dg[2] && got.xor_pos == dg[3], "one contig in %d piece(s) per device: %llu vs %llu",
+                  pieces, (unsigned long long)got.count, (unsigned long long)dg[0]);
+            auto sy = node.syncmers(s.data(), offs, 1, 31, 11, 0, 20, true);
+            CHECK(sy.count == cnt && sy.xor_pos == xp, "syncmers of one contig in %d piece(s): %llu vs %llu", pieces, (unsigned long long)sy.count, (unsigned long long)cnt);
+        }
+        node.set_pieces_per_device(1);
+    }
+    // host reads: ragged lengths; the digests — positions are global — equal the oracle's over the whole input for any number of
+    // devices and pieces
     {
         const uint64_t n = 3000000;
         std::string s(n, 'A');
@@ -80,7 +117,11 @@ int main()
         auto got = node.minimizers(s.data(), offs.data(), n_seqs, 31, 11, 42, true);
         CHECK(got.count == dg[0] && got.xor_value == dg[1] && got.xor_hash == dg[2], "minimizers over %d device(s): %llu vs %llu", node.devices(),
               (unsigned long long)got.count, (unsigned long long)dg[0]);
-        if (node.devices() == 1) CHECK(got.xor_pos == dg[3], "position digest");
+        CHECK(got.xor_pos == dg[3], "position digest");
+        node.set_pieces_per_device(5);
+        auto cut = node.minimizers(s.data(), offs.data(), n_seqs, 31, 11, 42, true);
+        CHECK(cut.count == dg[0] && cut.xor_value == dg[1] && cut.xor_hash == dg[2] && cut.xor_pos == dg[3], "reads cut into 5 pieces per device");
+        node.set_pieces_per_device(1);
         std::vector<uint64_t> pos(n);
         const uint64_t cnt = blo_syncmers(s.data(), offs.data(), n_seqs, 31, 11, 0, 20, 1, 0, 1, pos.data(), pos.size());
         auto sy = node.syncmers(s.data(), offs.data(), n_seqs, 31, 11, 0, 20, true);

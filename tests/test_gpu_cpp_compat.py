@@ -9,11 +9,16 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def built(name):
+    """the test program, rebuilt by make whenever a header under include/ (or its source) is newer than the binary: a stale
+    binary must not pass for the headers of the tree"""
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "cpp")], timeout=900)
+    return os.path.join(ROOT, "tests", "cpp", "_build", name)
+
+
 @pytest.mark.gpu
 def test_cpp_compat_views():
-    exe = os.path.join(ROOT, "tests", "cpp", "_build", "test_compat_views")
-    if not os.path.exists(exe):
-        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "cpp")])
+    exe = built("test_compat_views")
     out = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-4000:] + out.stderr[-4000:]
     assert "test_compat_views: OK" in out.stdout
@@ -23,9 +28,7 @@ def test_cpp_compat_views():
 def test_cpp_compat_jaccard(tmp_path):
     """the reference's Jaccard tool body (tests/test_jaccard.cpp:55-130) over external_memory_vector / ordered_unique_sampler /
     jaccard from include/compat/, on two fixture files"""
-    exe = os.path.join(ROOT, "tests", "cpp", "_build", "test_compat_jaccard")
-    if not os.path.exists(exe):
-        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "cpp")])
+    exe = built("test_compat_jaccard")
     ing = os.path.join(ROOT, "tests", "golden", "ingest")
     out = subprocess.run([exe, os.path.join(ing, "many.fa"), os.path.join(ing, "many.fa.gz"), str(tmp_path)], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "Jaccard : " in out.stdout, out.stdout[-4000:] + out.stderr[-4000:]
@@ -38,9 +41,7 @@ def test_cpp_compat_jaccard(tmp_path):
 @pytest.mark.gpu
 def test_cpp_multi_gpu_driver():
     """include/compat/multi_gpu.hpp + bl_count_allreduce (RCCL C API) with every visible device (one on the test box)"""
-    exe = os.path.join(ROOT, "tests", "cpp", "_build", "test_multi_gpu")
-    if not os.path.exists(exe):
-        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "cpp")])
+    exe = built("test_multi_gpu")
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     out = subprocess.run([exe], capture_output=True, text=True, timeout=900, env=env)
     assert out.returncode == 0 and "test_multi_gpu: OK" in out.stdout, out.stdout[-4000:] + out.stderr[-4000:]
@@ -56,9 +57,7 @@ def test_cpp_view_loop_pooled_vs_per_view(tmp_path):
 
     import oracle_lib as O
 
-    exe = os.path.join(ROOT, "tests", "cpp", "_build", "bench_view_loop")
-    if not os.path.exists(exe):
-        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "cpp")])
+    exe = built("bench_view_loop")
     n_reads, L = 20_000, 150
     seq = O.synth(3, n_reads * L)
     seq[::1009] = ord("N")
@@ -86,9 +85,7 @@ def test_cpp_minimizer_loop_pooled_vs_per_view(tmp_path):
 
     import oracle_lib as O
 
-    exe = os.path.join(ROOT, "tests", "cpp", "_build", "bench_view_loop")
-    if not os.path.exists(exe):
-        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "cpp")])
+    exe = built("bench_view_loop")
     rng = np.random.default_rng(6)
     lens = rng.integers(12, 300, 20_000)  # some reads shorter than k: no window, no record
     offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
@@ -119,9 +116,7 @@ def test_cpp_super_kmer_loop_pooled_vs_per_view(tmp_path):
 
     import oracle_lib as O
 
-    exe = os.path.join(ROOT, "tests", "cpp", "_build", "bench_view_loop")
-    if not os.path.exists(exe):
-        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "cpp")])
+    exe = built("bench_view_loop")
     rng = np.random.default_rng(16)
     lens = rng.integers(20, 300, 20_000)  # some reads shorter than k
     offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
