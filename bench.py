@@ -39,6 +39,28 @@ MODEL_PATH = os.path.join(ROOT, "profiles", "valu_model.json")   # tools/valu_mo
 TRAFFIC_PATH = os.path.join(ROOT, "profiles", "traffic.json")    # tools/summarise_profiles.py
 
 
+KERNEL_SOURCES = ("bl_kernels.hip", "bl_scan_core.hpp", "bl_scan_phases.hpp", "bl_scan_frl.hpp", "bl_launch.hpp")  # what the scan kernels are compiled from
+
+
+def kernel_sources_digest(root=ROOT):
+    """sha256 over the scan kernels' sources.  tools/summarise_profiles.py stamps profiles/traffic.json and valu_model.json with
+    it when it turns a collection run into those files; this run recomputes it: a difference means the counters the roofline
+    line quotes were measured on OTHER kernels than the ones that ran (`traffic_stale`, `valu.stale`)."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for name in KERNEL_SOURCES:
+        h.update(name.encode())
+        with open(os.path.join(root, "biolib_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def profile_is_stale(provenance, digest):
+    """True unless the profile carries the digest of the sources as they are now (a profile without one is of unknown age: stale)."""
+    return (provenance or {}).get("kernel_sources_sha256") != digest
+
+
 def load_json_or_none(path):
     """A missing profile file is reported as such in the JSON line; a broken one is an error, not a silent null."""
     if not os.path.exists(path):
@@ -60,7 +82,7 @@ def valu_ceiling(model, kernels, bases, seconds, ghz):
         parts[k] = {"valu_lane_instr_per_base": round(km["valu_per_base"] * 64, 1), "simd_cycles_per_base": round(km["cycles_per_base"], 4),
                     "avg_issue_cycles": round(km["cycles_per_base"] / km["valu_per_base"], 3)}
     avail = N_SIMD * ghz * 1e9 * seconds
-    return {"frac": round(need / avail, 4), "simd_cycles_needed": int(need), "simd_cycles_available": int(avail), "shader_clock_GHz": round(ghz, 3),
+    return {"frac": round(need / avail, 4), "stale": profile_is_stale(model["provenance"].get("pmc"), kernel_sources_digest()), "simd_cycles_needed": int(need), "simd_cycles_available": int(avail), "shader_clock_GHz": round(ghz, 3),
             "kernels": parts, "issue_cycles": model["issue_cycles"], "source": model["provenance"]}
 
 
@@ -75,6 +97,8 @@ def main():
                     help="execution lanes of the context: 2 = the record pass of one range runs beside the hashing pass of the next")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true")
+    ap.add_argument("--no-next-rows", action="store_true")
+    ap.add_argument("--no-h2d", action="store_true", help="skip the upload-inclusive companion figure")
     ap.add_argument("--other-gbp", type=float, default=0.0, help="size of the other configs (0 = as BASELINE.json states them: 10 / 50 / 50 Gbp)")
     args = ap.parse_args()
 
@@ -149,12 +173,16 @@ def main():
     probe = None if os.environ.get("BL_NO_CLOCK_PROBE") else ctx.clock_probe_start(5000)  # (switch: A/B runs under a profiler)
     t0 = time.perf_counter()
     all_res = []
+    ctx.mark()  # markers on the device's timeline behind every step: per-step times without a sync between the steps
     for _ in range(args.steps):
         one_step(all_res)
+        ctx.mark()
     ctx.sync()
     clock_ghz = ctx.clock_probe_finish(probe) if probe is not None else 2.4
     barrier()
     elapsed = time.perf_counter() - t0
+    marks = ctx.mark_times()
+    step_ms = [b - a for a, b in zip(marks[:-1], marks[1:])]
     kernel_ms, launches = ctx.kernel_time()
     ctx.kernel_timing(False)
     for r in all_res:
@@ -172,10 +200,19 @@ def main():
     t_max = elapsed
     total_count = count
     allreduce_ms = None
+    rank_ms = [elapsed / args.steps * 1e3]
+    c5_reduce = None
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         t_max = float(t.item())
+        # per-step times: the slowest rank's; per-rank whole-run times: a straggler shows as max >> min
+        sm = torch.tensor(step_ms, dtype=torch.float64, device=coll_dev)
+        dist.all_reduce(sm, op=dist.ReduceOp.MAX)
+        step_ms = [float(x) for x in sm.cpu().tolist()]
+        every = [torch.zeros(1, dtype=torch.float64, device=coll_dev) for _ in range(world)]
+        dist.all_gather(every, torch.tensor([elapsed / args.steps * 1e3], dtype=torch.float64, device=coll_dev))
+        rank_ms = [float(x.item()) for x in every]
         # optional final count reduction over RCCL/xGMI (64-bit sums all-reduced, XOR digests gathered and
         # folded: biolib_amd/shard.py); outside the timed region, its time is reported
         from biolib_amd.shard import reduce_digests
@@ -189,6 +226,7 @@ def main():
         k = torch.tensor([kernel_ms], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(k, op=dist.ReduceOp.MAX)
         kernel_ms = float(k.item())
+        c5_reduce = c5_count_reduce(ctx, torch, dist, rank, world, coll_dev)
 
     out = None
     if rank == 0:
@@ -196,12 +234,15 @@ def main():
         prof = load_json_or_none(TRAFFIC_PATH)
         total_bases = float(n_bases) * n_gpus * args.steps
         value = total_bases / t_max / 1e9
+        step_values = sorted(float(n_bases) * n_gpus / (ms / 1e3) / 1e9 for ms in step_ms if ms > 0)
         bases_per_launch = sum(n for _, n in ranges) / len(ranges)
         avg_kernel_s = kernel_ms / 1e3 / max(launches, 1)
         achieved = bases_per_launch * 1.0 / avg_kernel_s / 1e9  # 1 algorithmic byte per base
         range_s = t_max / args.steps / len(ranges)
         traffic, hbm_actual, traffic_note = None, None, "profiles/traffic.json missing: no PMC traffic figure"
+        traffic_stale = True
         if prof is not None:
+            traffic_stale = profile_is_stale(prof.get("provenance"), kernel_sources_digest())
             c3 = prof["c3"]
             traffic = int(c3["count_kernel"]["hbm_bytes_per_base"] * bases_per_launch)  # PMC bytes per base x this run's bases per launch
             both = (c3["count_kernel"]["hbm_bytes_per_base"] + c3["emit_kernel"]["hbm_bytes_per_base"]) * bases_per_launch
@@ -215,6 +256,11 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(t_max / args.steps * 1e3, 3),
+            "median_value": round(step_values[len(step_values) // 2], 3) if step_values else None,
+            "best_value": round(step_values[-1], 3) if step_values else None,
+            "step_ms": [round(x, 3) for x in step_ms],
+            "step_ms_note": "device timeline markers behind every step (bl_ctx_mark), slowest rank per step; value = all steps / host wall time between the barriers",
+            "rank_ms_per_step": {"min": round(min(rank_ms), 3), "max": round(max(rank_ms), 3)},
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -230,7 +276,7 @@ def main():
             "xor_hash": xor_hash,
             "roofline": {
                 "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5),
-                "traffic": traffic, "traffic_source": traffic_note,
+                "traffic": traffic, "traffic_stale": traffic_stale, "traffic_source": traffic_note,
                 "kernel": "bl::scan_count_frl_kernel<MODE_MINIMIZER,W=11,NS=15,U=31,L=150,C=1> (pass 1 of 2, read-tiled)", "avg_kernel_ms": round(avg_kernel_s * 1e3, 4),
                 "launches_timed": launches, "algorithmic_bytes_per_launch": int(bases_per_launch),
                 "note": "VALU-issue bound before HBM: 6 x 64-bit multiplies per 31-mer (MurmurHash3_x64_128), see roofline.valu and DESIGN.md"
@@ -253,20 +299,98 @@ def main():
                 out["roofline"]["peak_measured"] = {"error": str(e)}
         if allreduce_ms is not None:
             out["count_allreduce_ms"] = round(allreduce_ms, 3)
+        if c5_reduce is not None:
+            out["c5_count_reduce"] = c5_reduce
         if n_gpus == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(np, ctx, batch, n_bases)
+        if n_gpus == 1 and not args.no_h2d:
+            try:
+                out["h2d_inclusive_Gbps"] = h2d_inclusive(np, torch, biolib_amd, dev, batch, cap)
+            except Exception as e:  # the companion figure must not lose the bench line
+                out["h2d_inclusive_Gbps"] = {"error": repr(e)[:300]}
     if n_gpus == 1 and not args.no_other_configs:
         batch.close()
         del outs
         torch.cuda.empty_cache()
         out["other_configs"] = other_configs(ctx, args, load_json_or_none(MODEL_PATH))
-        out["next_rows"] = next_rows(ctx)
+        if not args.no_next_rows:
+            out["next_rows"] = next_rows(ctx)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     return out
+
+
+def h2d_inclusive(np, torch, biolib_amd, dev, batch, cap):
+    """The upload-INCLUSIVE rate of the same scan ("end-to-end incl. H2D reported separately"; the reference's
+    drivers start from host memory, tests/test_kmer_view.cpp:30-42): 8.25 Gbp of the shard's reads leave page-locked host
+    memory in eleven chunks through bl_batch_upload_reads and are scanned as they arrive, records materialised as in the
+    headline.  Double-buffered over two contexts: the upload of one chunk (synchronous, as the ABI promises the caller its
+    buffer back) runs beside the scan of the chunk before it.  Never `value`: inputs of the headline are resident."""
+    n_chunk = 5_000_000 * READ_LEN
+    n_chunks = 11
+    n_chunk = min(n_chunk, batch.n_bases // READ_LEN * READ_LEN)
+    host = torch.empty(n_chunk, dtype=torch.uint8).pin_memory()
+    host.numpy()[:] = batch.download(0, n_chunk)
+    ctxs = [biolib_amd.Context(dev, torch_stream=False, lanes=1) for _ in range(2)]
+    outs = [tuple(c.empty_u64(cap) for _ in range(3)) for c in ctxs]
+    live = [None, None]
+    res = []
+
+    def run(k):
+        for i in range(k):
+            j = i & 1
+            if live[j] is not None:
+                live[j].close()  # waits for its scan, long finished: it ran beside the other context's upload
+            live[j] = ctxs[j].upload(host.numpy(), read_len=READ_LEN)
+            r = biolib_amd.Result()
+            v, p, h = outs[j]
+            live[j].minimizers_raw(UNIT, W, SEED, biolib_amd.FLAG_CANONICAL, values=v, positions=p, hashes=h, capacity=cap, result=r)
+            res.append(r)
+        for c in ctxs:
+            c.sync()
+
+    run(2)  # buffers allocated, pages touched
+    res.clear()
+    t0 = time.perf_counter()
+    run(n_chunks)
+    dt = time.perf_counter() - t0
+    ok = all(r.status == 0 and r.count == res[0].count and r.xor_hash == res[0].xor_hash for r in res)
+    for b in live:
+        if b is not None:
+            b.close()
+    for c in ctxs:
+        c.close()
+    return {"value": round(n_chunk * n_chunks / dt / 1e9, 2), "unit": "Gbp/s", "bases": n_chunk * n_chunks, "chunks": n_chunks, "host_to_device_GBps": round(n_chunk * n_chunks / dt / 1e9, 2),
+            "every_chunk_same_digest": bool(ok),
+            "path": "page-locked host memory -> bl_batch_upload_reads -> bl_scan_minimizers (records materialised), two contexts alternating: upload beside scan"}
+
+
+def c5_count_reduce(ctx, torch, dist, rank, world, coll_dev):
+    """BASELINE C5's collective, rehearsed in every multi-rank run: each rank counts the syncmers (k=31, s=11, offsets 0 / 20)
+    of its own 1.5-Gbp shard of 10-kbp reads (seed 42 + rank), the counts are summed across the ranks by the path's one
+    collective (biolib_amd.shard.reduce_digests: one all-reduce — RCCL over xGMI under the "nccl" backend) and the sum is checked
+    against the all-gathered per-rank counts."""
+    import biolib_amd as B
+    from biolib_amd.shard import reduce_digests
+
+    L = 10_000
+    n = 1_500_000_000 // L * L
+    b = ctx.synth(SEED + rank, n, L)
+    r = b.syncmers_raw(31, 11, 0, 20, 0, B.FLAG_CANONICAL | B.FLAG_SYNC)
+    mine = int(r.count)
+    b.close()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    total = reduce_digests(dict(count=mine), device=coll_dev)["count"]
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) * 1e3
+    every = [None] * world
+    dist.all_gather_object(every, mine)
+    assert total == sum(every), f"count reduction: {total} != sum of {every}"
+    return {"syncmers_all_ranks": int(total), "per_rank": [int(x) for x in every], "allreduce_ms": round(ms, 3), "sum_checked": True, "backend": dist.get_backend()}
 
 
 def other_configs(ctx, args, model):
@@ -487,6 +611,8 @@ def cpu_baseline(np, ctx, batch, n_bases):
     same = (gc, gv, gh, gp) == (dall["count"], dall["xor_value"], dall["xor_hash"], dall["xor_pos"])
     out = {
         "value": round(nall / tall / 1e9, 4), "unit": "Gbp/s", "cores": cores, "kind": "port",
+        "why_port": "the reference's own minimizer_view yields nothing and its minimizer_sampler does not compile (SURVEY.md §3.4, §8a-a7): the reference "
+                    "cannot run this configuration; it is timed on the part of the path it can run under reference_c2_anchor",
         "sample": f"first {nall // READ_LEN} reads ({nall / 1e9:.2f} Gbp) of rank 0's shard, OpenMP over reads, {cores} threads; "
                   f"single thread on the first {n1 / 1e9:.2f} Gbp",
         "single_thread_value": round(n1 / t1 / 1e9, 4),

@@ -102,6 +102,7 @@ struct bl_ctx {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_open;  // recorded, not yet read
     double kernel_ms = 0.0;
     uint64_t kernel_launches = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> marks;  // bl_ctx_mark: one event per lane stream (second: null with one stream)
     std::vector<bl_batch*> batches;  // live batches: destroyed with the context if the caller did not
     void* scratch[8] = {};  // grow-only device scratch of the non-scan entry points (bl_ctx_scratch)
     size_t scratch_bytes[8] = {};
@@ -506,6 +507,7 @@ int bl_ctx_destroy(bl_ctx* c)
         if (ev) (void)hipEventDestroy(ev);
     for (auto& pr : c->ev_open) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     for (hipEvent_t ev : c->ev_pool) (void)hipEventDestroy(ev);
+    for (auto& pr : c->marks) { (void)hipEventDestroy(pr.first); if (pr.second) (void)hipEventDestroy(pr.second); }
     delete c;
     return BL_OK;
 }
@@ -570,6 +572,50 @@ int bl_ctx_kernel_time(bl_ctx* c, double* total_ms, uint64_t* launches)
     return BL_OK;
 }
 
+// Markers on the device's own timeline, without stopping it: where a caller wants the time at which "everything issued so far" had
+// finished — a step of a benchmark — but must not synchronise there, because the next step's first kernels overlap this one's last.
+int bl_ctx_mark(bl_ctx* c)
+{
+    if (!c) return fail(BL_ERR_INVALID, "ctx is NULL");
+    BL_HIP(hipSetDevice(c->device));
+    std::pair<hipEvent_t, hipEvent_t> m{nullptr, nullptr};
+    BL_HIP(hipEventCreate(&m.first));
+    if (c->borrowed) {
+        BL_HIP(hipEventRecord(m.first, c->user_stream));
+    } else {
+        BL_HIP(hipEventRecord(m.first, c->lanes[0].own));
+        if (c->n_lanes == 2 && c->lanes[1].own) {
+            BL_HIP(hipEventCreate(&m.second));
+            BL_HIP(hipEventRecord(m.second, c->lanes[1].own));
+        }
+    }
+    c->marks.push_back(m);
+    return BL_OK;
+}
+
+int bl_ctx_mark_times(bl_ctx* c, double* ms, uint32_t capacity, uint32_t* n)
+{
+    if (!c || !n || (!ms && capacity)) return fail(BL_ERR_INVALID, "NULL argument");
+    int rc = sync_ctx(c);
+    if (rc != BL_OK) return rc;
+    *n = (uint32_t)c->marks.size();
+    hipError_t e = hipSuccess;
+    for (size_t i = 0; i < c->marks.size(); ++i) {
+        float a = 0.f, b = 0.f;  // since marker 0's event on the first stream: timestamps are the device's, whatever the stream
+        if (e == hipSuccess) e = hipEventSynchronize(c->marks[i].first);
+        if (e == hipSuccess) e = hipEventElapsedTime(&a, c->marks[0].first, c->marks[i].first);
+        if (e == hipSuccess && c->marks[i].second) {
+            e = hipEventSynchronize(c->marks[i].second);
+            if (e == hipSuccess) e = hipEventElapsedTime(&b, c->marks[0].first, c->marks[i].second);
+        }
+        if (i < capacity) ms[i] = a > b ? a : b;
+    }
+    for (auto& pr : c->marks) { (void)hipEventDestroy(pr.first); if (pr.second) (void)hipEventDestroy(pr.second); }
+    c->marks.clear();
+    if (e != hipSuccess) return fail(BL_ERR_HIP, std::string("bl_ctx_mark_times: ") + hipGetErrorString(e));
+    return BL_OK;
+}
+
 // ---------------------------------------------------------------------------------------- batches
 
 static int new_batch(bl_ctx* c, uint64_t n_bases, bl_batch** out, bl_batch*& b)
@@ -585,20 +631,30 @@ static int new_batch(bl_ctx* c, uint64_t n_bases, bl_batch** out, bl_batch*& b)
     return BL_OK;
 }
 
-int bl_batch_upload(bl_ctx* c, const char* bases, uint64_t n_bases, const uint64_t* offsets, uint64_t n_seqs, bl_batch** out)
+// the two upload entry points: sequences given by offsets, or reads of one length (read_len != 0, offsets ignored)
+static int upload_batch(bl_ctx* c, const char* bases, uint64_t n_bases, const uint64_t* offsets, uint64_t n_seqs, uint64_t read_len, bl_batch** out)
 {
     bl_batch* b = nullptr;
     int rc = new_batch(c, n_bases, out, b);
     if (rc != BL_OK) return rc;
     if (n_bases && !bases) { bl_batch_destroy(b); return fail(BL_ERR_INVALID, "bases is NULL"); }
-    hipError_t e = hipMalloc(&b->bases, n_bases + 64);
-    if (e != hipSuccess) { bl_batch_destroy(b); return fail(BL_ERR_OOM, std::string("hipMalloc(bases): ") + hipGetErrorString(e)); }
+    // from the context's pool of batch buffers: a stream of uploads reuses a few buffers instead of paying a device-wide wait per hipFree
+    b->bases = static_cast<uint8_t*>(bl_ctx_pool_alloc(c, n_bases + 64));
+    if (!b->bases) { bl_batch_destroy(b); return fail(BL_ERR_OOM, "device allocation of the batch's bases failed"); }
     b->owns_bases = true;
-    e = hipMemsetAsync(b->bases + (n_bases & ~15ull), 0, 64 + (n_bases & 15ull), c->stream);
+    hipError_t e = hipMemsetAsync(b->bases + (n_bases & ~15ull), 0, 64 + (n_bases & 15ull), c->stream);
     if (e == hipSuccess && n_bases) e = hipMemcpyAsync(b->bases, bases, n_bases, hipMemcpyHostToDevice, c->stream);
     if (e != hipSuccess) { bl_batch_destroy(b); return fail(BL_ERR_HIP, std::string("upload: ") + hipGetErrorString(e)); }
     uint64_t fixed = 0;  // offsets that describe equal-length reads (the usual short-read batch) need no start-bit vector
-    if (offsets && n_seqs > 1 && offsets[0] == 0 && offsets[n_seqs] == n_bases && offsets[1] > 0 && offsets[1] < n_bases) {
+    if (read_len) {
+        if (read_len < n_bases) {
+            fixed = read_len;
+            n_seqs = (n_bases + read_len - 1) / read_len;
+        } else {
+            offsets = nullptr;  // one read
+            n_seqs = 0;
+        }
+    } else if (offsets && n_seqs > 1 && offsets[0] == 0 && offsets[n_seqs] == n_bases && offsets[1] > 0 && offsets[1] < n_bases) {
         fixed = offsets[1];
         for (uint64_t q = 1; q < n_seqs && fixed; ++q)
             if (offsets[q] != q * fixed) fixed = 0;
@@ -617,6 +673,17 @@ int bl_batch_upload(bl_ctx* c, const char* bases, uint64_t n_bases, const uint64
     if (rc != BL_OK) { bl_batch_destroy(b); return rc; }
     *out = b;
     return BL_OK;
+}
+
+int bl_batch_upload(bl_ctx* c, const char* bases, uint64_t n_bases, const uint64_t* offsets, uint64_t n_seqs, bl_batch** out)
+{
+    return upload_batch(c, bases, n_bases, offsets, n_seqs, 0, out);
+}
+
+int bl_batch_upload_reads(bl_ctx* c, const char* bases, uint64_t n_bases, uint64_t read_len, bl_batch** out)
+{
+    if (read_len == 0) return fail(BL_ERR_INVALID, "read_len must not be 0");
+    return upload_batch(c, bases, n_bases, nullptr, 0, read_len, out);
 }
 
 int bl_batch_from_device(bl_ctx* c, const void* d_bases, uint64_t n_bases, const uint64_t* offsets, uint64_t n_seqs, uint64_t read_len,

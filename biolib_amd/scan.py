@@ -102,11 +102,27 @@ class Context:
         check(self._lib.bl_ctx_kernel_time(self._h, C.byref(ms), C.byref(n)))
         return float(ms.value), int(n.value)
 
+    def mark(self):
+        """a marker on the device's timeline behind everything issued so far (bl_ctx_mark): does not stop the device"""
+        check(self._lib.bl_ctx_mark(self._h))
+
+    def mark_times(self):
+        """synchronises; milliseconds after the first marker at which the work in front of each marker had finished; forgets the markers"""
+        n = C.c_uint32()
+        buf = (C.c_double * 4096)()
+        check(self._lib.bl_ctx_mark_times(self._h, buf, 4096, C.byref(n)))
+        return [float(buf[i]) for i in range(min(int(n.value), 4096))]
+
     # ---- batches
-    def upload(self, bases, offsets=None):
+    def upload(self, bases, offsets=None, read_len=0):
+        """host bases -> device batch; sequences by `offsets`, or reads of one length `read_len` laid end to end (bl_batch_upload_reads)"""
         if isinstance(bases, str):
             bases = bases.encode()
         arr = np.frombuffer(bytes(bases), dtype=np.uint8) if isinstance(bases, (bytes, bytearray)) else np.ascontiguousarray(bases, dtype=np.uint8)
+        if read_len:
+            h = C.c_void_p()
+            check(self._lib.bl_batch_upload_reads(self._h, arr.ctypes.data_as(C.c_void_p) if arr.size else None, arr.size, int(read_len), C.byref(h)))
+            return Batch(self, h)
         offs = None if offsets is None else np.ascontiguousarray(offsets, dtype=np.uint64)
         h = C.c_void_p()
         check(self._lib.bl_batch_upload(self._h, arr.ctypes.data_as(C.c_void_p) if arr.size else None, arr.size,

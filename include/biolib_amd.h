@@ -99,6 +99,9 @@ int bl_ctx_set_lanes(bl_ctx* ctx, int n);
 /* Copy host sequences to the device.  offsets has n_seqs+1 entries, offsets[0] = 0,
  * offsets[n_seqs] = n_bases; NULL offsets = one sequence. */
 int bl_batch_upload(bl_ctx* ctx, const char* bases, uint64_t n_bases, const uint64_t* offsets, uint64_t n_seqs, bl_batch** out);
+/* The same for reads of ONE length laid end to end (a shorter last read is kept): no offsets array to build or to check — a
+ * batch of 150-bp reads has 7 million of them per gigabase.  Such batches are scanned by the read-tiled kernels. */
+int bl_batch_upload_reads(bl_ctx* ctx, const char* bases, uint64_t n_bases, uint64_t read_len, bl_batch** out);
 /* Wrap bases already in device memory (16-byte aligned, not copied, must outlive the batch).
  * Sequences are either given by host `offsets` (as above) or, if offsets is NULL and read_len > 0,
  * consecutive slices of read_len bases (a shorter last read is kept); both NULL/0 = one sequence. */
@@ -178,6 +181,12 @@ int bl_ctx_last_scan_ms(bl_ctx* ctx, float* ms);
  * switched on (switching it on or off resets both). */
 int bl_ctx_kernel_timing(bl_ctx* ctx, int enable);
 int bl_ctx_kernel_time(bl_ctx* ctx, double* total_ms, uint64_t* launches);
+/* Markers on the device's timeline that do not stop it.  bl_ctx_mark enqueues one behind everything issued so far on the
+ * context's stream(s); bl_ctx_mark_times synchronises, returns for each marker the milliseconds after marker 0 was reached at
+ * which the work in front of it had finished (with two lanes: on both), and forgets the markers.  A benchmark times its steps
+ * with them: a bl_ctx_sync between steps would cost the overlap of one step's last record pass with the next step's first scan. */
+int bl_ctx_mark(bl_ctx* ctx);
+int bl_ctx_mark_times(bl_ctx* ctx, double* ms, uint32_t capacity, uint32_t* n_marks);
 
 /* ---- ingest: FASTA / FASTQ, plain or gzip -> batches -----------------------------
  * Record semantics are those of the reader biolib's own tools use (reference tests/kseq.h:185-234): a record

@@ -2,8 +2,8 @@
 # Run ON THE GPU BOX (through gpurun) from the repo root: collects what profiles/ holds for this round.
 #   1. rocprofv3 --kernel-trace --stats of the default bench command (two lanes) and of --lanes 1
 #   2. PMC passes (separate runs, --kernel-trace only, as MI355X_MICROARCH.md prescribes): FETCH_SIZE, WRITE_SIZE, SQ counters,
-#      over ONE lane so that every counter belongs to exactly one kernel, all BASELINE configurations in one command
-#      (C3 at 6 Gbp, the others at 3 Gbp: 1.5e9 bases per launch everywhere)
+#      with the DEFAULT bench command's workloads (C3 at 50 Gbp, the others at their stated sizes) over ONE lane, so that every
+#      counter belongs to exactly one kernel; one timed step (the counters do not need repetitions)
 #   3. the VALU issue-cost table (tools/ubench_valu.hip)
 # Outputs under gpurun_out/prof/; tools/summarise_profiles.py (in the build container, where git is) turns them into profiles/.
 set -o pipefail
@@ -13,9 +13,9 @@ rm -rf $OUT && mkdir -p $OUT
 (hostname; date -u +%Y-%m-%dT%H:%M:%SZ; /opt/rocm/bin/rocminfo 2>/dev/null | grep -m1 "Marketing Name.*MI3" ) > $OUT/box.txt 2>&1
 cd /tmp && export TMPDIR=/tmp
 $ROOT/tools/_build/ubench_valu --json $OUT/ubench_valu.json > $OUT/ubench_valu.txt 2>&1 || exit 1
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_lanes2 -o s -- python3 $ROOT/bench.py --no-cpu-baseline > $OUT/stats_lanes2.log 2>&1 || exit 1
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_lanes1 -o s -- python3 $ROOT/bench.py --lanes 1 --no-cpu-baseline > $OUT/stats_lanes1.log 2>&1 || exit 1
-PMC_CMD="python3 $ROOT/bench.py --gbp 6 --other-gbp 3 --steps 1 --warmup 0 --lanes 1 --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_lanes2 -o s -- python3 $ROOT/bench.py --no-cpu-baseline --no-next-rows > $OUT/stats_lanes2.log 2>&1 || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_lanes1 -o s -- python3 $ROOT/bench.py --lanes 1 --no-cpu-baseline --no-next-rows > $OUT/stats_lanes1.log 2>&1 || exit 1
+PMC_CMD="python3 $ROOT/bench.py --steps 1 --warmup 0 --lanes 1 --no-cpu-baseline --no-next-rows"
 echo "$PMC_CMD" > $OUT/pmc_command.txt
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o p -- $PMC_CMD > $OUT/pmc_fetch.log 2>&1 || exit 1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o p -- $PMC_CMD > $OUT/pmc_write.log 2>&1 || exit 1

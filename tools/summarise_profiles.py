@@ -5,16 +5,27 @@ traffic.json — each stamped with where and from which commit it was measured. 
 import collections, csv, json, os, shutil, subprocess, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-RND = sys.argv[1] if len(sys.argv) > 1 else "r02"
+RND = sys.argv[1] if len(sys.argv) > 1 else "r03"
 src = os.path.join(ROOT, "gpurun_out", "prof")
 dst = os.path.join(ROOT, "profiles")
-BASES = 1_500_000_000  # every launch of the PMC command covers 1.5e9 bases (collect_profiles.sh)
+sys.path.insert(0, ROOT)
+from bench import kernel_sources_digest  # what bench.py compares at run time: traffic_stale / valu_stale
 
 git = lambda *a: subprocess.run(["git", "-C", ROOT, *a], capture_output=True, text=True).stdout.strip()
 box = open(os.path.join(src, "box.txt")).read().split("\n")
 prov = {"commit": git("rev-parse", "--short", "HEAD") + ("+dirty" if git("status", "--porcelain", "--untracked-files=no") else ""),
         "box": box[0], "collected_utc": box[1] if len(box) > 1 else "", "command": open(os.path.join(src, "pmc_command.txt")).read().strip(),
-        "tools": "tools/collect_profiles.sh + tools/summarise_profiles.py"}
+        "tools": "tools/collect_profiles.sh + tools/summarise_profiles.py", "kernel_sources_sha256": kernel_sources_digest()}
+
+# bases per launch of every configuration, from the JSON line the PMC command itself printed (its workloads are bench.py's defaults)
+line = [x for x in open(os.path.join(src, "pmc_sq1.log")).read().splitlines() if x.startswith("{")][-1]
+bj = json.loads(line)
+per_launch = {"c3": bj["config"]["bases_per_launch"]}
+for cfg, key in (("c2", "C2_kmer_hash_10Gbp"), ("c4", "C4_super_kmers_50Gbp_10kbp_reads"), ("c5", "C5_syncmers_50Gbp_shard_10kbp_reads")):
+    oc = bj["other_configs"][key]
+    per_launch[cfg] = oc["bases"] * oc["steps"] / oc["launches_timed"]
+BASES_OF = {"c3_count": per_launch["c3"], "c3_emit": per_launch["c3"], "c2_kmer": per_launch["c2"], "c4_count": per_launch["c4"], "c4_emit": per_launch["c4"],
+            "c5_count": per_launch["c5"], "c5_emit": per_launch["c5"]}
 
 shutil.copy(os.path.join(src, "stats_lanes2", "s_kernel_stats.csv"), os.path.join(dst, f"{RND}_kernel_stats.csv"))
 shutil.copy(os.path.join(src, "stats_lanes1", "s_kernel_stats.csv"), os.path.join(dst, f"{RND}_kernel_stats_lanes1.csv"))
@@ -29,8 +40,8 @@ for lanes in ("lanes2", "lanes1"):
 kernels = {
     "c3_count": "scan_count_frl_kernel<0, 11, 15, 31, 150, 1>", "c3_emit": "scan_emit_kernel<0>",
     "c2_kmer": "kmer_kernel",
-    "c4_count": "scan_count_kernel<1, 17, 15, 1>", "c4_emit": "scan_emit_kernel<1>",
-    "c5_count": "scan_count_kernel<2, 21, 11, 1>", "c5_emit": "scan_emit_kernel<2>",
+    "c4_count": "scan_count_kernel<1, 17, 15, 1, false>", "c4_emit": "scan_emit_kernel<1>",
+    "c5_count": "scan_count_kernel<2, 21, 11, 1, true>", "c5_emit": "scan_emit_kernel<2>",
 }
 means = {k: {} for k in kernels}
 for d in ("pmc_fetch", "pmc_write", "pmc_sq1", "pmc_sq2", "pmc_sq3"):
@@ -43,12 +54,14 @@ for d in ("pmc_fetch", "pmc_write", "pmc_sq1", "pmc_sq2", "pmc_sq3"):
         for c, v in acc[k].items():
             means[k][c] = (sum(v) / len(v), len(v))
 with open(os.path.join(dst, f"{RND}_pmc_summary.txt"), "w") as f:
-    f.write(f"# {json.dumps(prov)}\n# mean per launch of {BASES:.3g} bases; FETCH_SIZE / WRITE_SIZE in KiB; FETCH_SIZE to be doubled on gfx950 (MI355X_MICROARCH.md, HBM)\n")
+    f.write(f"# {json.dumps(prov)}\n# mean per launch; bases per launch: {json.dumps({k: round(v) for k, v in per_launch.items()})}; FETCH_SIZE / WRITE_SIZE in KiB; FETCH_SIZE to be doubled on gfx950 (MI355X_MICROARCH.md, HBM)\n")
     for k in kernels:
         f.write(f"== {k}: {kernels[k]}\n")
         for c, (m, n) in sorted(means[k].items()):
             f.write(f"{c:28s} n={n:3d} mean={m:.6g}\n")
-pmc = {"provenance": prov, "bases_per_launch": BASES, "kernels": {k: dict(kernel=kernels[k], **{c: m for c, (m, n) in means[k].items()}) for k in kernels}}
+        if "SQ_INSTS_VALU" in means[k]:
+            f.write(f"{'lane-instructions per base':28s} {means[k]['SQ_INSTS_VALU'][0] * 64 / BASES_OF[k]:.2f}\n")
+pmc = {"provenance": prov, "kernels": {k: dict(kernel=kernels[k], bases_per_launch=BASES_OF[k], **{c: m for c, (m, n) in means[k].items()}) for k in kernels}}
 json.dump(pmc, open(os.path.join(dst, f"{RND}_pmc.json"), "w"), indent=1)
 
 hbm = lambda m: (2 * m["FETCH_SIZE"][0] + m["WRITE_SIZE"][0]) * 1024  # FETCH_SIZE doubled: gfx950 tallies a wide coalesced read stream at 1/2
@@ -60,9 +73,9 @@ for cfg, (kc, ke) in {"c3": ("c3_count", "c3_emit"), "c4": ("c4_count", "c4_emit
     if "FETCH_SIZE" not in means[kc]:
         continue
     traffic[cfg] = {"count_kernel": {"kernel": kernels[kc], "FETCH_SIZE_KiB": means[kc]["FETCH_SIZE"][0], "WRITE_SIZE_KiB": means[kc]["WRITE_SIZE"][0],
-                                     "hbm_bytes_per_base": hbm(means[kc]) / BASES}}
+                                     "hbm_bytes_per_base": hbm(means[kc]) / BASES_OF[kc]}}
     if ke and "FETCH_SIZE" in means[ke]:
         traffic[cfg]["emit_kernel"] = {"kernel": kernels[ke], "FETCH_SIZE_KiB": means[ke]["FETCH_SIZE"][0], "WRITE_SIZE_KiB": means[ke]["WRITE_SIZE"][0],
-                                       "hbm_bytes_per_base": hbm(means[ke]) / BASES}
+                                       "hbm_bytes_per_base": hbm(means[ke]) / BASES_OF[ke]}
 json.dump(traffic, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
-print(json.dumps({k: {c: round(v, 4) for c, v in ((c, m[0] / BASES) for c, m in means[k].items() if c in ("SQ_INSTS_VALU",))} for k in kernels}))
+print(json.dumps({k: round(means[k]["SQ_INSTS_VALU"][0] * 64 / BASES_OF[k], 2) for k in kernels if "SQ_INSTS_VALU" in means[k]}))

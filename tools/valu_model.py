@@ -18,7 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 import isa_census
 
-RND = sys.argv[1] if len(sys.argv) > 1 else "r02"
+RND = sys.argv[1] if len(sys.argv) > 1 else "r03"
 ub = json.load(open(os.path.join(ROOT, "profiles", f"{RND}_ubench_valu.json")))
 pmc = json.load(open(os.path.join(ROOT, "profiles", f"{RND}_pmc.json")))
 
@@ -47,7 +47,7 @@ with tempfile.TemporaryDirectory() as tmp:
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-DBL_CENSUS_HOT", "-S", "--cuda-device-only",
                            os.path.join(ROOT, "biolib_amd", "csrc", "bl_kernels.hip"), "-o", asm], stderr=subprocess.DEVNULL)
     mangled = {"c3_count": r"scan_count_frl_kernelILi0ELi11ELi15ELi31ELi150ELi1E", "c3_emit": r"scan_emit_kernelILi0E", "c2_kmer": r"kmer_kernel",
-               "c4_count": r"scan_count_kernelILi1ELi17ELi15ELi1E", "c4_emit": r"scan_emit_kernelILi1E", "c5_count": r"scan_count_kernelILi2ELi21ELi11ELi1E",
+               "c4_count": r"scan_count_kernelILi1ELi17ELi15ELi1ELb0E", "c4_emit": r"scan_emit_kernelILi1E", "c5_count": r"scan_count_kernelILi2ELi21ELi11ELi1ELb1E",
                "c5_emit": r"scan_emit_kernelILi2E"}
     out = {"provenance": {"pmc": pmc["provenance"], "ubench": f"profiles/{RND}_ubench_valu.json (same collection run)", "census": "hipcc -DBL_CENSUS_HOT -S of biolib_amd/csrc/bl_kernels.hip, tools/isa_census.py",
                           "tool": "tools/valu_model.py"},
@@ -68,8 +68,8 @@ with tempfile.TemporaryDirectory() as tmp:
         if "SQ_INSTS_VALU" in k and "SQ_WAVES" in k:
             dyn_per_wave = k["SQ_INSTS_VALU"] / k["SQ_WAVES"]
             entry.update(dynamic_valu_per_wave=round(dyn_per_wave, 1), scale=round(dyn_per_wave / static, 4),
-                         valu_per_base=k["SQ_INSTS_VALU"] / pmc["bases_per_launch"],
-                         cycles_per_base=cycles / static * k["SQ_INSTS_VALU"] / pmc["bases_per_launch"])
+                         valu_per_base=k["SQ_INSTS_VALU"] / k["bases_per_launch"],
+                         cycles_per_base=cycles / static * k["SQ_INSTS_VALU"] / k["bases_per_launch"])
         out["kernels"][key] = entry
 json.dump(out, open(os.path.join(ROOT, "profiles", "valu_model.json"), "w"), indent=1)
 for k, e in out["kernels"].items():
