@@ -1,5 +1,12 @@
 // minimizer_view.hpp — drop-in for biolib's include/minimizer_view.hpp on top of the MI355X scan library.
 //
+// REFUSED AT COMPILE TIME: a HashFunction other than hash::hash64 (the reference's template takes any functor with a static
+// hash(T, uint64_t), minimizer_view.hpp:88-92) and a MinimizerType wider than 64 bits.  The device hashes with
+// MurmurHash3_x64_128 and nothing else, and this header has no host evaluation to fall back on — by design: a view that silently
+// ran on the CPU would be a different product.  Code that needs another functor has the same windows through
+// sampler::minimizer_sampler over a kmer_view of the m-mers (minimizer_sampler.hpp evaluates any functor element by element
+// on the host, as hash_sampler and syncmer_sampler do for pairings the GPU does not implement).  INTEGRATION.md lists this.
+//
 // Same public surface (reference minimizer_view.hpp:14-122): wrapper::minimizer_view<KmerType, MinimizerType,
 // HashFunction, Iterator>(start, stop, k, m, seed, canonical), cbegin/cend/get_k/get_m,
 // const_iterator::{operator* -> minimizer_context_t const&, ++, ++(int), break_offset},

@@ -1,5 +1,8 @@
 // super_kmer_view.hpp — drop-in for biolib's include/super_kmer_view.hpp on top of the MI355X scan library.
 //
+// REFUSED AT COMPILE TIME, like minimizer_view.hpp and for the same reason: a HashFunction other than hash::hash64, a
+// MinimizerType wider than 64 bits.  There is no host evaluation behind this view.
+//
 // Same public surface (reference super_kmer_view.hpp:11-58): wrapper::super_kmer_view<KmerType, MinimizerType,
 // HashFunction>(contig, len, k, m, canonical) / (std::string, k, m, canonical), cbegin/cend/get_k/get_m,
 // value_type super_kmer_t{minimizer, mm_pos, size}.  The reference header does not compile;
