@@ -142,19 +142,22 @@ __global__ __launch_bounds__(256) void expand_kernel(const ulonglong2* __restric
 //   3. bucket_starts_kernel  where each bucket begins in the sorted order (one thread per bucket, independent binary searches)
 //   4. count_buckets_kernel<false>  one WAVE per bucket (grid-stride over waves, 13 KB of LDS per wave, no workgroup barrier):
 //                         the bucket's k-mers go into an LDS hash table (1024 slots, linear probing, 64-bit compare-and-swap on
-//                         the key, 32-bit add on the count); only the number of distinct k-mers is kept.  A bucket with more
-//                         than CT_CAP k-mers or CT_RECS records is listed for the fallback instead.
+//                         the key, 32-bit add on the count), in rounds of up to 64 records / CT_CAP k-mers; only the number of
+//                         distinct k-mers is kept.  A bucket that may come to hold more than CT_FULL DISTINCT k-mers (or more
+//                         than CT_MAXREC records) is listed for the fallback instead.
 //   5. exclusive scan of those numbers = where every bucket writes
 //   6. count_buckets_kernel<true>   the tables are built again and written out at the buckets' offsets.  Two table passes
 //                         instead of one returning atomic per bucket on a single output cursor (~88 M/s on this chip: 48 ms for
 //                         4 M buckets); the output order is deterministic as a bonus.
 //   7. fallback           the records of listed buckets: gather -> expand -> radix sort -> run-length encode -> appended
 constexpr int CT_SLOTS = 1024;  // table slots of ONE WAVE
-constexpr int CT_CAP = 700;     // k-mers a bucket may hold to be counted in the table (load <= 0.68)
-constexpr int CT_RECS = 64;     // records a bucket may hold (one per lane)
+constexpr int CT_CAP = 700;     // k-mers one ROUND of a bucket inserts (the work list's size)
+constexpr int CT_FULL = 820;    // DISTINCT k-mers a bucket's table may come to hold (load 0.8): beyond it the fallback counts the bucket
+constexpr int CT_RECS = 64;     // records a round stages (one per lane)
+constexpr int CT_MAXREC = 2040; // records a bucket may hold at all: 2040 x 32 k-mers < 2^16, the width of a count
 constexpr int CT_WIDE = 2;      // k-mers a lane inserts per round
 constexpr int CT_WAVES = 2;     // waves per workgroup (12.4 KB of LDS per wave: 6 workgroups = 12 waves per CU)
-static_assert(CT_CAP < 65536, "counts are kept in 16 bits");
+static_assert(CT_MAXREC * 32 < 65536, "counts are kept in 16 bits");
 constexpr unsigned long long CT_EMPTY = ~0ULL;  // never a k-mer for k < 32, nor a canonical 32-mer (its reverse complement is 0)
 
 __device__ __forceinline__ unsigned long long mmer_at(unsigned long long hi, unsigned long long lo, int pos, int m)
@@ -226,17 +229,17 @@ __device__ __forceinline__ void wave_lds_sync()
 
 __device__ __forceinline__ uint32_t table_slot(unsigned long long key) { return (uint32_t)((key * 0xD6E8FEB86659FD93ULL) >> (64 - 10)); }
 
-// one probe: true when the key sits in slot h now (it was empty, or held the same key already)
-__device__ __forceinline__ bool table_probe(WaveTable& t, uint32_t h, unsigned long long key)
+// one probe: what slot h held (CT_EMPTY: the key sits there now; the key itself: it sat there already)
+__device__ __forceinline__ unsigned long long table_probe(WaveTable& t, uint32_t h, unsigned long long key)
 {
-    const unsigned long long old = atomicCAS(&t.keys[h], CT_EMPTY, key);
-    return old == CT_EMPTY || old == key;
+    return atomicCAS(&t.keys[h], CT_EMPTY, key);
 }
 
 // W keys at once (live[i] = false: key i is not there): all first probes are issued before any result is looked at, so their
 // LDS round trips overlap; the few that collide (load <= 0.68) walk on one by one.  The table never fills.
+// Returns how many of the lane's keys were NEW to the table.
 template <int W>
-__device__ __forceinline__ void table_insert_many(WaveTable& t, const unsigned long long (&key)[W], const bool (&live)[W])
+__device__ __forceinline__ unsigned int table_insert_many(WaveTable& t, const unsigned long long (&key)[W], const bool (&live)[W])
 {
     uint32_t h[W];
     unsigned long long old[W];
@@ -244,17 +247,19 @@ __device__ __forceinline__ void table_insert_many(WaveTable& t, const unsigned l
     for (int i = 0; i < W; ++i) h[i] = table_slot(key[i]);
 #pragma unroll
     for (int i = 0; i < W; ++i) old[i] = live[i] ? atomicCAS(&t.keys[h[i]], CT_EMPTY, key[i]) : key[i];
+    unsigned int fresh = 0;
 #pragma unroll
     for (int i = 0; i < W; ++i) {
-        bool ok = old[i] == CT_EMPTY || old[i] == key[i];
-        while (!ok) {
+        while (old[i] != CT_EMPTY && old[i] != key[i]) {
             h[i] = (h[i] + 1) & (CT_SLOTS - 1);
-            ok = table_probe(t, h[i], key[i]);
+            old[i] = table_probe(t, h[i], key[i]);
         }
+        fresh += (live[i] && old[i] == CT_EMPTY) ? 1u : 0u;
     }
 #pragma unroll
     for (int i = 0; i < W; ++i)
         if (live[i]) atomicAdd(&t.cnt[h[i] >> 1], 1u << (16 * (h[i] & 1u)));
+    return fresh;
 }
 
 __device__ __forceinline__ unsigned long long kmer_of(ulonglong2 r, int q, int k, int canonical, unsigned long long kmask)
@@ -319,10 +324,15 @@ struct WaveChunk {
 };
 
 // one bucket, one wave: records [lo, hi) of the sorted order; `rec` = this lane's record of it (lane l holds record lo + l; lanes
-// beyond the bucket hold something else and do not use it)
-template <bool WRITE>
-__device__ __forceinline__ void count_one_bucket(WaveTable& t, int lane, uint32_t bucket, uint32_t lo, uint32_t hi, ulonglong2 rec, int k, int canonical,
-                                                 unsigned long long kmask, unsigned int* __restrict__ distinct, const CountedOut& out, WaveChunk& chunk,
+// beyond the bucket hold something else and do not use it).
+// A bucket is counted in ROUNDS: a round stages up to 64 records — as many as have <= CT_CAP k-mers between them —, expands them
+// through the work list and inserts their k-mers; the table and its counts live on from round to round.  What bounds a bucket
+// is therefore the number of DISTINCT k-mers it holds (CT_FULL), not the number of occurrences: on reads of high coverage every
+// minimizer comes 30 times over with the same k-mers behind it, a bucket of the usual ~36 records holds a handful of distinct
+// minimizers, and its hundred records are three rounds into a table that stays nearly empty (before: straight to the sort).
+template <bool WRITE, typename RecPtr>
+__device__ __forceinline__ void count_one_bucket(WaveTable& t, int lane, uint32_t bucket, uint32_t lo, uint32_t hi, ulonglong2 rec, RecPtr grecs, uint32_t last_r, int k,
+                                                 int canonical, unsigned long long kmask, unsigned int* __restrict__ distinct, const CountedOut& out, WaveChunk& chunk,
                                                  unsigned long long* cursor, uint2* __restrict__ overflow, uint32_t max_overflow STAMP_ARGS)
 {
     STAMP(0);  // everything between two buckets: loop control, the waits for this bucket's records and range
@@ -331,7 +341,7 @@ __device__ __forceinline__ void count_one_bucket(WaveTable& t, int lane, uint32_
         if (!WRITE && lane == 0) distinct[bucket] = 0;
         return;
     }
-    if (n_rec > CT_RECS) {  // too many records for one wave's table: the fallback counts this bucket
+    if (n_rec > CT_MAXREC) {  // more occurrences than a 16-bit count holds: the fallback counts this bucket
         list_overflow(lane, lo, hi, cursor, overflow, max_overflow);
         if (!WRITE && lane == 0) distinct[bucket] = 0;
         return;
@@ -342,41 +352,53 @@ __device__ __forceinline__ void count_one_bucket(WaveTable& t, int lane, uint32_
         t.keys[i * 64 + lane] = CT_EMPTY;
         if (i < CT_SLOTS / 128) t.cnt[i * 64 + lane] = 0;
     }
-    unsigned int size = 0;
-    if ((uint32_t)lane < n_rec) {
-        t.recs[lane] = rec;
-        size = (unsigned int)(rec.y & 31ULL) + 1;
-    }
-    STAMP(1);  // table cleared, records staged
-    const unsigned int incl = wave_incl_scan(size, lane);
-    const unsigned int total = __shfl(incl, 63, 64);
-    STAMP(2);  // size prefix
-    if (total > CT_CAP) {  // wave-uniform
-        list_overflow(lane, lo, hi, cursor, overflow, max_overflow);
-        if (!WRITE && lane == 0) distinct[bucket] = 0;
-        return;
-    }
-    // work list: k-mer j of the bucket -> (record, index inside it), written by the record's own lane at its prefix (fire and
-    // forget LDS stores, no search later)
-    {
-        const unsigned int first = incl - size;
-        for (unsigned int q = 0; q < size; ++q) t.work[first + q] = (unsigned short)((lane << 5) | q);
-    }
-    wave_lds_sync();
-    // CT_WIDE k-mers per lane and round, their table probes in flight together: the rounds are chains of LDS round trips (work
-    // list -> record -> probe -> count) with little to overlap them with, so fewer, wider rounds it is
-    for (unsigned int j = lane; j < total; j += 64 * CT_WIDE) {
-        unsigned long long key[CT_WIDE];
-        bool live[CT_WIDE];
-        unsigned int w[CT_WIDE];
-#pragma unroll
-        for (int i = 0; i < CT_WIDE; ++i) {
-            live[i] = j + 64 * i < total;
-            w[i] = t.work[live[i] ? j + 64 * i : j];
+    STAMP(1);  // table cleared
+    unsigned int held = 0;  // distinct k-mers in the table (wave-uniform)
+    for (uint32_t at = lo; at < hi;) {
+        if (at != lo) {  // later rounds fetch their records themselves (the first round's came with the software pipeline)
+            const uint32_t c = at + lane < last_r ? at + lane : last_r;
+            rec.x = grecs[2ull * c];
+            rec.y = grecs[2ull * c + 1];
         }
+        const unsigned int size = at + (uint32_t)lane < hi ? (unsigned int)(rec.y & 31ULL) + 1 : 0u;
+        const unsigned int incl = wave_incl_scan(size, lane);
+        // the records of this round: the longest prefix whose k-mers fit the work list (sizes are <= 32: at least 21 records)
+        const unsigned long long fits = __ballot(size != 0 && incl <= (unsigned int)CT_CAP);
+        const int n_take = (int)__popcll(fits);  // wave-uniform; a prefix of the lanes, since incl only grows
+        const unsigned int total = __shfl(incl, n_take - 1, 64);
+        STAMP(2);  // size prefix
+        if (held + total > (unsigned int)CT_FULL) {  // the table might fill up (every k-mer of the round may be new): the fallback's
+            list_overflow(lane, lo, hi, cursor, overflow, max_overflow);
+            if (!WRITE && lane == 0) distinct[bucket] = 0;
+            return;
+        }
+        if (at != lo) wave_lds_sync();  // the round before has read its records and its work list
+        // work list: k-mer j of the round -> (record, index inside it), written by the record's own lane at its prefix (fire and
+        // forget LDS stores, no search later)
+        if (lane < n_take) {
+            t.recs[lane] = rec;
+            const unsigned int first = incl - size;
+            for (unsigned int q = 0; q < size; ++q) t.work[first + q] = (unsigned short)((lane << 5) | q);
+        }
+        wave_lds_sync();
+        // CT_WIDE k-mers per lane and round, their table probes in flight together: the rounds are chains of LDS round trips (work
+        // list -> record -> probe -> count) with little to overlap them with, so fewer, wider rounds it is
+        unsigned int fresh = 0;
+        for (unsigned int j = lane; j < total; j += 64 * CT_WIDE) {
+            unsigned long long key[CT_WIDE];
+            bool live[CT_WIDE];
+            unsigned int w[CT_WIDE];
 #pragma unroll
-        for (int i = 0; i < CT_WIDE; ++i) key[i] = kmer_of(t.recs[w[i] >> 5], (int)(w[i] & 31u), k, canonical, kmask);
-        table_insert_many<CT_WIDE>(t, key, live);
+            for (int i = 0; i < CT_WIDE; ++i) {
+                live[i] = j + 64 * i < total;
+                w[i] = t.work[live[i] ? j + 64 * i : j];
+            }
+#pragma unroll
+            for (int i = 0; i < CT_WIDE; ++i) key[i] = kmer_of(t.recs[w[i] >> 5], (int)(w[i] & 31u), k, canonical, kmask);
+            fresh += table_insert_many<CT_WIDE>(t, key, live);
+        }
+        at += (uint32_t)n_take;
+        if (at < hi) held += __shfl(wave_incl_scan(fresh, lane), 63, 64);  // (only buckets of several rounds pay for this sum)
     }
     wave_lds_sync();
     STAMP(3);  // k-mers inserted
@@ -499,7 +521,7 @@ __global__ __launch_bounds__(64 * CT_WAVES) void count_buckets_kernel(const ulon
         const uint32_t b2 = bn + stride;
         uint32_t v2lo, v2hi;
         range_of(b2, v2lo, v2hi);                       // the range of the one after
-        count_one_bucket<WRITE>(t, lane, b, lo, hi, rec, k, canonical, kmask, distinct, out, chunk, cursor, overflow, max_overflow STAMP_PASS);
+        count_one_bucket<WRITE>(t, lane, b, lo, hi, rec, grecs, last_r, k, canonical, kmask, distinct, out, chunk, cursor, overflow, max_overflow STAMP_PASS);
 #ifdef BL_COUNT_STAMPS
         acc[7] += 1;
 #endif
@@ -593,6 +615,9 @@ int bl_pack_super_kmers(bl_ctx* ctx, const bl_batch* batch, const uint64_t* d_fi
                         uint32_t k, uint32_t m, uint64_t* d_records)
 {
     if (!ctx || !batch || (n_groups && (!d_first_pos || !d_sizes || !d_records))) return bl_set_error(BL_ERR_INVALID, "NULL argument");
+    // a record without its minimizer's offset would be bucketed by its first m-mer by bl_count_super_kmers: occurrences of one k-mer
+    // could then meet in different buckets and come out as several partial counts, with no error anywhere
+    if (n_groups && !d_mm_pos) return bl_set_error(BL_ERR_INVALID, "d_mm_pos is required: the record's owner finds the minimizer through it");
     if (k < 1 || k > 32 || m < 1 || m > k || 2 * k - m > MAX_BASES) return bl_set_error(BL_ERR_INVALID, "need 1 <= m <= k <= 32 and 2k - m <= 59 (bases per packed record)");
     if (n_groups == 0) return BL_OK;
     SK_HIP(hipSetDevice(bl_ctx_device(ctx)));

@@ -263,7 +263,8 @@ int bl_count_allreduce(bl_ctx* const* ctxs, int n_gpu, uint64_t* counters, int n
 /* Super-k-mer bucket exchange (record of reference super_kmer_view.hpp:20-24 made self-contained).
  * bl_pack_super_kmers: one 16-byte record per group of bl_scan_super_kmers — d_records[2g] = bases 0..31 of the group's
  *   size + k - 1 bases (2 bits each, first base most significant), d_records[2g+1] = bases 32.. in bits 63..10, mm_pos in
- *   bits 9..5 (d_mm_pos may be NULL: 0), size - 1 in bits 4..0.  Needs 2k - m <= 59.
+ *   bits 9..5 (d_mm_pos is REQUIRED: bl_count_super_kmers finds a record's minimizer through it), size - 1 in bits 4..0.
+ *   Needs 2k - m <= 59.
  * bl_partition_records: reorder 16-byte records into `parts` (<= 64) contiguous buckets by d_hashes[g] % parts (the
  *   minimizer hash the scan returned = the owner rank); counts[b] (host) = records in bucket b.
  * bl_expand_super_kmers: records -> their k-mers (canonical with BL_FLAG_CANONICAL), group after group;
@@ -281,7 +282,8 @@ int bl_scan_super_kmer_records(bl_ctx* ctx, const bl_batch* batch, uint64_t firs
  *   into buckets of a few thousand k-mers, and every bucket is expanded and counted in an LDS hash table by one workgroup (buckets
  *   that do not fit take a sort + run-length path).  All occurrences of a canonical k-mer share their minimizer, so they meet in
  *   one bucket and the count is exact.  d_kmers / d_counts receive the distinct k-mers and their multiplicities in NO particular
- *   order; BL_ERR_CAPACITY with *n_distinct = need when they are too small.  Records must carry mm_pos (bl_pack_super_kmers). */
+ *   order; BL_ERR_CAPACITY with *n_distinct = need when they are too small.  A bucket's table is filled in rounds, so what bounds a
+ *   bucket is its DISTINCT k-mers, not their occurrences: reads of high coverage (every minimizer many times over) stay in the tables. */
 int bl_count_super_kmers(bl_ctx* ctx, const uint64_t* d_records, uint64_t n_groups, uint32_t k, uint32_t m, uint64_t seed, uint32_t flags, uint64_t* d_kmers,
                          uint32_t* d_counts, uint64_t capacity, uint64_t* n_distinct);
 int bl_partition_records(bl_ctx* ctx, const uint64_t* d_hashes, const uint64_t* d_records, uint64_t n, uint32_t parts, uint64_t* d_out, uint64_t* counts);
