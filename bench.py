@@ -507,11 +507,9 @@ def next_rows(ctx):
     try:  # the same chain on reads of 30x COVERAGE: 0.6 Gbp drawn at random offsets of a 20-Mbp genome (tests/perf/count_coverage_bench.py is the long form)
         k, m, L = 31, 15, 150
         n_reads = 4_000_000
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
-        import oracle_lib as O  # (the generator of the synthetic genome only: nothing of the oracle is timed or compared here)
-
-        genome = O.synth(9, n_reads * L // 30)
-        pos = np.random.default_rng(6).integers(0, genome.size - L, n_reads)
+        rng = np.random.default_rng(6)
+        genome = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, n_reads * L // 30)]
+        pos = rng.integers(0, genome.size - L, n_reads)
         seq = np.ascontiguousarray(genome[pos[:, None] + np.arange(L)[None, :]]).reshape(-1)
         b = ctx.upload(seq, read_len=L)
         best = None
