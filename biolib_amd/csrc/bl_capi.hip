@@ -883,7 +883,7 @@ static int scan_windows(int mode, bl_ctx* c, const bl_batch* b, uint64_t first, 
     if (rc != BL_OK) return rc;
     // scratch: tile counts + local prefixes + scan-block totals/prefixes, and the per-tile u16 list slots
     const size_t nt = (size_t)p.n_tiles, nb = (nt + bl::SCAN_BLK - 1) / bl::SCAN_BLK;
-    rc = grow(c, reinterpret_cast<void**>(&c->cur->tile_buf), &c->cur->tile_buf_bytes, (2 * nt + 2 * nb + 8) * sizeof(unsigned long long));
+    rc = grow(c, reinterpret_cast<void**>(&c->cur->tile_buf), &c->cur->tile_buf_bytes, (2 * nt + 2 * nb + 8) * sizeof(unsigned long long) + nt * sizeof(uint32_t));
     if (rc != BL_OK) return rc;
     const size_t n_lists = mode == bl::MODE_SUPERKMER ? 3 : 1;
     const size_t slot_entries = nt * (size_t)p.stride;
@@ -895,6 +895,8 @@ static int scan_windows(int mode, bl_ctx* c, const bl_batch* b, uint64_t first, 
     p.tile_base = tb + nt;
     unsigned long long* block_tot = tb + 2 * nt;
     p.block_base = block_tot + nb;
+    p.redo_list = reinterpret_cast<uint32_t*>(tb + 2 * nt + 2 * nb + 8);                     // tiles a closed-syncmer pass 1 could not decide
+    p.redo_count = reinterpret_cast<unsigned long long*>(c->cur->ws) + 1;                     // header word 1, zeroed by begin_scan
     p.slots_a = c->cur->slot_buf;
     p.slots_j = mode == bl::MODE_SUPERKMER ? c->cur->slot_buf + slot_entries : nullptr;
     p.slots_e = mode == bl::MODE_SUPERKMER ? c->cur->slot_buf + 2 * slot_entries : nullptr;

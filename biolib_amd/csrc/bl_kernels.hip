@@ -6,7 +6,7 @@
 #include "bl_launch.hpp"
 
 #ifndef BL_CS_WAVES
-#define BL_CS_WAVES 4  // waves per SIMD the closed-syncmer kernel is compiled for
+#define BL_CS_WAVES 3  // waves per SIMD the closed-syncmer kernel is compiled for
 #endif
 
 namespace bl {
@@ -104,11 +104,12 @@ __device__ __forceinline__ void fill_list(uint16_t* dst, const uint16_t* src, ui
 // Pass 1 of one tile: hash, window minimum, start/end decisions, tile-local compaction; leaves the
 // tile's record counts and u16 lists in global scratch.  Tiles are independent: no ticket, no
 // inter-workgroup wait, any dispatch order.
-template <int MODE, int W, bool CS = false>
+template <int MODE, int W, bool CS = false, int U = 0>
 __device__ __forceinline__ void count_tile(const ScanParams& p, TileShared<MODE, W>& sh, uint32_t tile, int tid)
 {
     const int64_t q0 = p.origin + (int64_t)tile * p.stride;
     phase_load<MODE, W>(p, sh, tid, q0);
+    if (CS && tid == 0) sh.redo = 0;
     {   // hand the packed codes to pass 2 (0.26 B/base instead of re-reading and re-encoding 1 B/base there)
         const int needed = staged_chunks(p);
         uint32_t* sc = p.slots_c + (size_t)tile * p.slot_chunks;
@@ -118,18 +119,17 @@ __device__ __forceinline__ void count_tile(const ScanParams& p, TileShared<MODE,
     __syncthreads();
 
     ThreadState st;
-    phase_hash<MODE, W>(p, sh, tid, st);
+    constexpr bool DIRECT = MODE == MODE_SYNCMER && CS && U >= 1 && U <= 16 && U + W - 1 >= 16 && U + W - 1 <= 32;  // phase_hash_closed applies
+    if (DIRECT) phase_hash_closed<MODE, W, (DIRECT ? U : 1)>(p, sh, tid, st);
+    else phase_hash<MODE, W>(p, sh, tid, st);
 
     uint32_t packed;
     if (MODE == MODE_SYNCMER && CS) {  // closed syncmers: sliding minima of the high dwords, no argmin
         bool undecided;
-        packed = phase_sync_closed<MODE, (W > 1 ? W : 2)>(p, reinterpret_cast<TileShared<MODE, (W > 1 ? W : 2)>&>(sh), tid, q0, st, nullptr, undecided);
-        if (BL_COLD(wave_any(undecided))) {  // equal high dwords somewhere in the wave: the exact form, on hashes computed again
-            phase_hash<MODE, W>(p, sh, tid, st);
-            uint32_t af[S + 1];
-            phase_sync_fwd<MODE, W>(p, sh, tid, st, nullptr, af);
-            packed = phase_sync_rev<MODE, W>(p, sh, tid, q0, st, nullptr, af);
-        }
+        packed = phase_sync_closed<MODE, (W > 1 ? W : 2), (DIRECT ? U : 0)>(p, reinterpret_cast<TileShared<MODE, (W > 1 ? W : 2)>&>(sh), tid, q0, st, nullptr, undecided);
+        // equal high dwords somewhere in the wave: the tile is listed and counted again, in the exact form, by scan_redo_kernel — a
+        // kernel of its own, because that form needs twice the registers and, inlined here, pushes spills into this kernel's hot path
+        if (BL_COLD(wave_any(undecided)) && (tid & 63) == 0) sh.redo = 1;
     } else if (MODE == MODE_SYNCMER) {
         uint32_t af[S + 1];
         phase_sync_fwd<MODE, W>(p, sh, tid, st, nullptr, af);
@@ -144,6 +144,7 @@ __device__ __forceinline__ void count_tile(const ScanParams& p, TileShared<MODE,
     phase_list<MODE, W>(sh, tid, st, excl & 0xffffu, excl >> 16);
     if (tid == 0) p.tile_counts[tile] = (unsigned long long)n_s | ((unsigned long long)n_e << 32);
     __syncthreads();  // lists complete
+    if (CS && tid == 0 && BL_COLD(sh.redo != 0)) p.redo_list[atomicAdd(p.redo_count, 1ull)] = tile;
 
     // spill the compacted lists: two u16 entries per 32-bit store (sub-dword global stores are not
     // write-combined on gfx950: 2-byte stores cost a 32-byte memory write each, measured 6.4 GB of
@@ -259,7 +260,25 @@ __global__ __launch_bounds__(TPB, (CS ? BL_CS_WAVES : (MODE == MODE_SYNCMER || (
         p.stride = NWAVE * (64 * S - 16 * ((W + 15) / 16));  // plan_scan's value, as a constant
     }
     if (C >= 0) p.canonical = C;
-    if (blockIdx.x < g.count) count_tile<MODE, W, CS>(p, sh, g.first + blockIdx.x, threadIdx.x);
+    if (blockIdx.x < g.count) count_tile<MODE, W, CS, U>(p, sh, g.first + blockIdx.x, threadIdx.x);
+}
+
+// The tiles a closed-syncmer pass 1 could not decide (p.redo_list), counted again in the exact argmin form: same outputs, written
+// over what pass 1 left for them.  Runs between pass 1 and the prefix scan; clean data lists nothing and every workgroup leaves at once.
+template <int MODE, int W, int U, int C>
+__global__ __launch_bounds__(TPB, 2) void scan_redo_kernel(const ScanParams pin)
+{
+    __shared__ TileShared<MODE, W> sh;
+    ScanParams p = pin;
+    if (U != 0) p.unit = U;
+    p.w = W;
+    p.stride = NWAVE * (64 * S - 16 * ((W + 15) / 16));
+    if (C >= 0) p.canonical = C;
+    const unsigned long long n = *p.redo_count;
+    for (unsigned long long i = blockIdx.x; i < n; i += gridDim.x) {
+        count_tile<MODE, W>(p, sh, p.redo_list[i], threadIdx.x);
+        __syncthreads();  // the lists in LDS have been spilled before the next tile overwrites them
+    }
 }
 
 // Read-tiled pass 1.  L (read length) and U, C specialise the headline configuration as in scan_count_kernel; L fixes
@@ -537,8 +556,13 @@ static hipError_t launch_count_mode(const ScanParams& p, GroupRange g, hipStream
     if (MODE == MODE_SYNCMER && p.w == 21 && p.unit == 11 && p.canonical) {
         const bool closed = (p.soff == 0 && p.eoff == 20) || (p.soff == 20 && p.eoff == 0);
         static const bool no_cs = std::getenv("BL_NO_CLOSED") != nullptr;  // A/B runs: the argmin form
-        if (closed && !no_cs) hipLaunchKernelGGL((scan_count_kernel<MODE_SYNCMER, 21, 11, 1, true>), grid, block, 0, stream, p, g);  // BASELINE C5
-        else hipLaunchKernelGGL((scan_count_kernel<MODE, 21, 11, 1>), grid, block, 0, stream, p, g);
+        if (closed && !no_cs && p.redo_list && g.first == 0) {  // BASELINE C5
+            hipLaunchKernelGGL((scan_count_kernel<MODE_SYNCMER, 21, 11, 1, true>), grid, block, 0, stream, p, g);
+            const unsigned redo_grid = g.count < 512u ? g.count : 512u;
+            hipLaunchKernelGGL((scan_redo_kernel<MODE_SYNCMER, 21, 11, 1>), dim3(redo_grid), block, 0, stream, p);
+        } else {
+            hipLaunchKernelGGL((scan_count_kernel<MODE, 21, 11, 1>), grid, block, 0, stream, p, g);
+        }
         return hipGetLastError();
     }
     if (MODE != MODE_SYNCMER) {

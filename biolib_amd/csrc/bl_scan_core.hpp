@@ -85,6 +85,10 @@ struct ScanParams {
     uint32_t* slots_c;                // [n_tiles][slot_chunks] the tile's 2-bit codes (pass 2 rebuilds unit values from them)
     int32_t slot_chunks;              // chunks a tile stages and hands to pass 2 (<= NCHUNK)
     unsigned long long* shards;       // [NSHARD][8] digest accumulators
+    // closed-syncmer scans: tiles in which a comparison met equal high dwords are listed here by pass 1 and counted again, in the
+    // exact argmin form, by scan_redo_kernel before the prefix scan (nullptr: never happens for other scans)
+    uint32_t* redo_list;              // [n_tiles]
+    unsigned long long* redo_count;
     // Read-tiled layout (bl_scan_frl.hpp): batches of FIXED-LENGTH short reads, range aligned to reads.  A wave takes
     // rpw whole reads, lpr lanes per read, ns consecutive unit starts per lane: the unit-1 tail positions of a read,
     // which cannot start a unit, are never rolled or hashed, sequence starts are arithmetic (no start_bits), and there

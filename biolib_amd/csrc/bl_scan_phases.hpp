@@ -41,6 +41,7 @@ struct TileShared {
     alignas(4) uint16_t list_j[MODE == MODE_SUPERKMER ? H : 2];  // compacted: first window of the occurrence
     alignas(4) uint16_t list_e[MODE == MODE_SUPERKMER ? H : 2];  // compacted: last window of the occurrence
     uint32_t wave_tot[NWAVE];
+    uint32_t redo;                  // closed-syncmer scans: some wave of the tile could not decide (equal high dwords)
     uint32_t wave_bad[NWAVE];       // read-tiled scans: wave wv staged at least one base that is not ACGTUacgtu
     unsigned long long dig[4];
 };
@@ -57,6 +58,7 @@ struct ThreadState {
     int32_t jlane;        // index of the lane inside its read, -1: the lane has no read
     uint32_t a_first, a_last;  // argmin index of the lane's first / last window
     uint32_t vmask;       // bit s: window s exists and is valid
+    uint32_t cw[3], rw[3];  // closed-syncmer scans: the lane's 48 bases as codes, and their reverse complement (first base of each in the top pair of word 0)
     uint32_t occ;         // element-centric minimizer scans: bit e = element e (own or, from NS on, the next lane's) is the argmin of a valid window
 };
 
@@ -650,6 +652,48 @@ BL_DEV uint32_t phase_sync_rev(const ScanParams& p, TileShared<MODE, W>& sh, int
 // tie bookkeeping inside the windows) and four comparisons per k-mer decide.  A comparison whose two high dwords are EQUAL is
 // undecided; the caller then runs the exact argmin form for the wave (phase_sync_fwd / phase_sync_rev).
 
+// n bases (n <= 16) from base `o` of the 48 bases a0:a1:a2 (16 per word, first base in the top pair), as an n-mer in the low 2n bits.
+// o and n are compile-time constants where this is used: one v_bfe_u32 when the bases lie in one word, v_alignbit_b32 + shift
+// otherwise — against the six instructions a rolling update of a forward and a reverse-complement register costs per base.
+BL_DEV uint32_t bases_at(uint32_t a0, uint32_t a1, uint32_t a2, int o, int n)
+{
+    const int q = o >> 4, r = o & 15;
+    const uint32_t hi = q == 0 ? a0 : (q == 1 ? a1 : a2), lo = q == 0 ? a1 : (q == 1 ? a2 : 0u);
+    if (r + n <= 16) return n == 16 ? hi : (hi >> (32 - 2 * (r + n))) & ((1u << (2 * n)) - 1u);
+    const uint32_t w16 = funnel_shr(hi, lo, 32 - 2 * r);  // the 16 bases from o on (r != 0 here)
+    return n == 16 ? w16 : w16 >> (32 - 2 * n);
+}
+
+// reverse complement of 16 bases (one word of codes)
+BL_DEV uint32_t revcomp16(uint32_t c)
+{
+    const uint32_t r = __builtin_bitreverse32(c);
+    return ~(((r >> 1) & 0x55555555u) | ((r & 0x55555555u) << 1));
+}
+
+// Phase 2 of the closed-syncmer scan (compile-time s-mer length U <= 16): both s-mers of every position straight from the codes
+// and from their reverse complement — no rolling registers, and no k-mer register at all: which strand of the K-MER is canonical
+// is decided later from its first 16 bases on either strand (phase_sync_closed).
+template <int MODE, int W, int U>
+BL_DEV void phase_hash_closed(const ScanParams& p, TileShared<MODE, W>& sh, int tid, ThreadState& st)
+{
+    static_assert(U >= 1 && U <= 16, "s-mers of the closed-syncmer kernel fit one word");
+    const int wv = wave_index(tid), lane = tid & 63;
+    const uint32_t* wcodes = sh.codes + wave_chunk0(p, wv);
+    const uint32_t c0 = wcodes[lane], c1 = wcodes[lane + 1], c2 = wcodes[lane + 2];
+    const uint32_t r0 = revcomp16(c2), r1 = revcomp16(c1), r2 = revcomp16(c0);  // base b of the lane = base 47 - b of r0:r1:r2
+    st.cw[0] = c0; st.cw[1] = c1; st.cw[2] = c2;
+    st.rw[0] = r0; st.rw[1] = r1; st.rw[2] = r2;
+    BL_UNROLL
+    for (int s = 0; s < S; ++s) {
+        const uint32_t fw = bases_at(c0, c1, c2, s, U);            // bases s .. s+U-1
+        const uint32_t rv = bases_at(r0, r1, r2, 48 - U - s, U);   // their reverse complement
+        st.h[s] = murmur64(fw, p.seed);
+        st.h2[s] = murmur64(rv, p.seed);
+    }
+    st.strand = 0;
+}
+
 // m[i] = min(key[i .. i+WW-1]) for i < NW, over key[0 .. NW+WW-2] (van Herk / Gil-Werman on values)
 template <int NW, int WW>
 BL_DEV void window_min(const uint32_t* key, uint32_t* m)
@@ -702,41 +746,63 @@ BL_DEV void gather_halo_hi(const ThreadState* all, int tid, uint32_t* key)
 }
 
 // Returns the number of syncmers the lane reports; `undecided` = true when one of the lane's comparisons met equal high dwords.
-template <int MODE, int W>
+// DIRECT: the hashes came from phase_hash_closed<U>; the k-mer's strand is then decided here, from the k-mer's first 16 bases on
+// the forward strand against its first 16 on the reverse strand (k = U + W - 1 >= 16; equal words: undecided, the exact form runs).
+template <int MODE, int W, int U = 0>
 BL_DEV uint32_t phase_sync_closed(const ScanParams& p, TileShared<MODE, W>& sh, int tid, int64_t q0, ThreadState& st, const ThreadState* all, bool& undecided)
 {
     static_assert(W >= 2, "closed syncmers need at least two s-mers per k-mer");
+    constexpr bool DIRECT = U != 0;
+    static_assert(!DIRECT || (U + W - 1 >= 16 && U + W - 1 <= 32), "the strand test reads 16 bases from either end of the k-mer");
     const int wv = wave_index(tid), lane = tid & 63;
     constexpr int NE = W - 1;        // halo elements
     constexpr int WW = W - 1;        // width of the sliding minimum
-    uint32_t kf[S + NE], kr[S + NE], mf[S + 1], mr[S + 1];
-    BL_UNROLL
-    for (int s = 0; s < S; ++s) {
-        kf[s] = (uint32_t)(st.h[s] >> 32);
-        kr[s] = (uint32_t)(st.h2[s] >> 32);
-    }
-    gather_halo_hi<NE, false>(all, tid, kf);
-    window_min<S + 1, WW>(kf, mf);
-    if (p.canonical) {
-        gather_halo_hi<NE, true>(all, tid, kr);
-        window_min<S + 1, WW>(kr, mr);
-    }
-    uint32_t hit = 0, closest = ~0u;
-    BL_UNROLL
-    for (int s = 0; s < S; ++s) {
-        const uint32_t a1 = kf[s], m1 = mf[s + 1], a2 = kf[s + W - 1], m2 = mf[s];
-        bool h = a1 <= m1 || a2 < m2;
-        uint32_t d = (a1 ^ m1) < (a2 ^ m2) ? (a1 ^ m1) : (a2 ^ m2);
-        if (p.canonical) {
-            const uint32_t a3 = kr[s + W - 1], m3 = mr[s], a4 = kr[s], m4 = mr[s + 1];
-            const bool hr = a3 <= m3 || a4 < m4;
-            const uint32_t dr = (a3 ^ m3) < (a4 ^ m4) ? (a3 ^ m3) : (a4 ^ m4);
-            const bool rev = (st.strand >> s) & 1;
-            h = rev ? hr : h;
-            d = rev ? dr : d;
+    // One strand at a time — its 16 + W - 1 high dwords, their sliding minima, then ONE BIT per k-mer: "hit if this strand is the
+    // canonical one" — so that only one strand's arrays are alive at any moment (both at once do not fit the registers of four
+    // waves per SIMD); the k-mers' strands then pick between the two 16-bit masks with three word operations.
+    uint32_t closest = ~0u;  // smallest xor distance between the two sides of any comparison: 0 = some comparison met equal dwords
+    uint32_t hit_f = 0, hit_r = 0;
+    {
+        uint32_t key[S + NE], mn[S + 1];
+        BL_UNROLL
+        for (int s = 0; s < S; ++s) key[s] = (uint32_t)(st.h[s] >> 32);
+        gather_halo_hi<NE, false>(all, tid, key);
+        window_min<S + 1, WW>(key, mn);
+        BL_UNROLL
+        for (int s = 0; s < S; ++s) {  // forward strand canonical: minimum at offset 0 (leftmost wins a tie) or strictly at W - 1
+            const uint32_t a1 = key[s], m1 = mn[s + 1], a2 = key[s + W - 1], m2 = mn[s];
+            if (a1 <= m1 || a2 < m2) hit_f |= 1u << s;
+            const uint32_t d = (a1 ^ m1) < (a2 ^ m2) ? (a1 ^ m1) : (a2 ^ m2);
+            closest = d < closest ? d : closest;
         }
-        if (h) hit |= 1u << s;
-        closest = d < closest ? d : closest;
+    }
+    uint32_t hit = hit_f;
+    if (p.canonical) {
+        uint32_t key[S + NE], mn[S + 1];
+        BL_UNROLL
+        for (int s = 0; s < S; ++s) key[s] = (uint32_t)(st.h2[s] >> 32);
+        gather_halo_hi<NE, true>(all, tid, key);
+        window_min<S + 1, WW>(key, mn);
+        BL_UNROLL
+        for (int s = 0; s < S; ++s) {  // reverse strand canonical: positions mirror, the rightmost wins a tie
+            const uint32_t a3 = key[s + W - 1], m3 = mn[s], a4 = key[s], m4 = mn[s + 1];
+            if (a3 <= m3 || a4 < m4) hit_r |= 1u << s;
+            const uint32_t d = (a3 ^ m3) < (a4 ^ m4) ? (a3 ^ m3) : (a4 ^ m4);
+            closest = d < closest ? d : closest;
+        }
+        uint32_t rev = st.strand;
+        if (DIRECT) {  // reverse strand canonical <=> rc < fwd (kmer_view.hpp:196), read off the 16 leading bases of each
+            rev = 0;
+            BL_UNROLL
+            for (int s = 0; s < S; ++s) {
+                const uint32_t f16 = bases_at(st.cw[0], st.cw[1], st.cw[2], s, 16);
+                const uint32_t r16 = bases_at(st.rw[0], st.rw[1], st.rw[2], 48 - (U + W - 1) - s, 16);
+                if (r16 < f16) rev |= 1u << s;
+                const uint32_t d = f16 ^ r16;
+                closest = d < closest ? d : closest;
+            }
+        }
+        hit = (rev & hit_r) | (~rev & hit_f);
     }
     Bits128 good, start;
     gather_flags(sh.flags + wave_chunk0(p, wv), lane, good, start);

@@ -53,12 +53,18 @@ void run_tiles(ScanParams p, unsigned long long* result)
             const int64_t q0 = p.origin + (int64_t)tile * p.stride;
             for (int tid = 0; tid < TPB; ++tid) phase_load<MODE, W>(p, *sh, tid, q0);
             for (int c = 0; c < staged_chunks(p); ++c) sc[tile * p.slot_chunks + c] = sh->codes[c];  // codes spill
-            for (int tid = 0; tid < TPB; ++tid) phase_hash<MODE, W>(p, *sh, tid, st[tid]);
+            constexpr int CSU = (MODE == MODE_SYNCMER && CS) ? 11 : 0;  // the closed-syncmer kernel is instantiated for s = 11 (launch_count_mode)
+            if (CSU) {
+                for (int tid = 0; tid < TPB; ++tid) phase_hash_closed<MODE, W, (CSU ? CSU : 1)>(p, *sh, tid, st[tid]);
+            } else {
+                for (int tid = 0; tid < TPB; ++tid) phase_hash<MODE, W>(p, *sh, tid, st[tid]);
+            }
             if (MODE == MODE_SYNCMER && CS) {  // closed syncmers: count_tile's order, the exact form where a lane is undecided
                 for (int tid = 0; tid < TPB; ++tid) {
                     bool undecided;  // (the phases read only the hashes of other lanes, which they do not change)
-                    packed[tid] = phase_sync_closed<MODE, (W > 1 ? W : 2)>(p, reinterpret_cast<TileShared<MODE, (W > 1 ? W : 2)>&>(*sh), tid, q0, st[tid], st.data(), undecided);
-                    if (undecided) {
+                    packed[tid] = phase_sync_closed<MODE, (W > 1 ? W : 2), CSU>(p, reinterpret_cast<TileShared<MODE, (W > 1 ? W : 2)>&>(*sh), tid, q0, st[tid], st.data(), undecided);
+                    if (undecided) {  // the exact form, on the rolled hashes and the exact strand (count_tile hashes again too)
+                        phase_hash<MODE, W>(p, *sh, tid, st[tid]);  // (the same hashes: the neighbours' stay valid)
                         phase_sync_fwd<MODE, W>(p, *sh, tid, st[tid], st.data(), &af[tid * (S + 1)]);
                         packed[tid] = phase_sync_rev<MODE, W>(p, *sh, tid, q0, st[tid], st.data(), &af[tid * (S + 1)]);
                     }
