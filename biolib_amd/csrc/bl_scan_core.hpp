@@ -32,6 +32,15 @@
 #define BL_COLD(c) (c)
 #endif
 
+// The instruction scheduler may not move anything across this point.  Used between groups of independent hashes: left alone, the
+// scheduler interleaves all of a lane's hashes for instruction-level parallelism and keeps every one's temporaries alive at once,
+// which is what decides whether a kernel fits the registers of four waves per SIMD.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(BL_CPU_EMU)
+#define BL_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define BL_SCHED_FENCE() do {} while (0)
+#endif
+
 namespace bl {
 
 constexpr int TPB = 256;            // threads per workgroup (4 wave64)
@@ -563,6 +572,17 @@ BL_DEV void fold_min(uint32_t& acc, uint32_t d)
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(BL_CPU_EMU)
     asm("v_min_u32_e32 %0, %1, %0" : "+v"(acc) : "v"(d));
 #else
+    acc = d < acc ? d : acc;
+#endif
+}
+
+// acc = min(acc, d1, d2), equally opaque: one v_min3_u32
+BL_DEV void fold_min3(uint32_t& acc, uint32_t d1, uint32_t d2)
+{
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(BL_CPU_EMU)
+    asm("v_min3_u32 %0, %1, %2, %0" : "+v"(acc) : "v"(d1), "v"(d2));
+#else
+    const uint32_t d = d1 < d2 ? d1 : d2;
     acc = d < acc ? d : acc;
 #endif
 }

@@ -689,7 +689,12 @@ BL_DEV void phase_hash_closed(const ScanParams& p, TileShared<MODE, W>& sh, int 
         const uint32_t fw = bases_at(c0, c1, c2, s, U);            // bases s .. s+U-1
         const uint32_t rv = bases_at(r0, r1, r2, 48 - U - s, U);   // their reverse complement
         st.h[s] = murmur64(fw, p.seed);
+        if ((s & 3) == 3) BL_SCHED_FENCE();
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(BL_CPU_EMU)
+        (void)rv;  // the reverse-strand s-mers are hashed where their minima are taken (phase_sync_closed): one strand's dwords alive at a time
+#else
         st.h2[s] = murmur64(rv, p.seed);
+#endif
     }
     st.strand = 0;
 }
@@ -772,23 +777,32 @@ BL_DEV uint32_t phase_sync_closed(const ScanParams& p, TileShared<MODE, W>& sh, 
         for (int s = 0; s < S; ++s) {  // forward strand canonical: minimum at offset 0 (leftmost wins a tie) or strictly at W - 1
             const uint32_t a1 = key[s], m1 = mn[s + 1], a2 = key[s + W - 1], m2 = mn[s];
             if (a1 <= m1 || a2 < m2) hit_f |= 1u << s;
-            const uint32_t d = (a1 ^ m1) < (a2 ^ m2) ? (a1 ^ m1) : (a2 ^ m2);
-            closest = d < closest ? d : closest;
+            fold_min3(closest, a1 ^ m1, a2 ^ m2);  // (opaque to the optimizer, which would turn the chain into a tree with every leaf alive)
         }
     }
     uint32_t hit = hit_f;
     if (p.canonical) {
         uint32_t key[S + NE], mn[S + 1];
-        BL_UNROLL
-        for (int s = 0; s < S; ++s) key[s] = (uint32_t)(st.h2[s] >> 32);
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(BL_CPU_EMU)
+        if (DIRECT) {
+            BL_UNROLL
+            for (int s = 0; s < S; ++s) {
+                key[s] = (uint32_t)(murmur64(bases_at(st.rw[0], st.rw[1], st.rw[2], 48 - (DIRECT ? U : 1) - s, DIRECT ? U : 1), p.seed) >> 32);
+                if ((s & 3) == 3) BL_SCHED_FENCE();
+            }
+        } else
+#endif
+        {
+            BL_UNROLL
+            for (int s = 0; s < S; ++s) key[s] = (uint32_t)(st.h2[s] >> 32);
+        }
         gather_halo_hi<NE, true>(all, tid, key);
         window_min<S + 1, WW>(key, mn);
         BL_UNROLL
         for (int s = 0; s < S; ++s) {  // reverse strand canonical: positions mirror, the rightmost wins a tie
             const uint32_t a3 = key[s + W - 1], m3 = mn[s], a4 = key[s], m4 = mn[s + 1];
             if (a3 <= m3 || a4 < m4) hit_r |= 1u << s;
-            const uint32_t d = (a3 ^ m3) < (a4 ^ m4) ? (a3 ^ m3) : (a4 ^ m4);
-            closest = d < closest ? d : closest;
+            fold_min3(closest, a3 ^ m3, a4 ^ m4);
         }
         uint32_t rev = st.strand;
         if (DIRECT) {  // reverse strand canonical <=> rc < fwd (kmer_view.hpp:196), read off the 16 leading bases of each
@@ -798,8 +812,7 @@ BL_DEV uint32_t phase_sync_closed(const ScanParams& p, TileShared<MODE, W>& sh, 
                 const uint32_t f16 = bases_at(st.cw[0], st.cw[1], st.cw[2], s, 16);
                 const uint32_t r16 = bases_at(st.rw[0], st.rw[1], st.rw[2], 48 - (U + W - 1) - s, 16);
                 if (r16 < f16) rev |= 1u << s;
-                const uint32_t d = f16 ^ r16;
-                closest = d < closest ? d : closest;
+                fold_min(closest, f16 ^ r16);
             }
         }
         hit = (rev & hit_r) | (~rev & hit_f);
