@@ -143,6 +143,7 @@ KERNEL64(k_mov_b64, "v_mov_b64 %0, %0")
     }
 KERNELC(k_add64, x + k)
 KERNELC(k_mul64c, x * 0x87c37b91114253d5ULL)
+KERNELC(k_mul64split, bl::mul64c(x, 0x87c37b91114253d5ULL))
 KERNELC(k_xorshift33, x ^ (x >> 33))
 KERNELC(k_rotl31, bl::rotl64_31(x))
 KERNELC(k_fmix64, bl::fmix64(x))
@@ -189,7 +190,7 @@ int main(int argc, char** argv)
         {"v_add_u32_dpp wave_shl", k_add_dpp_wave_shl, 0},
         {"v_mad_u64_u32", k_mad_u64_u32, 0}, {"v_lshlrev_b64", k_lshlrev_b64, 0}, {"v_lshrrev_b64", k_lshrrev_b64, 0}, {"v_cmp_lt_u64", k_cmp_lt_u64, 0},
         {"v_lshl_add_u64", k_lshl_add_u64, 0}, {"v_mov_b64", k_mov_b64, 0},
-        {"C: x + k (u64)", k_add64, 1}, {"C: x * const (u64)", k_mul64c, 1}, {"C: x ^ (x >> 33)", k_xorshift33, 1}, {"C: rotl64(x, 31)", k_rotl31, 1},
+        {"C: x + k (u64)", k_add64, 1}, {"C: x * const (u64)", k_mul64c, 1}, {"C: mul64c(x, const): mul_lo + 2 mad + mov", k_mul64split, 1}, {"C: x ^ (x >> 33)", k_xorshift33, 1}, {"C: rotl64(x, 31)", k_rotl31, 1},
         {"C: fmix64", k_fmix64, 1}, {"C: murmur64 (whole hash)", k_murmur64, 1}, {"C: min(x, k) (u64)", k_min64, 1},
     };
     const int wps_list[4] = {1, 2, 4, 8};
