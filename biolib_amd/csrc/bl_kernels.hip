@@ -110,7 +110,8 @@ __device__ __forceinline__ void count_tile(const ScanParams& p, TileShared<MODE,
     const int64_t q0 = p.origin + (int64_t)tile * p.stride;
     phase_load<MODE, W>(p, sh, tid, q0);
     if (CS && tid == 0) sh.redo = 0;
-    {   // hand the packed codes to pass 2 (0.26 B/base instead of re-reading and re-encoding 1 B/base there)
+    if (MODE != MODE_SYNCMER) {  // hand the packed codes to pass 2 (0.26 B/base instead of re-reading and re-encoding 1 B/base there);
+                                 // a syncmer record is a position: its pass 2 rebuilds nothing and reads no codes
         const int needed = staged_chunks(p);
         uint32_t* sc = p.slots_c + (size_t)tile * p.slot_chunks;
         if (tid < needed) sc[tid] = sh.codes[tid];  // own LDS entries: no barrier needed
@@ -204,8 +205,8 @@ __device__ __forceinline__ void emit_tile(const ScanParams& p, uint32_t* codes, 
     const unsigned long long base = p.tile_base[tile] + p.block_base[tile / SCAN_BLK];
     const int needed = staged_chunks(p);
     const uint32_t* sc = p.slots_c + (size_t)tile * p.slot_chunks;
-    const uint32_t c0 = tid < needed ? sc[tid] : 0;
-    const uint32_t c1 = TPB + tid < needed ? sc[TPB + tid] : 0;
+    const uint32_t c0 = (MODE != MODE_SYNCMER && tid < needed) ? sc[tid] : 0;
+    const uint32_t c1 = (MODE != MODE_SYNCMER && TPB + tid < needed) ? sc[TPB + tid] : 0;
     const uint16_t* la = p.slots_a + slot;
     const uint16_t* lj = MODE == MODE_SUPERKMER ? p.slots_j + slot : nullptr;
     const bool in0 = tid < p.stride, in1 = TPB + tid < p.stride;  // inside the slot (its tail past n_s holds stale entries: never used)
@@ -218,9 +219,11 @@ __device__ __forceinline__ void emit_tile(const ScanParams& p, uint32_t* codes, 
     const uint32_t n_s = (uint32_t)cnt, n_e = (uint32_t)(cnt >> 32);
     if (n_s == 0 && n_e == 0) return;  // uniform for the workgroup
     const uint64_t base_s = base & 0xffffffffull, base_e = base >> 32;
-    if (tid < needed) codes[tid] = c0;
-    if (TPB + tid < needed) codes[TPB + tid] = c1;
-    __syncthreads();
+    if (MODE != MODE_SYNCMER) {  // (syncmers: no codes, no barrier — a record is its list entry's position)
+        if (tid < needed) codes[tid] = c0;
+        if (TPB + tid < needed) codes[TPB + tid] = c1;
+        __syncthreads();
+    }
     const bool fits = !BL_COLD(base_s + n_s > p.capacity);
     TileLists L{codes, la, lj, MODE == MODE_SUPERKMER ? p.slots_e + slot : nullptr, MODE == MODE_SUPERKMER ? p.slots_e + slot + p.stride : nullptr};
     const uint32_t d = (uint32_t)(base_s - base_e);  // 0 or 1 (see end_position)
