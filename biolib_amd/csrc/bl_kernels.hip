@@ -122,7 +122,7 @@ __device__ __forceinline__ void count_tile(const ScanParams& p, TileShared<MODE,
     ThreadState st;
     constexpr bool DIRECT = MODE == MODE_SYNCMER && CS && U >= 1 && U <= 16 && U + W - 1 >= 16 && U + W - 1 <= 32;  // phase_hash_closed applies
     if (DIRECT) phase_hash_closed<MODE, W, (DIRECT ? U : 1)>(p, sh, tid, st);
-    else phase_hash<MODE, W>(p, sh, tid, st);
+    else phase_hash<MODE, W, (MODE != MODE_SYNCMER && U >= 1 && U <= 16 ? U : 0)>(p, sh, tid, st);
 
     uint32_t packed;
     if (MODE == MODE_SYNCMER && CS) {  // closed syncmers: sliding minima of the high dwords, no argmin

@@ -177,9 +177,31 @@ BL_DEV void gather_flags(const uint32_t* flags, int lane, Bits128& good, Bits128
     start = Bits128{s[0], s[1]};
 }
 
+// n bases (n <= 16) from base `o` of the 48 bases a0:a1:a2 (16 per word, first base in the top pair), as an n-mer in the low 2n bits.
+// o and n are compile-time constants where this is used: one v_bfe_u32 when the bases lie in one word, v_alignbit_b32 + shift
+// otherwise — against the six instructions a rolling update of a forward and a reverse-complement register costs per base.
+BL_DEV uint32_t bases_at(uint32_t a0, uint32_t a1, uint32_t a2, int o, int n)
+{
+    const int q = o >> 4, r = o & 15;
+    const uint32_t hi = q == 0 ? a0 : (q == 1 ? a1 : a2), lo = q == 0 ? a1 : (q == 1 ? a2 : 0u);
+    if (r + n <= 16) return n == 16 ? hi : (hi >> (32 - 2 * (r + n))) & ((1u << (2 * n)) - 1u);
+    const uint32_t w16 = funnel_shr(hi, lo, 32 - 2 * r);  // the 16 bases from o on (r != 0 here)
+    return n == 16 ? w16 : w16 >> (32 - 2 * n);
+}
+
+// reverse complement of 16 bases (one word of codes)
+BL_DEV uint32_t revcomp16(uint32_t c)
+{
+    const uint32_t r = __builtin_bitreverse32(c);
+    return ~(((r >> 1) & 0x55555555u) | ((r & 0x55555555u) << 1));
+}
+
 // ------------------------------------------------------------------------------------------------
 // Phase 2: roll the owned 16 units in registers and hash them.
-template <int MODE, int W>
+// U: the unit length as a compile-time constant when it is one and fits a word (1..16; the BASELINE C4 kernel: 15-mers) — the
+// units then come straight from the codes and from their reverse complement (bases_at: one or two instructions each, the
+// canonical one by a single v_min_u32) instead of two rolling registers, a 64-bit compare and two selects.  0: rolling registers.
+template <int MODE, int W, int U = 0>
 BL_DEV void phase_hash(const ScanParams& p, TileShared<MODE, W>& sh, int tid, ThreadState& st)
 {
     const int wv = wave_index(tid), lane = tid & 63;
@@ -202,6 +224,18 @@ BL_DEV void phase_hash(const ScanParams& p, TileShared<MODE, W>& sh, int tid, Th
             if (p.canonical && roller_rc(rk) < roller_fwd(rk)) strand |= 1u << s;  // kmer_view.hpp:196
         }
         st.strand = strand;
+    } else if (U >= 1 && U <= 16) {
+        const uint32_t r0 = revcomp16(c2), r1 = revcomp16(c1), r2 = revcomp16(c0);  // base b of the lane = base 47 - b of r0:r1:r2
+        BL_UNROLL
+        for (int s = 0; s < S; ++s) {
+            const uint32_t fw = bases_at(c0, c1, c2, s, U >= 1 && U <= 16 ? U : 1);
+            uint32_t v = fw;
+            if (p.canonical) {
+                const uint32_t rv = bases_at(r0, r1, r2, 48 - (U >= 1 && U <= 16 ? U : 1) - s, U >= 1 && U <= 16 ? U : 1);
+                v = rv < fw ? rv : fw;  // numeric minimum, minimizer_view.hpp:236-238
+            }
+            st.h[s] = murmur64(v, p.seed);
+        }
     } else {
         BL_UNROLL
         for (int s = 0; s < S; ++s) {
@@ -651,25 +685,6 @@ BL_DEV uint32_t phase_sync_rev(const ScanParams& p, TileShared<MODE, W>& sh, int
 // so one sliding minimum of width W - 1 per strand over the hashes' HIGH DWORDS (no position tags, one v_min_u32 per step, no
 // tie bookkeeping inside the windows) and four comparisons per k-mer decide.  A comparison whose two high dwords are EQUAL is
 // undecided; the caller then runs the exact argmin form for the wave (phase_sync_fwd / phase_sync_rev).
-
-// n bases (n <= 16) from base `o` of the 48 bases a0:a1:a2 (16 per word, first base in the top pair), as an n-mer in the low 2n bits.
-// o and n are compile-time constants where this is used: one v_bfe_u32 when the bases lie in one word, v_alignbit_b32 + shift
-// otherwise — against the six instructions a rolling update of a forward and a reverse-complement register costs per base.
-BL_DEV uint32_t bases_at(uint32_t a0, uint32_t a1, uint32_t a2, int o, int n)
-{
-    const int q = o >> 4, r = o & 15;
-    const uint32_t hi = q == 0 ? a0 : (q == 1 ? a1 : a2), lo = q == 0 ? a1 : (q == 1 ? a2 : 0u);
-    if (r + n <= 16) return n == 16 ? hi : (hi >> (32 - 2 * (r + n))) & ((1u << (2 * n)) - 1u);
-    const uint32_t w16 = funnel_shr(hi, lo, 32 - 2 * r);  // the 16 bases from o on (r != 0 here)
-    return n == 16 ? w16 : w16 >> (32 - 2 * n);
-}
-
-// reverse complement of 16 bases (one word of codes)
-BL_DEV uint32_t revcomp16(uint32_t c)
-{
-    const uint32_t r = __builtin_bitreverse32(c);
-    return ~(((r >> 1) & 0x55555555u) | ((r & 0x55555555u) << 1));
-}
 
 // Phase 2 of the closed-syncmer scan (compile-time s-mer length U <= 16): both s-mers of every position straight from the codes
 // and from their reverse complement — no rolling registers, and no k-mer register at all: which strand of the K-MER is canonical

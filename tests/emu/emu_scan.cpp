@@ -35,7 +35,7 @@ std::vector<uint32_t> make_start_bits(uint64_t n_bases, const uint64_t* offsets,
 }
 
 // pass 1 (scan_count_kernel) for every tile, the tile-count prefix scan, pass 2 (scan_emit_kernel)
-template <int MODE, int W, bool CS = false>
+template <int MODE, int W, bool CS = false, int U = 0>
 void run_tiles(ScanParams p, unsigned long long* result)
 {
     const size_t nt = (size_t)p.n_tiles;
@@ -57,7 +57,7 @@ void run_tiles(ScanParams p, unsigned long long* result)
             if (CSU) {
                 for (int tid = 0; tid < TPB; ++tid) phase_hash_closed<MODE, W, (CSU ? CSU : 1)>(p, *sh, tid, st[tid]);
             } else {
-                for (int tid = 0; tid < TPB; ++tid) phase_hash<MODE, W>(p, *sh, tid, st[tid]);
+                for (int tid = 0; tid < TPB; ++tid) phase_hash<MODE, W, (MODE != MODE_SYNCMER ? U : 0)>(p, *sh, tid, st[tid]);
             }
             if (MODE == MODE_SYNCMER && CS) {  // closed syncmers: count_tile's order, the exact form where a lane is undecided
                 for (int tid = 0; tid < TPB; ++tid) {
@@ -224,7 +224,10 @@ void run_mode(const ScanParams& p, unsigned long long* result)
         case 10: if (MODE != MODE_SYNCMER) { run_tiles<MODE, 10>(p, result); break; } run_tiles<MODE, -8>(p, result); break;
         case 19: if (MODE != MODE_SYNCMER) { run_tiles<MODE, 19>(p, result); break; } run_tiles<MODE, -16>(p, result); break;
         case 11: run_tiles<MODE, 11>(p, result); break;
-        case 17: run_tiles<MODE, 17>(p, result); break;
+        case 17:
+            if (MODE == MODE_SUPERKMER && p.unit == 15 && p.canonical) { run_tiles<MODE_SUPERKMER, 17, false, 15>(p, result); break; }  // the BASELINE C4 kernel
+            run_tiles<MODE, 17>(p, result);
+            break;
         case 21:
             if (MODE == MODE_SYNCMER && p.unit == 11 && p.canonical && ((p.soff == 0 && p.eoff == 20) || (p.soff == 20 && p.eoff == 0))) {
                 run_tiles<MODE_SYNCMER, 21, true>(p, result);  // the BASELINE C5 kernel (launch_count_mode)
