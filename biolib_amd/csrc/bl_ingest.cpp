@@ -432,6 +432,7 @@ private:
     }
     void give_part(PartSlot* s)
     {
+        s->part.sym.shrink_to(8ull * part_bytes_);  // (text is usually 3-6 symbols per compressed byte)
         {
             std::lock_guard<std::mutex> lk(m_);
             free_parts_.push_back(s);
@@ -446,7 +447,9 @@ private:
         const uint64_t limit = 8 * (index + 1) * (uint64_t)part_bytes_;
         auto job = [this, s, index, first, limit] {
             static thread_local blpg::SymbolDecoder decoder;
-            constexpr uint64_t MAX_SYMBOLS = 48ull << 20;
+            // a part ends after 24 symbols per compressed byte of it at the latest (never less than 4 M, never more than 48 M): what
+            // follows is found by the next part's search or, failing that, decoded by zlib — bounded memory, not unbounded buffers
+            const uint64_t MAX_SYMBOLS = std::min<uint64_t>(48ull << 20, std::max<uint64_t>(4ull << 20, 24ull * part_bytes_));
             if (!cancel_) {
                 uint64_t t0 = now_us();
                 uint64_t at = index == 0 ? first : blpg::find_block(map_, size_, first, limit);

@@ -272,6 +272,15 @@ struct SymbolBuffer {
         cap = n;
         return true;
     }
+    // give memory back when a part needed far more than parts usually do (a run of highly compressible text): the slots live as
+    // long as the stream is read, and with 16 workers their high-water marks used to add up to gigabytes
+    void shrink_to(uint64_t n)
+    {
+        if (cap <= n) return;
+        std::free(p);
+        p = nullptr;
+        cap = 0;
+    }
 };
 
 // One part of the stream as symbols.

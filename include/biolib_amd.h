@@ -206,7 +206,12 @@ int bl_reader_open_threads(const char* path, int threads, bl_reader** out);
  * members from the first member boundary at or behind byte size / world * rank to the next part's, and delivers the records that
  * BEGIN in its text — from the first record start that can be recognised there (a line that opens a record, a newline in front of
  * it inside the part's text) to the place where the next part's reader finds its own, found by inflating into the next part.
- * The parts' records, in rank order, are the file's records; the readers do not talk to each other.  Device batches only
+ * The parts' records, in rank order, are the file's records; the readers do not talk to each other.
+ * RESTRICTION: a FASTQ record start is recognised as a line that opens with '@' and whose second-next line opens with '+', i.e.
+ * FOUR-LINE FASTQ (one sequence line, one quality line per record: what sequencers and every current tool write).  Multi-line
+ * FASTQ — which the whole-file readers accept, as kseq does — must be read with world = 1: in parts, its boundaries may not be
+ * found (records then fall to an earlier part) or, rarely, a quality line may be taken for a header.  FASTA has no such limit.
+ * Device batches only
  * (bl_reader_next_batch_device) from a BGZF part.  BL_ERR_INVALID for a gzip file that is not BGZF (one stream, no entry points).  This is how north_star's "shard by read" reaches the
  * file: the reference's drivers read one file per process (tests/test_kmer_view.cpp:23-42). */
 int bl_reader_open_shard(const char* path, uint32_t rank, uint32_t world, bl_reader** out);
