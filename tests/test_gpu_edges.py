@@ -370,3 +370,48 @@ def test_full_baseline_size_c5_syncmers_with_rccl_count_reduce():
         if created:
             dist.destroy_process_group()
     c.close()
+
+
+def test_upload_reads_origin_and_markers(ctx):
+    """round-3 entry points: bl_batch_upload_reads (reads of one length, no offsets) scans like the same reads uploaded with
+    offsets and like the device generator's batch; bl_batch_set_origin shifts every reported position and the position digest,
+    nothing else; bl_ctx_mark / bl_ctx_mark_times give non-decreasing device times, one per marker"""
+    import biolib_amd as B
+
+    L, n_reads = 150, 20_001
+    n = L * n_reads - 37  # a shorter last read is kept
+    seq = O.synth(42, n)
+    a = ctx.upload(seq, read_len=L)
+    b = ctx.upload(seq, np.minimum(np.arange(0, n + L, L, dtype=np.uint64), n))
+    assert a.n_seqs == b.n_seqs == n_reads and a.n_bases == n
+    ra, rb = a.minimizers(31, 11, seed=42, canonical=True), b.minimizers(31, 11, seed=42, canonical=True)
+    v, p, h = O.minimizers(seq, np.minimum(np.arange(0, n + L, L, dtype=np.uint64), n), 31, 11, 42, True, brute=False)
+    for r in (ra, rb):
+        assert r["count"] == len(v) and np.array_equal(r["values"], v) and np.array_equal(r["positions"], p) and np.array_equal(r["hashes"], h)
+    one = ctx.upload(seq[:1000], read_len=5000)  # a read length beyond the batch: one sequence
+    assert one.n_seqs == 1
+    one.close()
+    # origin: positions and xor_pos move, values / hashes / counts do not
+    origin = (1 << 40) + 12345
+    a.set_origin(origin)
+    for scan, key in ((lambda: a.minimizers(31, 11, seed=42, canonical=True), "positions"), (lambda: a.super_kmers(31, 15, seed=42, canonical=True), "first_pos"),
+                      (lambda: a.syncmers(31, 11, 0, 20, canonical=True), "positions")):
+        moved = scan()
+        a.set_origin(0)
+        plain = scan()
+        a.set_origin(origin)
+        assert moved["count"] == plain["count"] and np.array_equal(moved[key], plain[key] + np.uint64(origin))
+    r0 = a.minimizers_raw(31, 11, 42, B.FLAG_CANONICAL | B.FLAG_SYNC)
+    assert int(r0.xor_pos) == O.xor_reduce(p + np.uint64(origin)) and int(r0.xor_hash) == O.xor_reduce(h)
+    a.close(); b.close()
+    # markers
+    c = B.Context(0, torch_stream=False, lanes=2)
+    big = c.synth(1, 150 * 2_000_000, 150)
+    c.mark()
+    for _ in range(3):
+        big.minimizers_raw(31, 11, 42, B.FLAG_CANONICAL)
+        c.mark()
+    t = c.mark_times()
+    assert len(t) == 4 and t[0] >= 0 and all(y >= x for x, y in zip(t[:-1], t[1:])) and t[-1] > 0
+    assert c.mark_times() == []  # forgotten
+    big.close(); c.close()
