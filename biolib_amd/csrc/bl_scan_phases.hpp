@@ -536,6 +536,10 @@ BL_DEV void window_argmin_runtime(const ScanParams& p, TileShared<MODE, W>& sh, 
 }
 
 
+// position-tiled minimizer scans with a window width in registers and an element mask that fits a dword
+template <int MODE, int W>
+constexpr bool pos_occ_form() { return MODE == MODE_MINIMIZER && W >= 2 && W <= 16; }
+
 // ------------------------------------------------------------------------------------------------
 // Phase 3 (minimizer / super-k-mer): window argmins, validity, start/end decisions.
 // Returns the packed per-thread counts: starts | ends << 16.
@@ -586,6 +590,49 @@ BL_DEV uint32_t phase_window(const ScanParams& p, TileShared<MODE, W>& sh, int t
     uint32_t inrange = 0x1ffffu;
     if (!inside) inrange = range_mask(p.win_first - j0, p.win_end - j0);
     if (MODE == MODE_SUPERKMER) valid &= inrange;
+    if (pos_occ_form<MODE, W>()) {
+        // ELEMENT-CENTRIC decisions (see bl_scan_frl.hpp: a minimizer occurrence is an element that some valid window chooses; the
+        // windows that choose it are consecutive and argmins never move left).  The lane reports the windows 1..16 it owns: one bit
+        // per window into a mask indexed by element (element = low bits of the packed minimum; at most 16 + W - 1 <= 31).  An
+        // element whose run of windows began BEFORE the first window this wave reports — the window in front of lane 0's, or one in
+        // front of the scanned range — is a continuation, not a new occurrence: the bit of that window's argmin is cleared.
+        const uint32_t owned = owned_mask(p, lane);
+        const uint32_t cnt = (valid >> 1) & owned & (inrange >> 1) & 0xffffu;  // bit s: window s + 1 is this lane's to report
+        uint32_t occ = 0;
+        if (BL_COLD(wave_any(cnt != 0xffffu && cnt != 0u))) {
+            BL_UNROLL
+            for (int s = 0; s < S; ++s) occ |= ((cnt >> s) & 1u) << (a[s + 1] & 31u);
+        } else {  // every lane reports all of its windows or none (the wave's last lane owns none)
+            BL_UNROLL
+            for (int s = 0; s < S; ++s) occ |= 1u << (a[s + 1] & 31u);
+            occ = cnt ? occ : 0u;
+        }
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(BL_CPU_EMU)
+        const uint32_t prev_cnt = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cnt, 0x138, 0xf, 0xf, false);  // wave_shr:1, lane 0 gets 0
+#else
+        const uint32_t prev_cnt = lane > 0 ? all[tid - 1].vmask : 0u;
+#endif
+        const uint32_t pc = (cnt << 1) | ((prev_cnt >> 15) & 1u);  // bit s: window s is reported by this wave (window 0: by the lane before)
+        const uint32_t edge = valid & ~pc & (pc >> 1);              // bit s: window s is valid, not reported here, and window s + 1 is
+        uint32_t kill = (edge & 1u) << (a[0] & 31u);
+        if (BL_COLD(wave_any((edge >> 1) != 0u))) {                 // (only at the front of a range that does not start its batch)
+            BL_UNROLL
+            for (int s = 1; s < S; ++s) kill |= ((edge >> s) & 1u) << (a[s] & 31u);
+        }
+        // (the windows that choose an element sit in its own lane and in the one before: a cleared element is cleared in both)
+        st.vmask = cnt;
+        st.occ = occ;
+        st.a_first = kill;
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(BL_CPU_EMU)
+        const uint32_t prev_occ = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)occ, 0x138, 0xf, 0xf, false);
+        const uint32_t prev_kill = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)kill, 0x138, 0xf, 0xf, false);
+#else
+        const uint32_t prev_occ = lane > 0 ? all[tid - 1].occ : 0u, prev_kill = lane > 0 ? all[tid - 1].a_first : 0u;
+#endif
+        st.emit = ((occ & 0xffffu) | (prev_occ >> 16)) & ~((kill & 0xffffu) | (prev_kill >> 16));  // bit s: the lane's own position s is a minimizer occurrence
+        st.endm = 0;
+        return (uint32_t)__builtin_popcount(st.emit);
+    }
     // a[s] holds the argmin of window s in its low 6 bits (the packed form leaves hash bits above them).  Four at a
     // time: apk[j] = bytes a[4j+1..4j+4] (what the list phase reads), prv[j] = bytes a[4j..4j+3]; differ bit s = the two
     // bytes at s disagree = argmin of window s+1 is a different occurrence than that of window s.
@@ -864,7 +911,7 @@ BL_DEV void phase_list(TileShared<MODE, W>& sh, int tid, const ThreadState& st, 
     while (m) {
         const int s = __builtin_ctz(m);
         m &= m - 1;
-        if (MODE == MODE_SYNCMER) {
+        if (MODE == MODE_SYNCMER || pos_occ_form<MODE, W>()) {  // the bit's own position is the record's
             sh.list_a[r] = (uint16_t)(tag | (uint32_t)(16 * lane + s));
         } else {
             const uint32_t arel = (uint32_t)((s < 8 ? st.apk0 : st.apk1) >> (8 * (s & 7))) & 0xffu;
