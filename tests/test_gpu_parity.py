@@ -360,3 +360,48 @@ def test_read_tiled_scan_on_tiles_of_repeats(ctx):
         assert got["count"] == len(v)
         assert np.array_equal(got["values"], v) and np.array_equal(got["positions"], p) and np.array_equal(got["hashes"], h)
     b.close()
+
+
+@pytest.mark.gpu
+def test_baseline_kernels_on_random_layouts_and_cuts(ctx):
+    """the specialised kernels of the BASELINE configurations (C3 read-tiled and position-tiled, C4, C5 closed syncmers with its
+    redo kernel) and the minimap2 widths on random sizes, layouts (one sequence, 150-bp / 10-kbp / ragged reads), breaks and
+    repeat islands: whole scans against the oracle, and two ranges cut at a random position against the whole
+    (BL_FUZZ_ROUNDS scales the number of cases for an exploratory run)"""
+    rng = np.random.default_rng(777)
+    for it in range(12 * int(os.environ.get("BL_FUZZ_ROUNDS", "1"))):
+        n = int(rng.integers(2_000, 400_000))
+        flavour = ["plain", "breaks", "mixed_repeats", "lowcomplexity"][int(rng.integers(4))]
+        seq, _ = _random_case(rng, n, flavour)
+        layout = int(rng.integers(4))
+        if layout == 0:
+            offs = np.array([0, n], np.uint64)
+        elif layout == 1:
+            n = n // 150 * 150
+            seq = seq[:n]
+            offs = O.fixed_offsets(n, 150)
+        elif layout == 2:
+            offs = O.fixed_offsets(n, 10_000)
+        else:
+            cuts = np.unique(np.concatenate([[0, n], rng.integers(0, n + 1, n // 3000 + 2)]))
+            offs = cuts.astype(np.uint64)
+        b = ctx.upload(seq, offs)
+        cut = int(rng.integers(1, n)) if layout != 1 else int(rng.integers(1, n // 150)) * 150  # (read-aligned for the read-tiled kernels half of the time)
+        if layout == 1 and rng.integers(2):
+            cut = int(rng.integers(1, n))
+        for unit, w in ((31, 11), (15, 10), (21, 5)):
+            v, p, h = O.minimizers(seq, offs, unit, w, 42, True, brute=False)
+            got = b.minimizers(unit, w, seed=42, canonical=True)
+            assert got["count"] == len(v) and np.array_equal(got["positions"], p) and np.array_equal(got["values"], v) and np.array_equal(got["hashes"], h), (it, flavour, layout, n, unit, w)
+            g1, g2 = b.minimizers(unit, w, seed=42, canonical=True, first=0, n=cut), b.minimizers(unit, w, seed=42, canonical=True, first=cut, n=n - cut)
+            assert np.array_equal(np.concatenate([g1["positions"], g2["positions"]]), p) and np.array_equal(np.concatenate([g1["hashes"], g2["hashes"]]), h), (it, flavour, layout, n, cut, unit, w)
+        mn, fp, mp, sz, hs = O.super_kmers(seq, offs, 31, 15, 42, True)
+        g = b.super_kmers(31, 15, seed=42, canonical=True)
+        assert g["count"] == len(mn) and np.array_equal(g["first_pos"], fp) and np.array_equal(g["sizes"], sz) and np.array_equal(g["mm_pos"], mp) and np.array_equal(g["minimizers"], mn), (it, flavour, layout, n)
+        for drop in (False, True):
+            cnt, pos = O.syncmers(seq, offs, 31, 11, 0, 20, True, drop_last=drop)
+            gs = b.syncmers(31, 11, 0, 20, canonical=True, drop_last=drop)
+            assert gs["count"] == cnt and np.array_equal(gs["positions"], pos), (it, flavour, layout, n, drop)
+            s1, s2 = b.syncmers(31, 11, 0, 20, canonical=True, drop_last=drop, first=0, n=cut), b.syncmers(31, 11, 0, 20, canonical=True, drop_last=drop, first=cut, n=n - cut)
+            assert np.array_equal(np.concatenate([s1["positions"], s2["positions"]]), pos), (it, flavour, layout, n, cut, drop)
+        b.close()
