@@ -5,6 +5,12 @@
 #include "bl_scan_frl.hpp"
 #include "bl_launch.hpp"
 
+#ifndef BL_SY0_WAVES
+#define BL_SY0_WAVES 2  // waves per SIMD the argmin syncmer kernels with the exact form inline are compiled for
+#endif
+#ifndef BL_SY2_WAVES
+#define BL_SY2_WAVES 3  // ... and the argmin syncmer kernel whose exact form is deferred to scan_redo_kernel
+#endif
 #ifndef BL_CS_WAVES
 #define BL_CS_WAVES 3  // waves per SIMD the closed-syncmer kernel is compiled for
 #endif
@@ -104,12 +110,15 @@ __device__ __forceinline__ void fill_list(uint16_t* dst, const uint16_t* src, ui
 // Pass 1 of one tile: hash, window minimum, start/end decisions, tile-local compaction; leaves the
 // tile's record counts and u16 lists in global scratch.  Tiles are independent: no ticket, no
 // inter-workgroup wait, any dispatch order.
-template <int MODE, int W, bool CS = false, int U = 0>
+// SY (syncmer scans): 0 = tagged argmins with the exact form inline (also what scan_redo_kernel runs), 1 = closed syncmers
+// (sliding minima), 2 = tagged argmins WITHOUT the exact form: a tile that met a prefix tie is listed for scan_redo_kernel
+template <int MODE, int W, int SY = 0, int U = 0>
 __device__ __forceinline__ void count_tile(const ScanParams& p, TileShared<MODE, W>& sh, uint32_t tile, int tid)
 {
     const int64_t q0 = p.origin + (int64_t)tile * p.stride;
     phase_load<MODE, W>(p, sh, tid, q0);
-    if (CS && tid == 0) sh.redo = 0;
+    constexpr bool CS = SY == 1;
+    if (SY != 0 && tid == 0) sh.redo = 0;
     if (MODE != MODE_SYNCMER) {  // hand the packed codes to pass 2 (0.26 B/base instead of re-reading and re-encoding 1 B/base there);
                                  // a syncmer record is a position: its pass 2 rebuilds nothing and reads no codes
         const int needed = staged_chunks(p);
@@ -120,8 +129,9 @@ __device__ __forceinline__ void count_tile(const ScanParams& p, TileShared<MODE,
     __syncthreads();
 
     ThreadState st;
-    constexpr bool DIRECT = MODE == MODE_SYNCMER && CS && U >= 1 && U <= 16 && U + W - 1 >= 16 && U + W - 1 <= 32;  // phase_hash_closed applies
-    if (DIRECT) phase_hash_closed<MODE, W, (DIRECT ? U : 1)>(p, sh, tid, st);
+    constexpr bool DIRECT = MODE == MODE_SYNCMER && SY != 0 && U >= 1 && U <= 16 && U + W - 1 >= 16 && U + W - 1 <= 32;  // phase_hash_closed applies
+    bool tie = false;
+    if (DIRECT) phase_hash_closed<MODE, W, (DIRECT ? U : 1), SY == 2>(p, sh, tid, st, &tie);
     else phase_hash<MODE, W, (MODE != MODE_SYNCMER && U >= 1 && U <= 16 ? U : 0)>(p, sh, tid, st);
 
     uint32_t packed;
@@ -131,6 +141,11 @@ __device__ __forceinline__ void count_tile(const ScanParams& p, TileShared<MODE,
         // equal high dwords somewhere in the wave: the tile is listed and counted again, in the exact form, by scan_redo_kernel — a
         // kernel of its own, because that form needs twice the registers and, inlined here, pushes spills into this kernel's hot path
         if (BL_COLD(wave_any(undecided)) && (tid & 63) == 0) sh.redo = 1;
+    } else if (MODE == MODE_SYNCMER && SY == 2 && W > 1) {
+        uint32_t af[S + 1];
+        phase_sync_fwd<MODE, W, true>(p, sh, tid, st, nullptr, af, &tie);
+        packed = phase_sync_rev<MODE, W, true>(p, sh, tid, q0, st, nullptr, af, &tie);
+        if (BL_COLD(wave_any(tie)) && (tid & 63) == 0) sh.redo = 1;
     } else if (MODE == MODE_SYNCMER) {
         uint32_t af[S + 1];
         phase_sync_fwd<MODE, W>(p, sh, tid, st, nullptr, af);
@@ -145,7 +160,7 @@ __device__ __forceinline__ void count_tile(const ScanParams& p, TileShared<MODE,
     phase_list<MODE, W>(sh, tid, st, excl & 0xffffu, excl >> 16);
     if (tid == 0) p.tile_counts[tile] = (unsigned long long)n_s | ((unsigned long long)n_e << 32);
     __syncthreads();  // lists complete
-    if (CS && tid == 0 && BL_COLD(sh.redo != 0)) p.redo_list[atomicAdd(p.redo_count, 1ull)] = tile;
+    if (SY != 0 && tid == 0 && BL_COLD(sh.redo != 0)) p.redo_list[atomicAdd(p.redo_count, 1ull)] = tile;
 
     // spill the compacted lists: two u16 entries per 32-bit store (sub-dword global stores are not
     // write-combined on gfx950: 2-byte stores cost a 32-byte memory write each, measured 6.4 GB of
@@ -251,9 +266,9 @@ __device__ __forceinline__ void emit_tile(const ScanParams& p, uint32_t* codes, 
 // U (unit length) and C (canonical flag) specialise the BASELINE configurations at compile time: the
 // parameter block is copied and the fields overwritten with constants, which the inlined phases fold
 // (constant shifts and masks in the roller, no strand selects).  U = 0 / C = -1: taken from the arguments.
-// CS: closed syncmers (offsets {0, W - 1}; phase_sync_closed)
-template <int MODE, int W, int U, int C, bool CS = false>
-__global__ __launch_bounds__(TPB, (CS ? BL_CS_WAVES : (MODE == MODE_SYNCMER || (MODE == MODE_SUPERKMER && W == -32) ? 2 : (W == -32 || (W < 0 && MODE == MODE_SUPERKMER) ? 3 : (W == -16 ? 5 : (W < 0 ? 4 : (W <= 11 ? 5 : 4))))))) void scan_count_kernel(const ScanParams pin, GroupRange g)
+// SY: the syncmer form (count_tile): 1 = closed syncmers (offsets {0, W - 1}; phase_sync_closed), 2 = argmins with the exact form deferred
+template <int MODE, int W, int U, int C, int SY = 0>
+__global__ __launch_bounds__(TPB, (SY == 1 ? BL_CS_WAVES : SY == 2 ? BL_SY2_WAVES : (MODE == MODE_SYNCMER && W > 0 ? BL_SY0_WAVES : MODE == MODE_SYNCMER || (MODE == MODE_SUPERKMER && W == -32) ? 2 : (W == -32 || (W < 0 && MODE == MODE_SUPERKMER) ? 3 : (W == -16 ? 5 : (W < 0 ? 4 : (W <= 11 ? 5 : 4))))))) void scan_count_kernel(const ScanParams pin, GroupRange g)
 {
     __shared__ TileShared<MODE, W> sh;
     ScanParams p = pin;
@@ -263,7 +278,7 @@ __global__ __launch_bounds__(TPB, (CS ? BL_CS_WAVES : (MODE == MODE_SYNCMER || (
         p.stride = NWAVE * (64 * S - 16 * ((W + 15) / 16));  // plan_scan's value, as a constant
     }
     if (C >= 0) p.canonical = C;
-    if (blockIdx.x < g.count) count_tile<MODE, W, CS, U>(p, sh, g.first + blockIdx.x, threadIdx.x);
+    if (blockIdx.x < g.count) count_tile<MODE, W, SY, U>(p, sh, g.first + blockIdx.x, threadIdx.x);
 }
 
 // The tiles a closed-syncmer pass 1 could not decide (p.redo_list), counted again in the exact argmin form: same outputs, written
@@ -559,10 +574,15 @@ static hipError_t launch_count_mode(const ScanParams& p, GroupRange g, hipStream
     if (MODE == MODE_SYNCMER && p.w == 21 && p.unit == 11 && p.canonical) {
         const bool closed = (p.soff == 0 && p.eoff == 20) || (p.soff == 20 && p.eoff == 0);
         static const bool no_cs = std::getenv("BL_NO_CLOSED") != nullptr;  // A/B runs: the argmin form
+        const unsigned redo_grid = g.count < 512u ? g.count : 512u;
         if (closed && !no_cs && p.redo_list && g.first == 0) {  // BASELINE C5
-            hipLaunchKernelGGL((scan_count_kernel<MODE_SYNCMER, 21, 11, 1, true>), grid, block, 0, stream, p, g);
-            const unsigned redo_grid = g.count < 512u ? g.count : 512u;
+            hipLaunchKernelGGL((scan_count_kernel<MODE_SYNCMER, 21, 11, 1, 1>), grid, block, 0, stream, p, g);
             hipLaunchKernelGGL((scan_redo_kernel<MODE_SYNCMER, 21, 11, 1>), dim3(redo_grid), block, 0, stream, p);
+#ifndef BL_NO_SY2
+        } else if (p.redo_list && g.first == 0) {  // any other pair of offsets: argmins, the exact form in the redo kernel
+            hipLaunchKernelGGL((scan_count_kernel<MODE_SYNCMER, 21, 11, 1, 2>), grid, block, 0, stream, p, g);
+            hipLaunchKernelGGL((scan_redo_kernel<MODE_SYNCMER, 21, 11, 1>), dim3(redo_grid), block, 0, stream, p);
+#endif
         } else {
             hipLaunchKernelGGL((scan_count_kernel<MODE, 21, 11, 1>), grid, block, 0, stream, p, g);
         }

@@ -230,6 +230,31 @@ BL_DEV uint64_t murmur64(uint64_t key, uint32_t seed)
     return h1 + h2;
 }
 
+// The same hash with the compiler's own lowering of the six multiplies (v_mad_u64_u32 + 2 x v_mul_lo_u32 + v_add3_u32).  For the
+// argmin form of the syncmer scan, which its 245 registers hold to two waves per SIMD: with so few waves to switch between, the
+// dependent v_mul_lo -> v_mad -> v_mov -> v_mad chain of mul64c is exposed, and that kernel ran 10 % SLOWER with it (252 -> 228).
+BL_DEV uint64_t fmix64_plain(uint64_t k)
+{
+    k ^= k >> 33;
+    k *= 0xff51afd7ed558ccdULL;
+    k ^= k >> 33;
+    k *= 0xc4ceb9fe1a85ec53ULL;
+    k ^= k >> 33;
+    return k;
+}
+BL_DEV uint64_t murmur64_plain(uint64_t key, uint32_t seed)
+{
+    uint64_t k1 = key * 0x87c37b91114253d5ULL;
+    k1 = rotl64_31(k1);
+    k1 *= 0x4cf5ad432745937fULL;
+    uint64_t h1 = (uint64_t)seed ^ k1;
+    uint64_t h2 = (uint64_t)seed;
+    h1 ^= 8; h2 ^= 8;
+    h1 += h2; h2 += h1;
+    h1 = fmix64_plain(h1); h2 = fmix64_plain(h2);
+    return h1 + h2;
+}
+
 // ------------------------------------------------------------------------------------------------
 // 16 ASCII bytes (4 little-endian dwords, first base in byte 0 of d[0]) ->
 //   code : 2 bits per base, FIRST base in the most significant pair (kmer_view.hpp:194 order)

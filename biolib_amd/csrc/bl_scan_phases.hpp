@@ -219,8 +219,8 @@ BL_DEV void phase_hash(const ScanParams& p, TileShared<MODE, W>& sh, int tid, Th
         for (int s = 0; s < S; ++s) {
             roller_step(r, s);
             roller_step(rk, s);
-            st.h[s] = murmur64(roller_fwd(r), p.seed);
-            st.h2[s] = murmur64(roller_rc(r), p.seed);
+            st.h[s] = murmur64_plain(roller_fwd(r), p.seed);  // (the compiler's multiply here: see murmur64_plain)
+            st.h2[s] = murmur64_plain(roller_rc(r), p.seed);
             if (p.canonical && roller_rc(rk) < roller_fwd(rk)) strand |= 1u << s;  // kmer_view.hpp:196
         }
         st.strand = strand;
@@ -336,8 +336,11 @@ __device__ unsigned long long bl_dbg_fallbacks;
 #endif
 // Window argmins of one lane: packed 32-bit keys first, the exact 64-bit form when a prefix tie was seen anywhere
 // in the wave among lanes that own windows.
-template <int NW, int W, bool LEFT, bool SECOND, bool RAW = false>
-BL_DEV void lane_window_argmin(const ThreadState* all, int tid, const ThreadState& st, bool owns, uint32_t* a)
+// DEFER: no exact form in here — a prefix tie in a lane that owns windows is reported through *tie, and the caller has the whole
+// tile decided again by a kernel that carries the exact form (the syncmer scan: without it, and without the hashes' low dwords it
+// would keep alive, the kernel fits three waves per SIMD instead of two).
+template <int NW, int W, bool LEFT, bool SECOND, bool RAW = false, bool DEFER = false>
+BL_DEV void lane_window_argmin(const ThreadState* all, int tid, const ThreadState& st, bool owns, uint32_t* a, bool* tie = nullptr)
 {
     uint32_t key[S + W];
     BL_UNROLL
@@ -355,6 +358,10 @@ BL_DEV void lane_window_argmin(const ThreadState* all, int tid, const ThreadStat
     }
 #endif
     const uint32_t dmin = window_argmin_packed<NW, W, LEFT, RAW && LEFT>(key, a);
+    if (DEFER) {
+        if (owns && dmin < 64u) *tie = true;
+        return;
+    }
     if (BL_COLD(wave_any(owns && dmin < 64u))) {
 #ifdef BL_EXPERIMENT_COUNT_FALLBACK
         if ((tid & 63) == 0) atomicAdd(&bl_dbg_fallbacks, 1ull);
@@ -661,23 +668,23 @@ BL_DEV uint32_t phase_window(const ScanParams& p, TileShared<MODE, W>& sh, int t
 }
 
 // Phase 3 (syncmer): leftmost minimum over the forward s-mer hashes, rightmost over the reverse ones.
-template <int MODE, int W>
+template <int MODE, int W, bool DEFER = false>
 BL_DEV void phase_sync_fwd(const ScanParams& p, TileShared<MODE, W>& sh, int tid, ThreadState& st, const ThreadState* all,
-                           uint32_t* af)
+                           uint32_t* af, bool* tie = nullptr)
 {
     if (W < 0 && p.w >= 2) {
         window_argmin_runtime<MODE, W, S, true, false, false>(p, sh, all, tid, st, p.w, af);
     } else if (W > 1) {
-        lane_window_argmin<S, (W > 1 ? W : 2), true, false>(all, tid, st, owned_mask(p, tid & 63) != 0, af);
+        lane_window_argmin<S, (W > 1 ? W : 2), true, false, false, DEFER>(all, tid, st, owned_mask(p, tid & 63) != 0, af, tie);
     } else if (W == 1) {
         BL_UNROLL
         for (int s = 0; s < S; ++s) af[s] = (uint32_t)s;
     }
 }
 
-template <int MODE, int W>
+template <int MODE, int W, bool DEFER = false>
 BL_DEV uint32_t phase_sync_rev(const ScanParams& p, TileShared<MODE, W>& sh, int tid, int64_t q0, ThreadState& st,
-                               const ThreadState* all, const uint32_t* af)
+                               const ThreadState* all, const uint32_t* af, bool* tie = nullptr)
 {
     const int wv = wave_index(tid), lane = tid & 63;
     const int w = W > 0 ? W : p.w;
@@ -687,7 +694,7 @@ BL_DEV uint32_t phase_sync_rev(const ScanParams& p, TileShared<MODE, W>& sh, int
         if (W < 0 && w >= 2) {
             window_argmin_runtime<MODE, W, S, false, true, false>(p, sh, all, tid, st, w, ar);
         } else if (W > 1) {
-            lane_window_argmin<S, (W > 1 ? W : 2), false, true>(all, tid, st, owned_mask(p, tid & 63) != 0, ar);
+            lane_window_argmin<S, (W > 1 ? W : 2), false, true, false, DEFER>(all, tid, st, owned_mask(p, tid & 63) != 0, ar, tie);
         } else if (W == 1) {
             BL_UNROLL
             for (int s = 0; s < S; ++s) ar[s] = (uint32_t)s;
@@ -736,8 +743,10 @@ BL_DEV uint32_t phase_sync_rev(const ScanParams& p, TileShared<MODE, W>& sh, int
 // Phase 2 of the closed-syncmer scan (compile-time s-mer length U <= 16): both s-mers of every position straight from the codes
 // and from their reverse complement — no rolling registers, and no k-mer register at all: which strand of the K-MER is canonical
 // is decided later from its first 16 bases on either strand (phase_sync_closed).
-template <int MODE, int W, int U>
-BL_DEV void phase_hash_closed(const ScanParams& p, TileShared<MODE, W>& sh, int tid, ThreadState& st)
+// BOTH (the argmin form with its exact part deferred, count_tile SY = 2): both strands' hashes whole, and the k-mers' strands here,
+// from the 16 leading bases of either strand; *tie is set where those are equal (the tile is then decided again, exactly).
+template <int MODE, int W, int U, bool BOTH = false>
+BL_DEV void phase_hash_closed(const ScanParams& p, TileShared<MODE, W>& sh, int tid, ThreadState& st, bool* tie = nullptr)
 {
     static_assert(U >= 1 && U <= 16, "s-mers of the closed-syncmer kernel fit one word");
     const int wv = wave_index(tid), lane = tid & 63;
@@ -753,12 +762,23 @@ BL_DEV void phase_hash_closed(const ScanParams& p, TileShared<MODE, W>& sh, int 
         st.h[s] = murmur64(fw, p.seed);
         if ((s & 3) == 3) BL_SCHED_FENCE();
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(BL_CPU_EMU)
-        (void)rv;  // the reverse-strand s-mers are hashed where their minima are taken (phase_sync_closed): one strand's dwords alive at a time
+        if (BOTH) st.h2[s] = murmur64(rv, p.seed);
+        else (void)rv;  // the reverse-strand s-mers are hashed where their minima are taken (phase_sync_closed): one strand's dwords alive at a time
 #else
         st.h2[s] = murmur64(rv, p.seed);
 #endif
     }
-    st.strand = 0;
+    uint32_t strand = 0;
+    if (BOTH && p.canonical) {  // reverse strand canonical <=> rc < fwd (kmer_view.hpp:196), read off the 16 leading bases of each
+        BL_UNROLL
+        for (int s = 0; s < S; ++s) {
+            const uint32_t f16 = bases_at(c0, c1, c2, s, 16);
+            const uint32_t r16 = bases_at(r0, r1, r2, 48 - (U + W - 1) - s, 16);
+            if (r16 < f16) strand |= 1u << s;
+            if (r16 == f16) *tie = true;
+        }
+    }
+    st.strand = strand;
 }
 
 // m[i] = min(key[i .. i+WW-1]) for i < NW, over key[0 .. NW+WW-2] (van Herk / Gil-Werman on values)
