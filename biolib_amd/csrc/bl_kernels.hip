@@ -132,7 +132,7 @@ __device__ __forceinline__ void count_tile(const ScanParams& p, TileShared<MODE,
     constexpr bool DIRECT = MODE == MODE_SYNCMER && SY != 0 && U >= 1 && U <= 16 && U + W - 1 >= 16 && U + W - 1 <= 32;  // phase_hash_closed applies
     bool tie = false;
     if (DIRECT) phase_hash_closed<MODE, W, (DIRECT ? U : 1), SY == 2>(p, sh, tid, st, &tie);
-    else phase_hash<MODE, W, (MODE != MODE_SYNCMER && U >= 1 && U <= 16 ? U : 0)>(p, sh, tid, st);
+    else phase_hash<MODE, W, (MODE != MODE_SYNCMER && U >= 1 && U <= 16 ? U : 0), U == 0>(p, sh, tid, st);
 
     uint32_t packed;
     if (MODE == MODE_SYNCMER && CS) {  // closed syncmers: sliding minima of the high dwords, no argmin
@@ -174,7 +174,7 @@ __device__ __forceinline__ void count_tile(const ScanParams& p, TileShared<MODE,
 }
 
 // Pass 1 of one tile in the read-tiled layout (fixed-length short reads, bl_scan_frl.hpp): same outputs as count_tile.
-template <int MODE, int W, int NS, int LIM_LAST>
+template <int MODE, int W, int NS, int LIM_LAST, bool GENERIC>
 __device__ __forceinline__ void count_tile_frl(const ScanParams& p, TileShared<MODE, W>& sh, uint32_t tile, int tid)
 {
     const int64_t q0 = tile_q0(p, tile);
@@ -186,7 +186,7 @@ __device__ __forceinline__ void count_tile_frl(const ScanParams& p, TileShared<M
     __syncthreads();
 
     ThreadState st;
-    phase_hash_frl<MODE, W, NS>(p, sh, tid, q0, tile, st);
+    phase_hash_frl<MODE, W, NS, GENERIC>(p, sh, tid, q0, tile, st);
     phase_window_frl_a<MODE, W, NS, LIM_LAST>(p, sh, tid, st, nullptr);
     const uint32_t packed = phase_window_frl_b<MODE, W, NS>(p, tid, st, nullptr);
 
@@ -323,7 +323,7 @@ __global__ __launch_bounds__(TPB, (W <= 11 ? 5 : 4)) void scan_count_frl_kernel(
     // compile-time geometry: every lane of a read owns NS windows but the last one (the launcher checks what this assumes)
     constexpr int LIM_LAST = L != 0 ? (L - U + 1 - W + 1) - ((L - U + 1 + S - 1) / S - 1) * NS : 0;
     static_assert(L == 0 || (LIM_LAST >= 1 && LIM_LAST <= NS), "read-tiled geometry: the last lane of a read must own 1..NS windows");
-    if (blockIdx.x < g.count) count_tile_frl<MODE, W, NS, LIM_LAST>(p, sh, g.first + blockIdx.x, threadIdx.x);
+    if (blockIdx.x < g.count) count_tile_frl<MODE, W, NS, LIM_LAST, U == 0>(p, sh, g.first + blockIdx.x, threadIdx.x);
 }
 
 template <int MODE>

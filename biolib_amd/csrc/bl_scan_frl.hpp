@@ -63,7 +63,8 @@ BL_DEV void phase_load_frl(const ScanParams& p, TileShared<MODE, W>& sh, int tid
 
 // ------------------------------------------------------------------------------------------------
 // Phase 2: which read and which units this lane owns; roll and hash them.
-template <int MODE, int W, int NS>
+// GENERIC: run-time unit length (see phase_hash: those kernels hash with the compiler's own multiply)
+template <int MODE, int W, int NS, bool GENERIC = false>
 BL_DEV void phase_hash_frl(const ScanParams& p, TileShared<MODE, W>& sh, int tid, int64_t q0, uint32_t tile, ThreadState& st)
 {
     const int wv = wave_index(tid), lane = tid & 63;
@@ -89,7 +90,7 @@ BL_DEV void phase_hash_frl(const ScanParams& p, TileShared<MODE, W>& sh, int tid
         roller_step(rr, s);
         const uint64_t fw = roller_fwd(rr), rv = roller_rc(rr);
         const uint64_t v = (p.canonical && rv < fw) ? rv : fw;  // minimizer_view.hpp:236-238
-        st.h[s] = murmur64(v, p.seed);
+        st.h[s] = GENERIC ? murmur64_plain(v, p.seed) : murmur64(v, p.seed);
     }
 }
 

@@ -201,7 +201,10 @@ BL_DEV uint32_t revcomp16(uint32_t c)
 // U: the unit length as a compile-time constant when it is one and fits a word (1..16; the BASELINE C4 kernel: 15-mers) — the
 // units then come straight from the codes and from their reverse complement (bases_at: one or two instructions each, the
 // canonical one by a single v_min_u32) instead of two rolling registers, a 64-bit compare and two selects.  0: rolling registers.
-template <int MODE, int W, int U = 0>
+// GENERIC: the kernel takes the unit length at run time (64-bit rolling registers with run-time shifts).  Those kernels hash with the
+// compiler's own multiply: the split one (mul64c) holds more register pairs alive, and compiled for five waves per SIMD they
+// spilled into the hashing loop with it (unit 15, w 10 on 150-bp reads: 381 -> 218 Gbp/s until this was noticed).
+template <int MODE, int W, int U = 0, bool GENERIC = false>
 BL_DEV void phase_hash(const ScanParams& p, TileShared<MODE, W>& sh, int tid, ThreadState& st)
 {
     const int wv = wave_index(tid), lane = tid & 63;
@@ -242,7 +245,7 @@ BL_DEV void phase_hash(const ScanParams& p, TileShared<MODE, W>& sh, int tid, Th
             roller_step(r, s);
             const uint64_t fw = roller_fwd(r), rv = roller_rc(r);
             const uint64_t v = (p.canonical && rv < fw) ? rv : fw;  // minimizer_view.hpp:236-238
-            st.h[s] = murmur64(v, p.seed);
+            st.h[s] = GENERIC ? murmur64_plain(v, p.seed) : murmur64(v, p.seed);
         }
     }
     (void)sh;  // the runtime-width kernels write hashes to LDS only in their exact branch (lane_window_argmin_generic)
@@ -519,7 +522,7 @@ BL_DEV void lane_window_argmin_generic(const ScanParams& p, TileShared<MODE, W>&
 #endif
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(BL_CPU_EMU)
         // minimizer scans dropped the full hashes after packing (they would pin 32 registers through the fast path)
-        if (MODE != MODE_SYNCMER) phase_hash<MODE, W>(p, sh, tid, st);
+        if (MODE != MODE_SYNCMER) phase_hash<MODE, W, 0, true>(p, sh, tid, st);
 #endif
         window_argmin_lds_exact<MODE, W, LEFT, SECOND, NW>(sh, all, tid, st, w, a);
     }
