@@ -466,7 +466,7 @@ def other_configs(ctx, args, model):
             k += 1
         return k
 
-    res["C5_syncmers_50Gbp_shard_10kbp_reads"] = timed(c5, n, ["c5_count", "c5_emit"], "bl::scan_count_kernel<MODE_SYNCMER,W=21,U=11,C=1,CS=true> (closed syncmers: sliding minima, no argmin)")
+    res["C5_syncmers_50Gbp_shard_10kbp_reads"] = timed(c5, n, ["c5_count", "c5_emit"], "bl::scan_count_kernel<MODE_SYNCMER,W=21,U=11,C=1,SY=1> (closed syncmers: sliding minima, no argmin)")
     b.close()
     res["note"] = ("parity of these configurations at these sizes: tests/test_gpu_edges.py (two cuttings agree, 256 Mbp against the oracle); "
                    "C5's 8-GPU RCCL leg needs hardware a 1-GPU box does not have (world-1 nccl reduce is tested)")

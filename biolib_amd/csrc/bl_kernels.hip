@@ -131,13 +131,18 @@ __device__ __forceinline__ void count_tile(const ScanParams& p, TileShared<MODE,
     ThreadState st;
     constexpr bool DIRECT = MODE == MODE_SYNCMER && SY != 0 && U >= 1 && U <= 16 && U + W - 1 >= 16 && U + W - 1 <= 32;  // phase_hash_closed applies
     bool tie = false;
-    if (DIRECT) phase_hash_closed<MODE, W, (DIRECT ? U : 1), SY == 2>(p, sh, tid, st, &tie);
+#ifdef BL_CLOSED_ON_HASHES  // A/B builds: the closed form on the hashes' own high dwords
+    constexpr bool AP = false;
+#else
+    constexpr bool AP = DIRECT && CS;  // ... on murmur64_top (phase_hash_closed)
+#endif
+    if (DIRECT) phase_hash_closed<MODE, W, (DIRECT ? U : 1), SY == 2, AP>(p, sh, tid, st, &tie);
     else phase_hash<MODE, W, (MODE != MODE_SYNCMER && U >= 1 && U <= 16 ? U : 0), U == 0>(p, sh, tid, st);
 
     uint32_t packed;
     if (MODE == MODE_SYNCMER && CS) {  // closed syncmers: sliding minima of the high dwords, no argmin
         bool undecided;
-        packed = phase_sync_closed<MODE, (W > 1 ? W : 2), (DIRECT ? U : 0)>(p, reinterpret_cast<TileShared<MODE, (W > 1 ? W : 2)>&>(sh), tid, q0, st, nullptr, undecided);
+        packed = phase_sync_closed<MODE, (W > 1 ? W : 2), (DIRECT ? U : 0), AP>(p, reinterpret_cast<TileShared<MODE, (W > 1 ? W : 2)>&>(sh), tid, q0, st, nullptr, undecided);
         // equal high dwords somewhere in the wave: the tile is listed and counted again, in the exact form, by scan_redo_kernel — a
         // kernel of its own, because that form needs twice the registers and, inlined here, pushes spills into this kernel's hot path
         if (BL_COLD(wave_any(undecided)) && (tid & 63) == 0) sh.redo = 1;
@@ -174,11 +179,14 @@ __device__ __forceinline__ void count_tile(const ScanParams& p, TileShared<MODE,
 }
 
 // Pass 1 of one tile in the read-tiled layout (fixed-length short reads, bl_scan_frl.hpp): same outputs as count_tile.
-template <int MODE, int W, int NS, int LIM_LAST, bool GENERIC>
+// APPROX: the windows are decided on murmur64_top (bl_scan_core.hpp), 7 instructions per hash cheaper than the hash; a tile in which
+// some lane could not tell two keys apart is listed for scan_redo_frl_kernel, which runs this function without the flag.
+template <int MODE, int W, int NS, int LIM_LAST, bool GENERIC, bool APPROX = false>
 __device__ __forceinline__ void count_tile_frl(const ScanParams& p, TileShared<MODE, W>& sh, uint32_t tile, int tid)
 {
     const int64_t q0 = tile_q0(p, tile);
     phase_load_frl<MODE, W>(p, sh, tid, q0);
+    if (APPROX && tid == 0) sh.redo = 0;
     {   // hand the packed codes to pass 2
         uint32_t* sc = p.slots_c + (size_t)tile * p.slot_chunks;
         for (int c = tid; c < p.slot_chunks; c += TPB) sc[c] = sh.codes[c];  // own LDS entries: no barrier needed
@@ -186,8 +194,10 @@ __device__ __forceinline__ void count_tile_frl(const ScanParams& p, TileShared<M
     __syncthreads();
 
     ThreadState st;
-    phase_hash_frl<MODE, W, NS, GENERIC>(p, sh, tid, q0, tile, st);
-    phase_window_frl_a<MODE, W, NS, LIM_LAST>(p, sh, tid, st, nullptr);
+    bool tie = false;
+    phase_hash_frl<MODE, W, NS, GENERIC, APPROX>(p, sh, tid, q0, tile, st);
+    phase_window_frl_a<MODE, W, NS, LIM_LAST, APPROX>(p, sh, tid, st, nullptr, &tie);
+    if (APPROX && BL_COLD(wave_any(tie)) && (tid & 63) == 0) sh.redo = 1;
     const uint32_t packed = phase_window_frl_b<MODE, W, NS>(p, tid, st, nullptr);
 
     uint32_t total;
@@ -196,6 +206,7 @@ __device__ __forceinline__ void count_tile_frl(const ScanParams& p, TileShared<M
     phase_list_frl<MODE, W, NS>(sh, st, excl & 0xffffu, excl >> 16);
     if (tid == 0) p.tile_counts[tile] = (unsigned long long)n_s | ((unsigned long long)n_e << 32);
     __syncthreads();  // lists complete
+    if (APPROX && tid == 0 && BL_COLD(sh.redo != 0)) p.redo_list[atomicAdd(p.redo_count, 1ull)] = tile;
     const size_t slot = (size_t)tile * p.stride;  // stride is a multiple of 4 entries: dword aligned
     spill_list(p.slots_a + slot, sh.list_a, n_s, tid);
     if (MODE == MODE_SUPERKMER) {
@@ -302,9 +313,8 @@ __global__ __launch_bounds__(TPB, 2) void scan_redo_kernel(const ScanParams pin)
 // Read-tiled pass 1.  L (read length) and U, C specialise the headline configuration as in scan_count_kernel; L fixes
 // the whole lane -> (read, unit) map at compile time (lanes per read, reads per wave, windows per read).
 template <int MODE, int W, int NS, int U, int L, int C>
-__global__ __launch_bounds__(TPB, (W <= 11 ? 5 : 4)) void scan_count_frl_kernel(const ScanParams pin, GroupRange g)
+__device__ __forceinline__ ScanParams frl_params(const ScanParams& pin)
 {
-    __shared__ TileShared<MODE, W> sh;
     ScanParams p = pin;
     p.w = W;
     p.ns = NS;
@@ -320,10 +330,35 @@ __global__ __launch_bounds__(TPB, (W <= 11 ? 5 : 4)) void scan_count_frl_kernel(
         p.stride = NWAVE * rpw * L;
         p.slot_chunks = (15 + NWAVE * rpw * L + 15) / 16 + 3;
     }
-    // compile-time geometry: every lane of a read owns NS windows but the last one (the launcher checks what this assumes)
-    constexpr int LIM_LAST = L != 0 ? (L - U + 1 - W + 1) - ((L - U + 1 + S - 1) / S - 1) * NS : 0;
+    return p;
+}
+// compile-time geometry: every lane of a read owns NS windows but the last one (the launcher checks what this assumes)
+template <int W, int NS, int U, int L>
+constexpr int frl_lim_last() { return L != 0 ? (L - U + 1 - W + 1) - ((L - U + 1 + S - 1) / S - 1) * NS : 0; }
+
+// APPROX: see count_tile_frl; the launcher follows such a launch with scan_redo_frl_kernel
+template <int MODE, int W, int NS, int U, int L, int C, bool APPROX = false>
+__global__ __launch_bounds__(TPB, (W <= 11 ? 5 : 4)) void scan_count_frl_kernel(const ScanParams pin, GroupRange g)
+{
+    __shared__ TileShared<MODE, W> sh;
+    const ScanParams p = frl_params<MODE, W, NS, U, L, C>(pin);
+    constexpr int LIM_LAST = frl_lim_last<W, NS, U, L>();
     static_assert(L == 0 || (LIM_LAST >= 1 && LIM_LAST <= NS), "read-tiled geometry: the last lane of a read must own 1..NS windows");
-    if (blockIdx.x < g.count) count_tile_frl<MODE, W, NS, LIM_LAST, U == 0>(p, sh, g.first + blockIdx.x, threadIdx.x);
+    if (blockIdx.x < g.count) count_tile_frl<MODE, W, NS, LIM_LAST, U == 0, APPROX>(p, sh, g.first + blockIdx.x, threadIdx.x);
+}
+
+// The tiles an APPROX pass 1 listed, counted again on the hashes themselves (same outputs, written over what pass 1 left for them);
+// between pass 1 and the prefix scan, like scan_redo_kernel.  Random reads list a tile in a few hundred.
+template <int MODE, int W, int NS, int U, int L, int C>
+__global__ __launch_bounds__(TPB, (W <= 11 ? 5 : 4)) void scan_redo_frl_kernel(const ScanParams pin)
+{
+    __shared__ TileShared<MODE, W> sh;
+    const ScanParams p = frl_params<MODE, W, NS, U, L, C>(pin);
+    const unsigned long long n = *p.redo_count;
+    for (unsigned long long i = blockIdx.x; i < n; i += gridDim.x) {
+        count_tile_frl<MODE, W, NS, frl_lim_last<W, NS, U, L>(), U == 0>(p, sh, p.redo_list[i], threadIdx.x);
+        __syncthreads();  // the lists in LDS have been spilled before the next tile overwrites them
+    }
 }
 
 template <int MODE>
@@ -538,7 +573,13 @@ static hipError_t launch_count_frl(int mode, const ScanParams& p, GroupRange g, 
 {
     const dim3 grid(g.count), block(TPB);
     if (mode == MODE_MINIMIZER && p.w == 11 && p.unit == 31 && p.canonical && p.read_len == 150 && p.ns == 15 && p.rpw == 8) {
-        hipLaunchKernelGGL((scan_count_frl_kernel<MODE_MINIMIZER, 11, 15, 31, 150, 1>), grid, block, 0, stream, p, g);  // BASELINE C3
+        static const bool exact = std::getenv("BL_NO_APPROX") != nullptr;  // A/B runs: windows decided on the hashes themselves
+        if (p.redo_list && g.first == 0 && !exact) {  // BASELINE C3
+            hipLaunchKernelGGL((scan_count_frl_kernel<MODE_MINIMIZER, 11, 15, 31, 150, 1, true>), grid, block, 0, stream, p, g);
+            hipLaunchKernelGGL((scan_redo_frl_kernel<MODE_MINIMIZER, 11, 15, 31, 150, 1>), dim3(g.count < 512u ? g.count : 512u), block, 0, stream, p);
+        } else {
+            hipLaunchKernelGGL((scan_count_frl_kernel<MODE_MINIMIZER, 11, 15, 31, 150, 1>), grid, block, 0, stream, p, g);
+        }
         return hipGetLastError();
     }
     if (p.ns != S) return hipErrorInvalidValue;  // the general kernels give every lane S unit starts
@@ -563,6 +604,8 @@ static hipError_t launch_count_mode(const ScanParams& p, GroupRange g, hipStream
 {
     const dim3 grid(g.count), block(TPB);
     // the BASELINE.json configurations, fully specialised
+    // (pass 1 on murmur64_top, as in the read-tiled headline kernel, was tried for these two: the minimizer kernel then needs 100
+    // registers where five waves per SIMD leave 96, and the super-k-mer scan ran no faster with it, 394 against 397 Gbp/s)
     if (MODE == MODE_MINIMIZER && p.w == 11 && p.unit == 31 && p.canonical) {
         hipLaunchKernelGGL((scan_count_kernel<MODE, 11, 31, 1>), grid, block, 0, stream, p, g);
         return hipGetLastError();

@@ -196,16 +196,26 @@ BL_DEV uint64_t rotl64_31(uint64_t x)
 // a * c mod 2^64 for a constant c.  Written so that gfx950 gets v_mul_lo_u32 + 2 x v_mad_u64_u32 + v_mov (the cross terms
 // ride in as the 64-bit addend of the multiply-adds): 15.0 issue cycles per wave against 16.5 for the compiler's own
 // lowering of `a * c` (v_mad_u64_u32 + 2 x v_mul_lo_u32 + v_add3_u32; tools/ubench_valu.hip prices both).
-BL_DEV uint64_t mul64c(uint64_t a, uint64_t c)
+template <bool SPELLED = false>
+BL_DEV uint64_t mul64c_as(uint64_t a, uint64_t c)
 {
     const uint32_t alo = (uint32_t)a, ahi = (uint32_t)(a >> 32);
     const uint32_t clo = (uint32_t)c, chi = (uint32_t)(c >> 32);
     uint32_t cross = alo * chi + ahi * clo;  // v_mul_lo_u32, then v_mad_u64_u32 with the first product as its addend
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(BL_CPU_EMU)
     asm("" : "+v"(cross));  // opaque: left visible, the optimizer folds the three products back into `a * c`
+    if (SPELLED) {
+        // the last multiply-add spelled out, for murmur64_top: written in C++, a caller that goes on with the two dwords separately
+        // gets a v_mul_lo_u32 of its own for the low one, beside the v_mad_u64_u32 that already holds it.  (Everywhere else the
+        // spelled form only adds register moves.)
+        uint64_t d, carry;
+        asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(d), "=s"(carry) : "v"(alo), "s"(clo), "v"((uint64_t)cross << 32));
+        return d;
+    }
 #endif
     return (uint64_t)alo * clo + ((uint64_t)cross << 32);
 }
+BL_DEV uint64_t mul64c(uint64_t a, uint64_t c) { return mul64c_as<false>(a, c); }
 
 BL_DEV uint64_t fmix64(uint64_t k)
 {
@@ -228,6 +238,66 @@ BL_DEV uint64_t murmur64(uint64_t key, uint32_t seed)
     h1 += h2; h2 += h1;
     h1 = fmix64(h1); h2 = fmix64(h2);
     return h1 + h2;
+}
+
+// NEARLY the high dword of murmur64(key, seed), for the window comparisons of pass 1: T = murmur64(...) >> 32 is S or S + 1
+// (mod 2^32), S the value returned here.  The hash is fmix64(h1) + fmix64(h2); its high dword is the sum of the two high
+// dwords plus the carry of the low ones, and the carry is what S leaves out — with it go the low halves of both final
+// multiplies, the two `k ^= k >> 33` that only touch those halves, and half of the 64-bit add: 8 instructions of 45.
+// What the callers make of it (window_argmin_packed<..., APPROX>): two keys whose 26-bit prefixes differ by 2 or more are
+// ordered like their hashes; anything closer counts as a tie and the tile is decided again with murmur64 itself, and so
+// is a tile that holds an S with all prefix bits set, the one place where S + 1 could wrap to the SMALLEST prefix.
+// a * b + c as v_mad_u64_u32 says it, for chains of which only the low dword is wanted in the end (the compiler, seeing that,
+// writes v_mul_lo_u32 + v_add per link): the high dword is carried along, never looked at.  mad_lo0: the first link, c = 0 (or 1).
+BL_DEV uint64_t mad_lo(uint32_t a, uint32_t b, uint64_t c)
+{
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(BL_CPU_EMU)
+    uint64_t d, carry;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(d), "=s"(carry) : "v"(a), "s"(b), "v"(c));
+    return d;
+#else
+    return (uint64_t)(uint32_t)(a * b + (uint32_t)c);
+#endif
+}
+template <bool PLUS_ONE = false>
+BL_DEV uint64_t mad_lo0(uint32_t a, uint32_t b)
+{
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(BL_CPU_EMU)
+    uint64_t d, carry;
+    if (PLUS_ONE) asm("v_mad_u64_u32 %0, %1, %2, %3, 1" : "=v"(d), "=s"(carry) : "v"(a), "s"(b));
+    else asm("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=v"(d), "=s"(carry) : "v"(a), "s"(b));
+    return d;
+#else
+    return (uint64_t)(uint32_t)(a * b + (PLUS_ONE ? 1u : 0u));
+#endif
+}
+// PLUS_ONE: S + 1 instead (the hash's high dword is then the value or one BELOW it, and the value that could wrap is 0): the 1 rides in
+// as the addend of the chain's first link.
+template <bool PLUS_ONE = false>
+BL_DEV uint32_t murmur64_top(uint64_t key, uint32_t seed)
+{
+    uint64_t k1 = mul64c(key, 0x87c37b91114253d5ULL);
+    k1 = rotl64_31(k1);
+    k1 = mul64c(k1, 0x4cf5ad432745937fULL);
+    uint64_t h1 = (uint64_t)seed ^ k1;
+    uint64_t h2 = (uint64_t)seed;
+    h1 ^= 8; h2 ^= 8;
+    h1 += h2; h2 += h1;
+    h1 ^= h1 >> 33;
+    h1 = mul64c_as<true>(h1, 0xff51afd7ed558ccdULL);
+    h1 ^= h1 >> 33;
+    h2 ^= h2 >> 33;
+    h2 = mul64c_as<true>(h2, 0xff51afd7ed558ccdULL);
+    h2 ^= h2 >> 33;
+    // high dwords of h1 * C and h2 * C, summed: the four cross products in one chain of multiply-adds, the two v_mul_hi on top
+    const uint32_t clo = 0x1a85ec53u, chi = 0xc4ceb9feu;
+    const uint32_t a1 = (uint32_t)h1, b1 = (uint32_t)(h1 >> 32), a2 = (uint32_t)h2, b2 = (uint32_t)(h2 >> 32);
+    const uint32_t cross = (uint32_t)mad_lo(b2, clo, mad_lo(a2, chi, mad_lo(b1, clo, mad_lo0<PLUS_ONE>(a1, chi))));
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(BL_CPU_EMU)
+    return __umulhi(a1, clo) + __umulhi(a2, clo) + cross;
+#else
+    return (uint32_t)(((uint64_t)a1 * clo) >> 32) + (uint32_t)(((uint64_t)a2 * clo) >> 32) + cross;
+#endif
 }
 
 // The same hash with the compiler's own lowering of the six multiplies (v_mad_u64_u32 + 2 x v_mul_lo_u32 + v_add3_u32).  For the
@@ -548,7 +618,30 @@ BL_DEV void window_argmin(const uint64_t* e, uint32_t* a)
 // (probability ~1e-6 per window on random hashes; certain on repeats, which is why the exact form stays).
 // Returns the minimum xor distance seen.  NW + W - 1 <= 64 elements.
 // RAW: leave the whole minimum key in a[] (position in its low 6 bits, hash bits above) for callers that mask anyway.
-template <int NW, int W, bool LEFT, bool RAW = false>
+// APPROX: the keys come from murmur64_top; the distance folded is |a - b| instead of a ^ b and the caller's bound is 128 (prefixes
+// that differ by less than 2) instead of 64 (equal prefixes).
+BL_DEV uint32_t abs_diff(uint32_t a, uint32_t b)
+{
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(BL_CPU_EMU)
+    uint32_t d;
+    asm("v_sad_u32 %0, %1, %2, 0" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+#else
+    return a < b ? b - a : a - b;
+#endif
+}
+BL_DEV uint32_t key_distance(uint32_t a, uint32_t b, bool approx)
+{
+    if (!approx) return a ^ b;
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(BL_CPU_EMU)
+    uint32_t d;
+    asm("v_sad_u32 %0, %1, %2, 0" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+#else
+    return a < b ? b - a : a - b;
+#endif
+}
+template <int NW, int W, bool LEFT, bool RAW = false, bool APPROX = false>
 BL_DEV uint32_t window_argmin_packed(const uint32_t* key, uint32_t* a)
 {
     uint32_t dmin = ~0u;
@@ -558,7 +651,7 @@ BL_DEV uint32_t window_argmin_packed(const uint32_t* key, uint32_t* a)
         sv[W - 1] = key[base + W - 1];
         BL_UNROLL
         for (int i = W - 2; i >= 0; --i) {
-            const uint32_t x = key[base + i], d = x ^ sv[i + 1];
+            const uint32_t x = key[base + i], d = key_distance(x, sv[i + 1], APPROX);
             sv[i] = x < sv[i + 1] ? x : sv[i + 1];
             dmin = d < dmin ? d : dmin;
         }
@@ -571,11 +664,11 @@ BL_DEV uint32_t window_argmin_packed(const uint32_t* key, uint32_t* a)
             if (i == 1) {
                 pv = x;
             } else {
-                const uint32_t d = x ^ pv;
+                const uint32_t d = key_distance(x, pv, APPROX);
                 pv = x < pv ? x : pv;
                 dmin = d < dmin ? d : dmin;
             }
-            const uint32_t d2 = pv ^ sv[i];
+            const uint32_t d2 = key_distance(pv, sv[i], APPROX);
             const uint32_t r = pv < sv[i] ? pv : sv[i];
             dmin = d2 < dmin ? d2 : dmin;
             a[base + i] = RAW ? r : (LEFT ? (r & 63u) : 63u - (r & 63u));

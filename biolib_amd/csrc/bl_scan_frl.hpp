@@ -64,7 +64,9 @@ BL_DEV void phase_load_frl(const ScanParams& p, TileShared<MODE, W>& sh, int tid
 // ------------------------------------------------------------------------------------------------
 // Phase 2: which read and which units this lane owns; roll and hash them.
 // GENERIC: run-time unit length (see phase_hash: those kernels hash with the compiler's own multiply)
-template <int MODE, int W, int NS, bool GENERIC = false>
+// APPROX: st.h[s] holds murmur64_top in its high dword (low dword 0) and st.hmax the largest of them: the window phase works on
+// those and reports what it cannot decide (lane_window_argmin_frl)
+template <int MODE, int W, int NS, bool GENERIC = false, bool APPROX = false>
 BL_DEV void phase_hash_frl(const ScanParams& p, TileShared<MODE, W>& sh, int tid, int64_t q0, uint32_t tile, ThreadState& st)
 {
     const int wv = wave_index(tid), lane = tid & 63;
@@ -85,13 +87,21 @@ BL_DEV void phase_hash_frl(const ScanParams& p, TileShared<MODE, W>& sh, int tid
     const uint32_t a2 = (uint32_t)(((((uint64_t)c2 << 32) | c3) << sh2) >> 32);
     Roller rr;
     roller_start(rr, a0, a1, a2, p.unit);
+    uint32_t hmax = 0;
     BL_UNROLL
     for (int s = 0; s < NS; ++s) {
         roller_step(rr, s);
         const uint64_t fw = roller_fwd(rr), rv = roller_rc(rr);
         const uint64_t v = (p.canonical && rv < fw) ? rv : fw;  // minimizer_view.hpp:236-238
-        st.h[s] = GENERIC ? murmur64_plain(v, p.seed) : murmur64(v, p.seed);
+        if (APPROX) {
+            const uint32_t top = murmur64_top(v, p.seed);
+            hmax = top > hmax ? top : hmax;
+            st.h[s] = (uint64_t)top << 32;
+        } else {
+            st.h[s] = GENERIC ? murmur64_plain(v, p.seed) : murmur64(v, p.seed);
+        }
     }
+    st.hmax = hmax;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -106,8 +116,10 @@ BL_DEV uint32_t dpp_prev32(uint32_t v) { return (uint32_t)__builtin_amdgcn_updat
 
 // Window argmins of a lane that owns NS elements: the W - 1 halo elements come from the following lanes, NS per hop.
 // a[i] = raw packed key (element index in its low 6 bits) or, after the exact branch, the plain element index.
-template <int NS, int W>
-BL_DEV void lane_window_argmin_frl(const ThreadState* all, int tid, const ThreadState& st, bool owns, uint32_t* a)
+// APPROX (keys from murmur64_top): no exact form in here; *tie is set when a lane that owns windows met two keys less than two
+// prefixes apart, or holds a key whose prefix could wrap, and the caller has the whole tile decided again (scan_redo_frl_kernel)
+template <int NS, int W, bool APPROX = false>
+BL_DEV void lane_window_argmin_frl(const ThreadState* all, int tid, const ThreadState& st, bool owns, uint32_t* a, bool* tie = nullptr)
 {
     constexpr int NE = W - 1, NK = NS + NE;  // NK <= 64: 6-bit tags
     uint32_t key[NK];
@@ -125,9 +137,9 @@ BL_DEV void lane_window_argmin_frl(const ThreadState* all, int tid, const Thread
             BL_UNROLL
             for (int x = 0; x < NS; ++x) {
                 // lane 63 owns windows too (64 = rpw * lpr lanes at work) but has no lane to take a halo from: it gets pad
-                // keys with pairwise different prefixes, so that its (non-existent) halo windows never look like a hash tie
+                // keys whose prefixes are pairwise two or more apart, so that its (non-existent) halo windows never look like a hash tie
                 if (hop * NS + x < NE || (hop + 1) * NS + x < NE || (hop + 2) * NS + x < NE)
-                    cur[x] = dpp_next32_or(cur[x], (0x03fffff0u - (uint32_t)(4 * x + hop)) << 6) + (uint32_t)NS;
+                    cur[x] = dpp_next32_or(cur[x], (0x03fffff0u - (uint32_t)(2 * (4 * x + hop))) << 6) + (uint32_t)NS;
                 if (hop * NS + x < NE) key[(hop + 1) * NS + x] = cur[x];
             }
         }
@@ -137,12 +149,17 @@ BL_DEV void lane_window_argmin_frl(const ThreadState* all, int tid, const Thread
         const int lane = tid & 63;
         for (int x = 0; x < NE; ++x) {
             const int nb = lane + 1 + x / NS;
-            const uint32_t hi = nb < 64 ? (uint32_t)(all[tid + 1 + x / NS].h[x % NS] >> 32) : 0xDEADBEEFu;
+            const uint32_t hi = nb < 64 ? (uint32_t)(all[tid + 1 + x / NS].h[x % NS] >> 32) : (0x03fffff0u - 2u * (uint32_t)x) << 6;  // pads, two prefixes apart
             key[NS + x] = packed_key(hi, NS + x, true);
         }
     }
 #endif
-    const uint32_t dmin = window_argmin_packed<NS, W, true, true>(key, a);
+    const uint32_t dmin = window_argmin_packed<NS, W, true, true, APPROX>(key, a);
+    if (APPROX) {
+        // (a lane's keys: its own NS elements and the W - 1 that follow; the lanes those belong to test their own hmax)
+        if (owns && (dmin < 128u || st.hmax >= 0xffffffc0u)) *tie = true;
+        return;
+    }
     if (BL_COLD(wave_any(owns && dmin < 64u))) {  // a prefix tie somewhere in the wave: the exact 64-bit form
         uint64_t e[NK];
         BL_UNROLL
@@ -204,11 +221,11 @@ constexpr bool frl_occ_form() { return MODE == MODE_MINIMIZER && W > 1 && W - 1 
 // Phase 3a: window argmins of the lane's NS windows and which of them exist.
 // LIM_LAST != 0 (the compile-time geometry of scan_count_frl_kernel): every lane of a read owns NS windows but the last,
 // which owns LIM_LAST (1..NS); 0: any geometry.
-template <int MODE, int W, int NS, int LIM_LAST = 0>
-BL_DEV void phase_window_frl_a(const ScanParams& p, TileShared<MODE, W>& sh, int tid, ThreadState& st, const ThreadState* all)
+template <int MODE, int W, int NS, int LIM_LAST = 0, bool APPROX = false>
+BL_DEV void phase_window_frl_a(const ScanParams& p, TileShared<MODE, W>& sh, int tid, ThreadState& st, const ThreadState* all, bool* tie = nullptr)
 {
     uint32_t a[S];
-    lane_window_argmin_frl<NS, (W > 1 ? W : 2)>(all, tid, st, st.jlane >= 0, a);
+    lane_window_argmin_frl<NS, (W > 1 ? W : 2), APPROX>(all, tid, st, st.jlane >= 0, a, tie);
     // windows of the read: window index j * NS + s must be below nwin; breaks only where the tile holds one
     uint32_t vmask = 0;
     if (st.jlane >= 0) {

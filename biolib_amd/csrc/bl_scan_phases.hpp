@@ -59,6 +59,8 @@ struct ThreadState {
     uint32_t a_first, a_last;  // argmin index of the lane's first / last window
     uint32_t vmask;       // bit s: window s exists and is valid
     uint32_t cw[3], rw[3];  // closed-syncmer scans: the lane's 48 bases as codes, and their reverse complement (first base of each in the top pair of word 0)
+    uint32_t hmax;        // scans on murmur64_top: the largest of the lane's own values
+    uint32_t hlow;        // closed-syncmer scans on murmur64_top<true>: the smallest of the lane's own forward values
     uint32_t occ;         // element-centric minimizer scans: bit e = element e (own or, from NS on, the next lane's) is the argmin of a valid window
 };
 
@@ -748,9 +750,14 @@ BL_DEV uint32_t phase_sync_rev(const ScanParams& p, TileShared<MODE, W>& sh, int
 // is decided later from its first 16 bases on either strand (phase_sync_closed).
 // BOTH (the argmin form with its exact part deferred, count_tile SY = 2): both strands' hashes whole, and the k-mers' strands here,
 // from the 16 leading bases of either strand; *tie is set where those are equal (the tile is then decided again, exactly).
-template <int MODE, int W, int U, bool BOTH = false>
+// AP (closed syncmers): murmur64_top<true> in place of the hashes' high dwords — the true dword is that value or one below it, so a
+// comparison of two of them stands when they are two or more apart (phase_sync_closed); st.hlow keeps the smallest, because a
+// value of 0 may stand for a true dword of 0xffffffff.
+template <int MODE, int W, int U, bool BOTH = false, bool AP = false>
 BL_DEV void phase_hash_closed(const ScanParams& p, TileShared<MODE, W>& sh, int tid, ThreadState& st, bool* tie = nullptr)
 {
+    static_assert(!(AP && BOTH), "the argmin form works on whole hashes");
+    uint32_t hlow = ~0u;
     static_assert(U >= 1 && U <= 16, "s-mers of the closed-syncmer kernel fit one word");
     const int wv = wave_index(tid), lane = tid & 63;
     const uint32_t* wcodes = sh.codes + wave_chunk0(p, wv);
@@ -762,15 +769,22 @@ BL_DEV void phase_hash_closed(const ScanParams& p, TileShared<MODE, W>& sh, int 
     for (int s = 0; s < S; ++s) {
         const uint32_t fw = bases_at(c0, c1, c2, s, U);            // bases s .. s+U-1
         const uint32_t rv = bases_at(r0, r1, r2, 48 - U - s, U);   // their reverse complement
-        st.h[s] = murmur64(fw, p.seed);
+        if (AP) {
+            const uint32_t top = murmur64_top<true>(fw, p.seed);
+            hlow = top < hlow ? top : hlow;
+            st.h[s] = (uint64_t)top << 32;
+        } else {
+            st.h[s] = murmur64(fw, p.seed);
+        }
         if ((s & 3) == 3) BL_SCHED_FENCE();
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(BL_CPU_EMU)
         if (BOTH) st.h2[s] = murmur64(rv, p.seed);
         else (void)rv;  // the reverse-strand s-mers are hashed where their minima are taken (phase_sync_closed): one strand's dwords alive at a time
 #else
-        st.h2[s] = murmur64(rv, p.seed);
+        st.h2[s] = AP ? (uint64_t)murmur64_top<true>(rv, p.seed) << 32 : murmur64(rv, p.seed);
 #endif
     }
+    st.hlow = hlow;
     uint32_t strand = 0;
     if (BOTH && p.canonical) {  // reverse strand canonical <=> rc < fwd (kmer_view.hpp:196), read off the 16 leading bases of each
         BL_UNROLL
@@ -838,9 +852,12 @@ BL_DEV void gather_halo_hi(const ThreadState* all, int tid, uint32_t* key)
 // Returns the number of syncmers the lane reports; `undecided` = true when one of the lane's comparisons met equal high dwords.
 // DIRECT: the hashes came from phase_hash_closed<U>; the k-mer's strand is then decided here, from the k-mer's first 16 bases on
 // the forward strand against its first 16 on the reverse strand (k = U + W - 1 >= 16; equal words: undecided, the exact form runs).
-template <int MODE, int W, int U = 0>
+// AP: the dwords are murmur64_top<true> values (phase_hash_closed); a comparison is undecided when its two sides are less than 2
+// apart, and so is the tile when any lane, owning k-mers or not, holds a value below 2.
+template <int MODE, int W, int U = 0, bool AP = false>
 BL_DEV uint32_t phase_sync_closed(const ScanParams& p, TileShared<MODE, W>& sh, int tid, int64_t q0, ThreadState& st, const ThreadState* all, bool& undecided)
 {
+    static_assert(!AP || U != 0, "approximate dwords: the direct form only");
     static_assert(W >= 2, "closed syncmers need at least two s-mers per k-mer");
     constexpr bool DIRECT = U != 0;
     static_assert(!DIRECT || (U + W - 1 >= 16 && U + W - 1 <= 32), "the strand test reads 16 bases from either end of the k-mer");
@@ -851,6 +868,9 @@ BL_DEV uint32_t phase_sync_closed(const ScanParams& p, TileShared<MODE, W>& sh, 
     // canonical one" — so that only one strand's arrays are alive at any moment (both at once do not fit the registers of four
     // waves per SIMD); the k-mers' strands then pick between the two 16-bit masks with three word operations.
     uint32_t closest = ~0u;  // smallest xor distance between the two sides of any comparison: 0 = some comparison met equal dwords
+                             // (AP: smallest absolute difference)
+    uint32_t same = ~0u;     // AP: the k-mers' strand tests, which stay exact, fold here
+    uint32_t low = AP ? st.hlow : ~0u;
     uint32_t hit_f = 0, hit_r = 0;
     {
         uint32_t key[S + NE], mn[S + 1];
@@ -862,7 +882,8 @@ BL_DEV uint32_t phase_sync_closed(const ScanParams& p, TileShared<MODE, W>& sh, 
         for (int s = 0; s < S; ++s) {  // forward strand canonical: minimum at offset 0 (leftmost wins a tie) or strictly at W - 1
             const uint32_t a1 = key[s], m1 = mn[s + 1], a2 = key[s + W - 1], m2 = mn[s];
             if (a1 <= m1 || a2 < m2) hit_f |= 1u << s;
-            fold_min3(closest, a1 ^ m1, a2 ^ m2);  // (opaque to the optimizer, which would turn the chain into a tree with every leaf alive)
+            if (AP) fold_min3(closest, abs_diff(a1, m1), abs_diff(a2, m2));
+            else fold_min3(closest, a1 ^ m1, a2 ^ m2);  // (opaque to the optimizer, which would turn the chain into a tree with every leaf alive)
         }
     }
     uint32_t hit = hit_f;
@@ -872,7 +893,8 @@ BL_DEV uint32_t phase_sync_closed(const ScanParams& p, TileShared<MODE, W>& sh, 
         if (DIRECT) {
             BL_UNROLL
             for (int s = 0; s < S; ++s) {
-                key[s] = (uint32_t)(murmur64(bases_at(st.rw[0], st.rw[1], st.rw[2], 48 - (DIRECT ? U : 1) - s, DIRECT ? U : 1), p.seed) >> 32);
+                const uint32_t rv = bases_at(st.rw[0], st.rw[1], st.rw[2], 48 - (DIRECT ? U : 1) - s, DIRECT ? U : 1);
+                key[s] = AP ? murmur64_top<true>(rv, p.seed) : (uint32_t)(murmur64(rv, p.seed) >> 32);
                 if ((s & 3) == 3) BL_SCHED_FENCE();
             }
         } else
@@ -881,13 +903,18 @@ BL_DEV uint32_t phase_sync_closed(const ScanParams& p, TileShared<MODE, W>& sh, 
             BL_UNROLL
             for (int s = 0; s < S; ++s) key[s] = (uint32_t)(st.h2[s] >> 32);
         }
+        if (AP) {
+            BL_UNROLL
+            for (int s = 0; s + 1 < S; s += 2) fold_min3(low, key[s], key[s + 1]);
+        }
         gather_halo_hi<NE, true>(all, tid, key);
         window_min<S + 1, WW>(key, mn);
         BL_UNROLL
         for (int s = 0; s < S; ++s) {  // reverse strand canonical: positions mirror, the rightmost wins a tie
             const uint32_t a3 = key[s + W - 1], m3 = mn[s], a4 = key[s], m4 = mn[s + 1];
             if (a3 <= m3 || a4 < m4) hit_r |= 1u << s;
-            fold_min3(closest, a3 ^ m3, a4 ^ m4);
+            if (AP) fold_min3(closest, abs_diff(a3, m3), abs_diff(a4, m4));
+            else fold_min3(closest, a3 ^ m3, a4 ^ m4);
         }
         uint32_t rev = st.strand;
         if (DIRECT) {  // reverse strand canonical <=> rc < fwd (kmer_view.hpp:196), read off the 16 leading bases of each
@@ -897,7 +924,7 @@ BL_DEV uint32_t phase_sync_closed(const ScanParams& p, TileShared<MODE, W>& sh, 
                 const uint32_t f16 = bases_at(st.cw[0], st.cw[1], st.cw[2], s, 16);
                 const uint32_t r16 = bases_at(st.rw[0], st.rw[1], st.rw[2], 48 - (U + W - 1) - s, 16);
                 if (r16 < f16) rev |= 1u << s;
-                fold_min(closest, f16 ^ r16);
+                fold_min(AP ? same : closest, f16 ^ r16);
             }
         }
         hit = (rev & hit_r) | (~rev & hit_f);
@@ -918,7 +945,7 @@ BL_DEV uint32_t phase_sync_closed(const ScanParams& p, TileShared<MODE, W>& sh, 
     }
     st.emit = emit;
     st.endm = 0;
-    undecided = closest == 0 && owned_mask(p, lane) != 0;
+    undecided = AP ? ((closest < 2u || same == 0u) && owned_mask(p, lane) != 0) || low < 2u : closest == 0 && owned_mask(p, lane) != 0;
     return (uint32_t)__builtin_popcount(emit);
 }
 

@@ -35,6 +35,7 @@ std::vector<uint32_t> make_start_bits(uint64_t n_bases, const uint64_t* offsets,
 }
 
 // pass 1 (scan_count_kernel) for every tile, the tile-count prefix scan, pass 2 (scan_emit_kernel)
+int g_closed_redone = 0;
 template <int MODE, int W, bool CS = false, int U = 0>
 void run_tiles(ScanParams p, unsigned long long* result)
 {
@@ -55,19 +56,24 @@ void run_tiles(ScanParams p, unsigned long long* result)
             for (int c = 0; c < staged_chunks(p); ++c) sc[tile * p.slot_chunks + c] = sh->codes[c];  // codes spill
             constexpr int CSU = (MODE == MODE_SYNCMER && CS) ? 11 : 0;  // the closed-syncmer kernel is instantiated for s = 11 (launch_count_mode)
             if (CSU) {
-                for (int tid = 0; tid < TPB; ++tid) phase_hash_closed<MODE, W, (CSU ? CSU : 1)>(p, *sh, tid, st[tid]);
+                for (int tid = 0; tid < TPB; ++tid) phase_hash_closed<MODE, W, (CSU ? CSU : 1), false, true>(p, *sh, tid, st[tid]);
             } else {
                 for (int tid = 0; tid < TPB; ++tid) phase_hash<MODE, W, (MODE != MODE_SYNCMER ? U : 0)>(p, *sh, tid, st[tid]);
             }
-            if (MODE == MODE_SYNCMER && CS) {  // closed syncmers: count_tile's order, the exact form where a lane is undecided
+            if (MODE == MODE_SYNCMER && CS) {  // closed syncmers on murmur64_top; a tile with an undecided lane again in the argmin form (scan_redo_kernel)
+                bool any = false;
                 for (int tid = 0; tid < TPB; ++tid) {
-                    bool undecided;  // (the phases read only the hashes of other lanes, which they do not change)
-                    packed[tid] = phase_sync_closed<MODE, (W > 1 ? W : 2), CSU>(p, reinterpret_cast<TileShared<MODE, (W > 1 ? W : 2)>&>(*sh), tid, q0, st[tid], st.data(), undecided);
-                    if (undecided) {  // the exact form, on the rolled hashes and the exact strand (count_tile hashes again too)
-                        phase_hash<MODE, W>(p, *sh, tid, st[tid]);  // (the same hashes: the neighbours' stay valid)
-                        phase_sync_fwd<MODE, W>(p, *sh, tid, st[tid], st.data(), &af[tid * (S + 1)]);
+                    bool undecided;
+                    packed[tid] = phase_sync_closed<MODE, (W > 1 ? W : 2), CSU, CSU != 0>(p, reinterpret_cast<TileShared<MODE, (W > 1 ? W : 2)>&>(*sh), tid, q0, st[tid], st.data(), undecided);
+                    any |= undecided;
+                }
+                if (any) {
+                    ++g_closed_redone;
+                    std::memset(st.data(), 0x5A, st.size() * sizeof(ThreadState));
+                    for (int tid = 0; tid < TPB; ++tid) phase_hash<MODE, W>(p, *sh, tid, st[tid]);
+                    for (int tid = 0; tid < TPB; ++tid) phase_sync_fwd<MODE, W>(p, *sh, tid, st[tid], st.data(), &af[tid * (S + 1)]);
+                    for (int tid = 0; tid < TPB; ++tid)
                         packed[tid] = phase_sync_rev<MODE, W>(p, *sh, tid, q0, st[tid], st.data(), &af[tid * (S + 1)]);
-                    }
                 }
             } else if (MODE == MODE_SYNCMER) {
                 for (int tid = 0; tid < TPB; ++tid) phase_sync_fwd<MODE, W>(p, *sh, tid, st[tid], st.data(), &af[tid * (S + 1)]);
@@ -127,7 +133,9 @@ void run_tiles(ScanParams p, unsigned long long* result)
 }
 
 // the read-tiled pass 1 (scan_count_frl_kernel), then the common prefix scan and pass 2
-template <int MODE, int W, int NS, int LIM_LAST = 0>
+// APPROX: pass 1 on murmur64_top, and a tile in which some lane reports a tie decided again on the hashes (scan_redo_frl_kernel)
+int g_frl_redone = 0, g_frl_tiles = 0;
+template <int MODE, int W, int NS, int LIM_LAST = 0, bool APPROX = false>
 void run_tiles_frl(ScanParams p, unsigned long long* result)
 {
     const size_t nt = (size_t)p.n_tiles;
@@ -144,8 +152,16 @@ void run_tiles_frl(ScanParams p, unsigned long long* result)
             const int64_t q0 = tile_q0(p, (uint32_t)tile);
             for (int tid = 0; tid < TPB; ++tid) phase_load_frl<MODE, W>(p, *sh, tid, q0);
             for (int c = 0; c < p.slot_chunks; ++c) sc[tile * p.slot_chunks + c] = sh->codes[c];
-            for (int tid = 0; tid < TPB; ++tid) phase_hash_frl<MODE, W, NS>(p, *sh, tid, q0, (uint32_t)tile, st[tid]);
-            for (int tid = 0; tid < TPB; ++tid) phase_window_frl_a<MODE, W, NS, LIM_LAST>(p, *sh, tid, st[tid], st.data());
+            bool tie = false;
+            for (int tid = 0; tid < TPB; ++tid) phase_hash_frl<MODE, W, NS, false, APPROX>(p, *sh, tid, q0, (uint32_t)tile, st[tid]);
+            for (int tid = 0; tid < TPB; ++tid) phase_window_frl_a<MODE, W, NS, LIM_LAST, APPROX>(p, *sh, tid, st[tid], st.data(), &tie);
+            ++g_frl_tiles;
+            if (APPROX && tie) {
+                ++g_frl_redone;
+                std::memset(st.data(), 0x5A, st.size() * sizeof(ThreadState));
+                for (int tid = 0; tid < TPB; ++tid) phase_hash_frl<MODE, W, NS>(p, *sh, tid, q0, (uint32_t)tile, st[tid]);
+                for (int tid = 0; tid < TPB; ++tid) phase_window_frl_a<MODE, W, NS, LIM_LAST>(p, *sh, tid, st[tid], st.data());
+            }
             for (int tid = 0; tid < TPB; ++tid) packed[tid] = phase_window_frl_b<MODE, W, NS>(p, tid, st[tid], st.data());
             uint32_t run = 0;
             for (int tid = 0; tid < TPB; ++tid) {
@@ -201,7 +217,7 @@ void run_tiles_frl(ScanParams p, unsigned long long* result)
 template <int MODE>
 void run_mode_frl(const ScanParams& p, unsigned long long* result)
 {
-    if (MODE == MODE_MINIMIZER && p.ns == 15) { run_tiles_frl<MODE_MINIMIZER, 11, 15, 5>(p, result); return; }  // the BASELINE C3 kernel
+    if (MODE == MODE_MINIMIZER && p.ns == 15) { run_tiles_frl<MODE_MINIMIZER, 11, 15, 5, true>(p, result); return; }  // the BASELINE C3 kernel
     if (MODE == MODE_MINIMIZER) {
         switch (p.w) {
             case 5: run_tiles_frl<MODE_MINIMIZER, 5, S>(p, result); return;
@@ -313,7 +329,20 @@ void emu_minimizers(const EmuBatch* b, uint64_t first, uint64_t n, unsigned unit
     run_mode<MODE_MINIMIZER>(p, result);
 }
 
+// murmur64_top against murmur64 for n keys: how many tops are neither T nor T - 1 (T = murmur64 >> 32; must be 0), how many are T - 1
+void emu_top_check(const uint64_t* keys, uint64_t n, uint32_t seed, uint64_t* bad, uint64_t* below)
+{
+    *bad = *below = 0;
+    for (uint64_t i = 0; i < n; ++i) {
+        const uint32_t t = (uint32_t)(murmur64(keys[i], seed) >> 32), s = murmur64_top(keys[i], seed);
+        if (t - s > 1u) ++*bad;
+        if (t - s == 1u) ++*below;
+    }
+}
 int emu_frl_scans() { return g_frl_scans; }
+int emu_frl_redone() { return g_frl_redone; }
+int emu_closed_redone() { return g_closed_redone; }
+int emu_frl_tiles() { return g_frl_tiles; }
 
 void emu_hash_sample(const EmuBatch* b, uint64_t first, uint64_t n, unsigned k, uint64_t seed, uint64_t threshold, unsigned flags,
                      uint64_t* out_value, uint64_t* out_pos, uint64_t* out_hash, uint64_t capacity, unsigned long long* result)

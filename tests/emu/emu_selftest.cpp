@@ -29,6 +29,9 @@ void emu_hash_sample(const EmuBatch* b, uint64_t first, uint64_t n, unsigned k, 
                      uint64_t* out_value, uint64_t* out_pos, uint64_t* out_hash, uint64_t capacity, unsigned long long* result);
 uint64_t emu_hash64(uint64_t v, uint64_t seed);
 int emu_frl_scans();
+int emu_frl_redone();
+int emu_closed_redone();
+int emu_frl_tiles();
 }
 
 static int g_fail = 0;
@@ -284,7 +287,7 @@ int main(int argc, char** argv)
         }
     }
     CHECK(emu_frl_scans() > 100, "the read-tiled path was hardly exercised: %d scans", emu_frl_scans());
-    std::printf("read-tiled scans run: %d\n", emu_frl_scans());
+    std::printf("read-tiled scans run: %d (tiles %d, of which decided again on the hashes: %d; tiles of closed-syncmer scans decided again: %d)\n", emu_frl_scans(), emu_frl_tiles(), emu_frl_redone(), emu_closed_redone());
     if (g_fail) {
         std::printf("emu_selftest: %d mismatches\n", g_fail);
         return 1;

@@ -36,6 +36,20 @@ def test_sanitizer_selftest(emu):
     assert "emu_selftest: OK" in out.stdout
 
 
+def test_top_dword_used_by_pass_one_is_the_hash_or_one_below(emu):
+    """murmur64_top (bl_scan_core.hpp) leaves out the carry of the two low dwords: T - S is 0 or 1, for every key and seed; the
+    window code of the approximate pass 1 relies on exactly that (ties: keys less than two prefixes apart)"""
+    rng = np.random.default_rng(5)
+    emu.emu_top_check.argtypes = [C.c_void_p, C.c_uint64, C.c_uint, C.c_void_p, C.c_void_p]
+    for seed in (0, 42, 0xffffffff, 7):
+        keys = rng.integers(0, 2**64, 400_000, dtype=np.uint64)
+        keys[:4] = (0, 1, 2**64 - 1, 2**62 - 1)
+        bad, below = C.c_uint64(), C.c_uint64()
+        emu.emu_top_check(O._ptr(keys), len(keys), seed, C.byref(bad), C.byref(below))
+        assert bad.value == 0
+        assert 0.4 < below.value / len(keys) < 0.6  # the carry is a coin toss
+
+
 def _batch(emu, seq, offs=None, read_len=0):
     seq = O.as_bytes(seq)
     if offs is not None:

@@ -40,8 +40,8 @@ for lanes in ("lanes2", "lanes1"):
 kernels = {
     "c3_count": "scan_count_frl_kernel<0, 11, 15, 31, 150, 1>", "c3_emit": "scan_emit_kernel<0>",
     "c2_kmer": "kmer_kernel",
-    "c4_count": "scan_count_kernel<1, 17, 15, 1, false>", "c4_emit": "scan_emit_kernel<1>",
-    "c5_count": "scan_count_kernel<2, 21, 11, 1, true>", "c5_emit": "scan_emit_kernel<2>",
+    "c4_count": "scan_count_kernel<1, 17, 15, 1, 0>", "c4_emit": "scan_emit_kernel<1>",
+    "c5_count": "scan_count_kernel<2, 21, 11, 1, 1>", "c5_emit": "scan_emit_kernel<2>",
 }
 means = {k: {} for k in kernels}
 for d in ("pmc_fetch", "pmc_write", "pmc_sq1", "pmc_sq2", "pmc_sq3"):
