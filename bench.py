@@ -277,7 +277,7 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5),
                 "traffic": traffic, "traffic_stale": traffic_stale, "traffic_source": traffic_note,
-                "kernel": "bl::scan_count_frl_kernel<MODE_MINIMIZER,W=11,NS=15,U=31,L=150,C=1> (pass 1 of 2, read-tiled)", "avg_kernel_ms": round(avg_kernel_s * 1e3, 4),
+                "kernel": "bl::scan_count_frl_kernel<MODE_MINIMIZER,W=11,NS=15,U=31,L=150,C=1,APPROX> (pass 1 of 2, read-tiled, windows decided on murmur64_top)", "avg_kernel_ms": round(avg_kernel_s * 1e3, 4),
                 "launches_timed": launches, "algorithmic_bytes_per_launch": int(bases_per_launch),
                 "note": "VALU-issue bound before HBM: 6 x 64-bit multiplies per 31-mer (MurmurHash3_x64_128), see roofline.valu and DESIGN.md"
                         + ("; with 2 lanes this kernel's duration includes sharing the SIMDs with the previous range's scan_emit_kernel (alone: --lanes 1)"

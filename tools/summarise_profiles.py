@@ -25,7 +25,7 @@ for cfg, key in (("c2", "C2_kmer_hash_10Gbp"), ("c4", "C4_super_kmers_50Gbp_10kb
     oc = bj["other_configs"][key]
     per_launch[cfg] = oc["bases"] * oc["steps"] / oc["launches_timed"]
 BASES_OF = {"c3_count": per_launch["c3"], "c3_emit": per_launch["c3"], "c2_kmer": per_launch["c2"], "c4_count": per_launch["c4"], "c4_emit": per_launch["c4"],
-            "c5_count": per_launch["c5"], "c5_emit": per_launch["c5"]}
+            "c5_count": per_launch["c5"], "c5_emit": per_launch["c5"], "c3_redo": per_launch["c3"], "c5_redo": per_launch["c5"]}
 
 shutil.copy(os.path.join(src, "stats_lanes2", "s_kernel_stats.csv"), os.path.join(dst, f"{RND}_kernel_stats.csv"))
 shutil.copy(os.path.join(src, "stats_lanes1", "s_kernel_stats.csv"), os.path.join(dst, f"{RND}_kernel_stats_lanes1.csv"))
@@ -38,10 +38,11 @@ for lanes in ("lanes2", "lanes1"):
 
 # kernel key -> substring of the kernel name rocprofv3 reports
 kernels = {
-    "c3_count": "scan_count_frl_kernel<0, 11, 15, 31, 150, 1>", "c3_emit": "scan_emit_kernel<0>",
+    "c3_count": "scan_count_frl_kernel<0, 11, 15, 31, 150, 1, true>", "c3_emit": "scan_emit_kernel<0>",
     "c2_kmer": "kmer_kernel",
     "c4_count": "scan_count_kernel<1, 17, 15, 1, 0>", "c4_emit": "scan_emit_kernel<1>",
     "c5_count": "scan_count_kernel<2, 21, 11, 1, 1>", "c5_emit": "scan_emit_kernel<2>",
+    "c3_redo": "scan_redo_frl_kernel<0, 11, 15, 31, 150, 1>", "c5_redo": "scan_redo_kernel<2, 21, 11, 1>",  # the tiles pass 1 could not decide, again
 }
 means = {k: {} for k in kernels}
 for d in ("pmc_fetch", "pmc_write", "pmc_sq1", "pmc_sq2", "pmc_sq3"):

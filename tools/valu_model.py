@@ -46,7 +46,7 @@ with tempfile.TemporaryDirectory() as tmp:
     asm = os.path.join(tmp, "k.s")
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-DBL_CENSUS_HOT", "-S", "--cuda-device-only",
                            os.path.join(ROOT, "biolib_amd", "csrc", "bl_kernels.hip"), "-o", asm], stderr=subprocess.DEVNULL)
-    mangled = {"c3_count": r"scan_count_frl_kernelILi0ELi11ELi15ELi31ELi150ELi1E", "c3_emit": r"scan_emit_kernelILi0E", "c2_kmer": r"kmer_kernel",
+    mangled = {"c3_count": r"scan_count_frl_kernelILi0ELi11ELi15ELi31ELi150ELi1ELb1E", "c3_emit": r"scan_emit_kernelILi0E", "c2_kmer": r"kmer_kernel",
                "c4_count": r"scan_count_kernelILi1ELi17ELi15ELi1ELi0E", "c4_emit": r"scan_emit_kernelILi1E", "c5_count": r"scan_count_kernelILi2ELi21ELi11ELi1ELi1E",
                "c5_emit": r"scan_emit_kernelILi2E"}
     out = {"provenance": {"pmc": pmc["provenance"], "ubench": f"profiles/{RND}_ubench_valu.json (same collection run)", "census": "hipcc -DBL_CENSUS_HOT -S of biolib_amd/csrc/bl_kernels.hip, tools/isa_census.py",
