@@ -274,6 +274,8 @@ def main():
             },
             "records_per_step": total_count,
             "xor_hash": xor_hash,
+            "tiles_decided_again_per_step": {"tiles": int(sum(int(r.redone) for r in step_res)), "of": int(-(-n_bases // 4800)),
+                                             "note": "rank 0: tiles of 32 reads in which pass 1, which looks at an approximation of the hash's high dword, met keys too close to order; counted a second time on the hashes (scan_redo_frl_kernel, inside the timed region)"},
             "roofline": {
                 "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5),
                 "traffic": traffic, "traffic_stale": traffic_stale, "traffic_source": traffic_note,

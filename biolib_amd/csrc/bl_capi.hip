@@ -97,6 +97,7 @@ struct bl_ctx {
     std::deque<Pending> pending;           // oldest first; at most RING entries
     bool timed = false;
     // optional per-launch timing of the main scan kernel alone (bl_ctx_kernel_timing)
+    bool exact_windows = false;  // bl_ctx_set_exact_windows
     bool ktiming = false;
     std::vector<hipEvent_t> ev_pool;                       // free events
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_open;  // recorded, not yet read
@@ -171,6 +172,7 @@ void deliver(bl_ctx* c, const Pending& p)
     out.xor_hash = r[2];
     out.xor_pos = r[3];
     out.aux = r[4];
+    out.redone = (int32_t)(r[5] > 0x7fffffffull ? 0x7fffffffull : r[5]);
     out.status = BL_OK;
     if (p.has_capacity && r[0] > p.capacity) out.status = BL_ERR_CAPACITY;
     if (p.user) *p.user = out;
@@ -241,7 +243,7 @@ int end_scan(bl_ctx* c, uint32_t add_mask, bl_result* user, bool has_capacity, u
              bool already_folded = false)
 {
     if (!already_folded) {
-        hipError_t e = bl::launch_reduce_shards(c->shards(), c->result(), add_mask, c->stream);
+        hipError_t e = bl::launch_reduce_shards(c->shards(), c->result(), add_mask, reinterpret_cast<unsigned long long*>(c->cur->ws) + 1, c->stream);
         if (e != hipSuccess) return fail(BL_ERR_HIP, std::string("reduce_shards: ") + hipGetErrorString(e));
     }
     if ((int)c->pending.size() >= RING) {
@@ -548,6 +550,13 @@ int bl_ctx_last_scan_ms(bl_ctx* c, float* ms)
     if (!c->timed) return fail(BL_ERR_INVALID, "no scan has been issued on this context");
     BL_HIP(hipEventSynchronize(c->cur->ev_stop));
     BL_HIP(hipEventElapsedTime(ms, c->cur->ev_start, c->cur->ev_stop));
+    return BL_OK;
+}
+
+int bl_ctx_set_exact_windows(bl_ctx* c, int on)
+{
+    if (!c) return fail(BL_ERR_INVALID, "ctx is NULL");
+    c->exact_windows = on != 0;
     return BL_OK;
 }
 
@@ -860,6 +869,7 @@ static int scan_windows(int mode, bl_ctx* c, const bl_batch* b, uint64_t first, 
     p.bases = b->bases;
     p.n_bases = (int64_t)b->n_bases;
     p.pos_base = (int64_t)b->origin;
+    p.exact_windows = c->exact_windows ? 1 : 0;
     bl::plan_scan(mode, (int64_t)first, (int64_t)end, (int)w, p);
     // fixed-length short reads, range aligned to reads: the read-tiled layout (no start bits, no hashing of positions
     // that cannot start a unit) when it pays; BL_NO_FRL=1 keeps the position-tiled kernels (A/B measurements)

@@ -498,11 +498,13 @@ __global__ __launch_bounds__(TPB) void kmer_kernel(const KmerParams p)
 // small helper kernels
 
 // fold the NSHARD digest lines into result[0..7]; slots listed in add_mask are sums, the others XORs
-__global__ void reduce_shards_kernel(const unsigned long long* shards, unsigned long long* result, uint32_t add_mask)
+__global__ void reduce_shards_kernel(const unsigned long long* shards, unsigned long long* result, uint32_t add_mask, const unsigned long long* redone)
 {
     const int slot = threadIdx.x;
     if (slot == 8) result[8] = 0;
+    if (slot == 9) result[5] = *redone;  // tiles pass 1 listed for a second run (no digest uses slot 5; written after the fold below by another lane: disjoint words)
     if (slot >= 8) return;
+    if (slot == 5) return;
     unsigned long long acc = 0;
     for (int i = 0; i < NSHARD; ++i) {
         const unsigned long long v = shards[8 * i + slot];
@@ -574,7 +576,7 @@ static hipError_t launch_count_frl(int mode, const ScanParams& p, GroupRange g, 
     const dim3 grid(g.count), block(TPB);
     if (mode == MODE_MINIMIZER && p.w == 11 && p.unit == 31 && p.canonical && p.read_len == 150 && p.ns == 15 && p.rpw == 8) {
         static const bool exact = std::getenv("BL_NO_APPROX") != nullptr;  // A/B runs: windows decided on the hashes themselves
-        if (p.redo_list && g.first == 0 && !exact) {  // BASELINE C3
+        if (p.redo_list && g.first == 0 && !exact && !p.exact_windows) {  // BASELINE C3
             hipLaunchKernelGGL((scan_count_frl_kernel<MODE_MINIMIZER, 11, 15, 31, 150, 1, true>), grid, block, 0, stream, p, g);
             hipLaunchKernelGGL((scan_redo_frl_kernel<MODE_MINIMIZER, 11, 15, 31, 150, 1>), dim3(g.count < 512u ? g.count : 512u), block, 0, stream, p);
         } else {
@@ -618,7 +620,7 @@ static hipError_t launch_count_mode(const ScanParams& p, GroupRange g, hipStream
         const bool closed = (p.soff == 0 && p.eoff == 20) || (p.soff == 20 && p.eoff == 0);
         static const bool no_cs = std::getenv("BL_NO_CLOSED") != nullptr;  // A/B runs: the argmin form
         const unsigned redo_grid = g.count < 512u ? g.count : 512u;
-        if (closed && !no_cs && p.redo_list && g.first == 0) {  // BASELINE C5
+        if (closed && !no_cs && !p.exact_windows && p.redo_list && g.first == 0) {  // BASELINE C5
             hipLaunchKernelGGL((scan_count_kernel<MODE_SYNCMER, 21, 11, 1, 1>), grid, block, 0, stream, p, g);
             hipLaunchKernelGGL((scan_redo_kernel<MODE_SYNCMER, 21, 11, 1>), dim3(redo_grid), block, 0, stream, p);
 #ifndef BL_NO_SY2
@@ -712,9 +714,9 @@ hipError_t launch_kmers(const KmerParams& p, int n_blocks, hipStream_t stream)
     return hipGetLastError();
 }
 
-hipError_t launch_reduce_shards(const unsigned long long* shards, unsigned long long* result, uint32_t add_mask, hipStream_t stream)
+hipError_t launch_reduce_shards(const unsigned long long* shards, unsigned long long* result, uint32_t add_mask, const unsigned long long* redone, hipStream_t stream)
 {
-    hipLaunchKernelGGL(reduce_shards_kernel, dim3(1), dim3(64), 0, stream, shards, result, add_mask);
+    hipLaunchKernelGGL(reduce_shards_kernel, dim3(1), dim3(64), 0, stream, shards, result, add_mask, redone);
     return hipGetLastError();
 }
 

@@ -96,6 +96,7 @@ struct ScanParams {
     unsigned long long* shards;       // [NSHARD][8] digest accumulators
     // closed-syncmer scans: tiles in which a comparison met equal high dwords are listed here by pass 1 and counted again, in the
     // exact argmin form, by scan_redo_kernel before the prefix scan (nullptr: never happens for other scans)
+    int32_t exact_windows;            // bl_ctx_set_exact_windows: no pass 1 on murmur64_top, no closed-syncmer form (checks and A/B runs)
     uint32_t* redo_list;              // [n_tiles]
     unsigned long long* redo_count;
     // Read-tiled layout (bl_scan_frl.hpp): batches of FIXED-LENGTH short reads, range aligned to reads.  A wave takes

@@ -85,6 +85,11 @@ class Context:
         check(self._lib.bl_ctx_last_scan_ms(self._h, C.byref(ms)))
         return float(ms.value)
 
+    def set_exact_windows(self, on=True):
+        """Later scans decide their windows on the 64-bit hashes themselves (bl_ctx_set_exact_windows): same records, for checks and A/B runs.
+        Result.redone counts the tiles a default scan had to decide a second time."""
+        check(self._lib.bl_ctx_set_exact_windows(self._h, 1 if on else 0))
+
     def kernel_timing(self, enable=True):
         check(self._lib.bl_ctx_kernel_timing(self._h, 1 if enable else 0))
 

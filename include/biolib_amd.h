@@ -70,7 +70,9 @@ typedef struct bl_result {
     uint64_t xor_pos;    /* XOR of their global positions (k-mer scan: wrapping SUM of hashes instead) */
     uint64_t aux;        /* super-k-mers: number of group ends seen (== count when consistent) */
     int32_t status;      /* BL_OK or BL_ERR_CAPACITY */
-    int32_t reserved;
+    int32_t redone;      /* diagnostic: tiles whose pass 1 could not decide a window on what it looks at (an approximation of the hash's
+                          * high dword, or high dwords alone) and were counted a second time on the hashes themselves; the records are the
+                          * same either way */
 } bl_result;
 
 const char* bl_last_error(void);
@@ -171,6 +173,10 @@ int bl_scan_super_kmers(bl_ctx* ctx, const bl_batch* batch, uint64_t first, uint
 int bl_scan_syncmers(bl_ctx* ctx, const bl_batch* batch, uint64_t first, uint64_t n, uint32_t k, uint32_t s, uint32_t start_offset,
                      uint32_t end_offset, uint64_t seed, uint32_t flags, uint64_t* d_positions, uint64_t capacity,
                      bl_result* result);
+
+/* on != 0: every later scan on this context decides its windows on the 64-bit hashes themselves — no pass 1 on the approximate high
+ * dword, no closed-syncmer form (§5.4).  Same records, 2-4 % slower; for checks and A/B measurements. */
+int bl_ctx_set_exact_windows(bl_ctx* ctx, int on);
 
 /* Elapsed GPU time of the most recent scan call on this context, from HIP events recorded on the
  * context's stream around its kernels (milliseconds).  Synchronises. */

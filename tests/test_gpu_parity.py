@@ -363,6 +363,52 @@ def test_read_tiled_scan_on_tiles_of_repeats(ctx):
 
 
 @pytest.mark.gpu
+def test_windows_decided_on_the_approximate_dword_give_the_records_of_the_hashes(ctx):
+    """C3's pass 1 and C5's closed form look at murmur64_top (the hash's high dword without the carry of the low ones, DESIGN.md
+    §5.1b) and have the tiles they cannot decide counted again on the hashes.  Against the same scans with
+    bl_ctx_set_exact_windows: the same records, array for array, on 0.6 Gbp of random reads (where about one tile in a thousand
+    is decided again: Result.redone says how many, and must not be 0 or the second path went untested) and on reads of repeats
+    (where every tile is)."""
+    import biolib_amd as B
+
+    n = 600_000_000
+    cap = n // 6
+    flags = B.FLAG_CANONICAL | B.FLAG_SYNC
+    for kind in ("minimizers", "closed_syncmers"):
+        b = ctx.synth(31 if kind == "minimizers" else 32, n, 150 if kind == "minimizers" else 10_000)
+        out = {}
+        for exact in (False, True):
+            ctx.set_exact_windows(exact)
+            v, p, h = ctx.empty_u64(cap), ctx.empty_u64(cap), ctx.empty_u64(cap)
+            if kind == "minimizers":
+                r = b.minimizers_raw(31, 11, 42, flags, values=v, positions=p, hashes=h, capacity=cap)
+            else:
+                r = b.syncmers_raw(31, 11, 0, 20, 0, flags, positions=p, capacity=cap)
+            cnt = int(r.count)
+            out[exact] = (r.as_dict(), int(r.redone), p[:cnt].clone(), (v[:cnt].clone(), h[:cnt].clone()) if kind == "minimizers" else None)
+        ctx.set_exact_windows(False)
+        b.close()
+        assert out[False][0] == out[True][0], kind
+        assert bool((out[False][2] == out[True][2]).all()), kind
+        if kind == "minimizers":
+            assert bool((out[False][3][0] == out[True][3][0]).all()) and bool((out[False][3][1] == out[True][3][1]).all())
+            assert out[True][1] == 0  # the hashes themselves leave nothing undecided in this kernel (its exact form is inline)
+        n_tiles = n // (4800 if kind == "minimizers" else 3700)
+        assert 0 < out[False][1] < n_tiles // 50, (kind, out[False][1], n_tiles)  # a few tiles in a thousand
+    # reads of repeats: every window ties
+    L, n_reads = 150, 32 * 40
+    seq = np.resize(np.frombuffer(b"ACGTTACA", np.uint8), L * n_reads).copy()
+    b = ctx.upload(seq, O.fixed_offsets(L * n_reads, L))
+    v, p, h = O.minimizers(seq, O.fixed_offsets(L * n_reads, L), 31, 11, 42, True, brute=False)
+    for exact in (False, True):
+        ctx.set_exact_windows(exact)
+        got = b.minimizers(31, 11, seed=42, canonical=True)
+        assert got["count"] == len(v) and np.array_equal(got["positions"], p) and np.array_equal(got["hashes"], h) and np.array_equal(got["values"], v)
+    ctx.set_exact_windows(False)
+    b.close()
+
+
+@pytest.mark.gpu
 def test_baseline_kernels_on_random_layouts_and_cuts(ctx):
     """the specialised kernels of the BASELINE configurations (C3 read-tiled and position-tiled, C4, C5 closed syncmers with its
     redo kernel) and the minimap2 widths on random sizes, layouts (one sequence, 150-bp / 10-kbp / ragged reads), breaks and
