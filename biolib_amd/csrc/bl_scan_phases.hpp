@@ -1160,7 +1160,9 @@ BL_DEV void kmer_thread(const KmerParams& p, const uint32_t* codes, const uint32
             continue;
         }
         const bool take = (ok >> s) & 1;
-        const uint64_t vm = take ? v : 0, hm = take ? h : 0;
+        const uint32_t m32 = 0u - ((ok >> s) & 1u);  // all ones / zero: and-masks (and, folded into the xors, v_bitop3) instead of selects
+        const uint64_t m = ((uint64_t)m32 << 32) | m32;
+        const uint64_t vm = v & m, hm = h & m;
         acc.xv ^= vm;
         acc.xh ^= hm;
         acc.sh += hm;
