@@ -820,6 +820,38 @@ BL_DEV void window_min(const uint32_t* key, uint32_t* m)
     }
 }
 
+// One strand's verdicts on the lane's 16 k-mers from its dwords key[0 .. S+W-2]: bit s = the smaller of k-mer s's two END s-mers
+// lies below every s-mer between them.  That is the whole closed-syncmer test on either strand: with e = min(first, last) and
+// mid = min(the W - 2 between), e < mid makes one end the minimum — the first if it is not above the last (leftmost wins, offset
+// 0), else the last, strictly (offset W - 1); mirrored on the reverse strand — and e > mid makes neither.  e against mid is also the
+// ONLY comparison that can be too close to call (two ends that tie below mid are a hit whichever way the tie goes): its
+// distance folds into `closest` (xor: 0 = equal dwords; AP: absolute difference, < 2 = undecided).  Per k-mer and strand: one
+// v_min_u32, one compare whose bit shifts in through an add-with-carry, one distance, half a v_min3_u32 — the two-comparison
+// form (first <= min of the rest || last < min of the rest) cost 7.
+template <int W, bool AP>
+BL_DEV uint32_t closed_hits(const uint32_t* key, uint32_t& closest)
+{
+    if (W == 2) return 0xffffu;  // two s-mers: one of them is the minimum
+    constexpr int WM = W > 2 ? W - 2 : 1;
+    uint32_t mid[S];
+    window_min<S, WM>(key + 1, mid);
+    uint32_t hit = 0, d_prev = 0;
+    BL_UNROLL
+    for (int s = S - 1; s >= 0; --s) {  // last k-mer first: every bit enters at the bottom and the earlier ones move up
+        const uint32_t e = key[s] < key[s + W - 1] ? key[s] : key[s + W - 1];
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(BL_CPU_EMU)
+        // hit = 2 * hit + (e < mid): the compare's carry straight into an add-with-carry (the compiler writes v_cndmask + v_lshl_or)
+        asm("v_cmp_lt_u32_e32 vcc, %1, %2\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(hit) : "v"(e), "v"(mid[s]) : "vcc");
+#else
+        hit = hit + hit + (e < mid[s] ? 1u : 0u);
+#endif
+        const uint32_t d = AP ? abs_diff(e, mid[s]) : e ^ mid[s];
+        if (s & 1) d_prev = d;
+        else fold_min3(closest, d, d_prev);  // (opaque to the optimizer, which would turn the chain into a tree with every leaf alive)
+    }
+    return hit;
+}
+
 // key[S .. S+NE-1] = the first NE values of the lanes that follow (16 per hop); the last lanes of a wave get values that no
 // owned k-mer looks at
 template <int NE, bool SECOND>
@@ -863,7 +895,6 @@ BL_DEV uint32_t phase_sync_closed(const ScanParams& p, TileShared<MODE, W>& sh, 
     static_assert(!DIRECT || (U + W - 1 >= 16 && U + W - 1 <= 32), "the strand test reads 16 bases from either end of the k-mer");
     const int wv = wave_index(tid), lane = tid & 63;
     constexpr int NE = W - 1;        // halo elements
-    constexpr int WW = W - 1;        // width of the sliding minimum
     // One strand at a time — its 16 + W - 1 high dwords, their sliding minima, then ONE BIT per k-mer: "hit if this strand is the
     // canonical one" — so that only one strand's arrays are alive at any moment (both at once do not fit the registers of four
     // waves per SIMD); the k-mers' strands then pick between the two 16-bit masks with three word operations.
@@ -873,22 +904,15 @@ BL_DEV uint32_t phase_sync_closed(const ScanParams& p, TileShared<MODE, W>& sh, 
     uint32_t low = AP ? st.hlow : ~0u;
     uint32_t hit_f = 0, hit_r = 0;
     {
-        uint32_t key[S + NE], mn[S + 1];
+        uint32_t key[S + NE];
         BL_UNROLL
         for (int s = 0; s < S; ++s) key[s] = (uint32_t)(st.h[s] >> 32);
         gather_halo_hi<NE, false>(all, tid, key);
-        window_min<S + 1, WW>(key, mn);
-        BL_UNROLL
-        for (int s = 0; s < S; ++s) {  // forward strand canonical: minimum at offset 0 (leftmost wins a tie) or strictly at W - 1
-            const uint32_t a1 = key[s], m1 = mn[s + 1], a2 = key[s + W - 1], m2 = mn[s];
-            if (a1 <= m1 || a2 < m2) hit_f |= 1u << s;
-            if (AP) fold_min3(closest, abs_diff(a1, m1), abs_diff(a2, m2));
-            else fold_min3(closest, a1 ^ m1, a2 ^ m2);  // (opaque to the optimizer, which would turn the chain into a tree with every leaf alive)
-        }
+        hit_f = closed_hits<W, AP>(key, closest);  // forward strand canonical: minimum at offset 0 (leftmost wins a tie) or strictly at W - 1
     }
     uint32_t hit = hit_f;
     if (p.canonical) {
-        uint32_t key[S + NE], mn[S + 1];
+        uint32_t key[S + NE];
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(BL_CPU_EMU)
         if (DIRECT) {
             BL_UNROLL
@@ -908,14 +932,7 @@ BL_DEV uint32_t phase_sync_closed(const ScanParams& p, TileShared<MODE, W>& sh, 
             for (int s = 0; s + 1 < S; s += 2) fold_min3(low, key[s], key[s + 1]);
         }
         gather_halo_hi<NE, true>(all, tid, key);
-        window_min<S + 1, WW>(key, mn);
-        BL_UNROLL
-        for (int s = 0; s < S; ++s) {  // reverse strand canonical: positions mirror, the rightmost wins a tie
-            const uint32_t a3 = key[s + W - 1], m3 = mn[s], a4 = key[s], m4 = mn[s + 1];
-            if (a3 <= m3 || a4 < m4) hit_r |= 1u << s;
-            if (AP) fold_min3(closest, abs_diff(a3, m3), abs_diff(a4, m4));
-            else fold_min3(closest, a3 ^ m3, a4 ^ m4);
-        }
+        hit_r = closed_hits<W, AP>(key, closest);  // reverse strand canonical: positions mirror, the rightmost wins a tie
         uint32_t rev = st.strand;
         if (DIRECT) {  // reverse strand canonical <=> rc < fwd (kmer_view.hpp:196), read off the 16 leading bases of each
             rev = 0;
