@@ -35,7 +35,7 @@
 // The instruction scheduler may not move anything across this point.  Used between groups of independent hashes: left alone, the
 // scheduler interleaves all of a lane's hashes for instruction-level parallelism and keeps every one's temporaries alive at once,
 // which is what decides whether a kernel fits the registers of four waves per SIMD.
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(BL_CPU_EMU)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(BL_CPU_EMU) && !defined(BL_NO_SCHED_FENCE)
 #define BL_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 #else
 #define BL_SCHED_FENCE() do {} while (0)

@@ -936,12 +936,18 @@ BL_DEV uint32_t phase_sync_closed(const ScanParams& p, TileShared<MODE, W>& sh, 
         uint32_t rev = st.strand;
         if (DIRECT) {  // reverse strand canonical <=> rc < fwd (kmer_view.hpp:196), read off the 16 leading bases of each
             rev = 0;
+            uint32_t x_prev = 0;
             BL_UNROLL
-            for (int s = 0; s < S; ++s) {
+            for (int s = S - 1; s >= 0; --s) {  // (last k-mer first, bits shifted in: see closed_hits)
                 const uint32_t f16 = bases_at(st.cw[0], st.cw[1], st.cw[2], s, 16);
                 const uint32_t r16 = bases_at(st.rw[0], st.rw[1], st.rw[2], 48 - (U + W - 1) - s, 16);
-                if (r16 < f16) rev |= 1u << s;
-                fold_min(AP ? same : closest, f16 ^ r16);
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(BL_CPU_EMU)
+                asm("v_cmp_lt_u32_e32 vcc, %1, %2\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(rev) : "v"(r16), "v"(f16) : "vcc");
+#else
+                rev = rev + rev + (r16 < f16 ? 1u : 0u);
+#endif
+                if (s & 1) x_prev = f16 ^ r16;
+                else fold_min3(AP ? same : closest, f16 ^ r16, x_prev);
             }
         }
         hit = (rev & hit_r) | (~rev & hit_f);
