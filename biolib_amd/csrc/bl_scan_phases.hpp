@@ -741,9 +741,11 @@ BL_DEV uint32_t phase_sync_rev(const ScanParams& p, TileShared<MODE, W>& sh, int
 //       offset 0      <=>  Hf[p] <= min Hf[p+1 .. p+W-1]          offset W-1  <=>  Hf[p+W-1] <  min Hf[p .. p+W-2]
 //   reverse strand canonical (positions mirror, the leftmost becomes the rightmost):
 //       offset 0      <=>  Hr[p+W-1] <= min Hr[p .. p+W-2]        offset W-1  <=>  Hr[p] <  min Hr[p+1 .. p+W-1]
-// so one sliding minimum of width W - 1 per strand over the hashes' HIGH DWORDS (no position tags, one v_min_u32 per step, no
-// tie bookkeeping inside the windows) and four comparisons per k-mer decide.  A comparison whose two high dwords are EQUAL is
-// undecided; the caller then runs the exact argmin form for the wave (phase_sync_fwd / phase_sync_rev).
+// Either pair of conditions is ONE comparison (closed_hits): the smaller of the two END s-mers against the minimum of the W - 2
+// between.  So one sliding minimum of width W - 2 per strand over the hashes' HIGH DWORDS (no position tags, one v_min_u32 per
+// step, no tie bookkeeping inside the windows) and two comparisons per k-mer decide.  A comparison whose two dwords are EQUAL
+// (or, on approximate dwords, less than 2 apart) is undecided; the tile is then decided again in the exact argmin form
+// (scan_redo_kernel: phase_sync_fwd / phase_sync_rev).
 
 // Phase 2 of the closed-syncmer scan (compile-time s-mer length U <= 16): both s-mers of every position straight from the codes
 // and from their reverse complement — no rolling registers, and no k-mer register at all: which strand of the K-MER is canonical
