@@ -71,8 +71,10 @@ def load_json_or_none(path):
 
 def valu_ceiling(model, kernels, bases, seconds, ghz):
     """Second ceiling: SIMD cycles the named kernels need per `bases` at the measured issue cost of their
-    instructions, over the SIMD cycles `seconds` hold at the measured shader clock.  <= 1 by construction: the issue
-    costs are the best sustained rates of tools/ubench_valu.hip (8 waves per SIMD, nothing else running)."""
+    instructions, over the SIMD cycles `seconds` hold at the measured shader clock.  The issue costs are the sustained rates
+    tools/ubench_valu.hip measures per opcode in isolation (8 waves per SIMD, nothing else running); a real mix pairs its cheap and
+    its expensive instructions a little better than any single-opcode loop, so the fraction is good to a few percent and a kernel
+    that issues flat out can read 1.01 (the closed-syncmer scan does)."""
     if model is None:
         return {"error": "profiles/valu_model.json missing: run tools/collect_profiles.sh on the GPU box and tools/valu_model.py"}
     need, parts = 0.0, {}

@@ -10,7 +10,8 @@ For every kernel of the BASELINE configurations:
      else running (profiles/rNN_ubench_valu.json; opcodes the table does not hold are priced at the cheapest class, so
      the total is a LOWER bound on the cycles the instruction stream needs).
 cycles_per_base = sum(count x cycles) x scale x waves / bases: the SIMD cycles a base costs at peak issue.  bench.py divides
-(cycles_per_base x bases) by (1024 SIMDs x the shader clock measured during its timed region x the time taken): <= 1.
+(cycles_per_base x bases) by (1024 SIMDs x the shader clock measured during its timed region x the time taken): the fraction of
+the issue ceiling reached, good to a few percent (per-opcode rates measured in isolation; a real mix can pair slightly better: 1.01 seen).
 Usage: python tools/valu_model.py [rNN]   (in the build container: hipcc cross-compiles, no GPU needed)"""
 import json, os, re, subprocess, sys, tempfile
 
