@@ -27,6 +27,25 @@ __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, int lane)
     // half (row_bcast31, rows 2 and 3).  Lanes without a source add the `old` operand, 0.  (The __shfl_up form costs
     // ~40 VALU per lane around its ds_bpermute's, 2.5 per base.)
     (void)lane;
+#ifndef BL_SCAN_BUILTIN_DPP
+    // one v_add_u32_dpp per step: v = v + dpp(v), lanes without a source add 0 (bound_ctrl), rows outside the mask keep v.  Through
+    // __builtin_amdgcn_update_dpp + add the compiler writes v_mov (the `old` operand) + v_mov_b32_dpp + v_add and a wait state per step.
+    // (a DPP operand written by the instruction before needs two wait states; the assembler does not look inside the asm)
+    asm("s_nop 1\n\t"
+        "v_add_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+        "s_nop 1\n\t"
+        "v_add_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+        "s_nop 1\n\t"
+        "v_add_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+        "s_nop 1\n\t"
+        "v_add_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+        "s_nop 1\n\t"
+        "v_add_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_add_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf"
+        : "+v"(v));
+    return v;
+#else
     v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);  // row_shr:1
     v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);  // row_shr:2
     v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);  // row_shr:4
@@ -34,6 +53,7 @@ __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, int lane)
     v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);  // row_bcast15 -> rows 1, 3
     v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);  // row_bcast31 -> rows 2, 3
     return v;
+#endif
 }
 
 // XOR of v over the wave, valid in LANE 63 ONLY (the inclusive-scan DPP sequence of wave_incl_scan_u32 with xor): the
