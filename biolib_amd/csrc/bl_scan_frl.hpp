@@ -108,10 +108,10 @@ BL_DEV void phase_hash_frl(const ScanParams& p, TileShared<MODE, W>& sh, int tid
 // Neighbouring lanes: values of lane - 1 / lane + 1 (DPP wave shifts on the GPU, lane 0 / 63 get their own value back,
 // which no owned window ever uses; the emulation reads the neighbour's state).
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(BL_CPU_EMU)
-BL_DEV uint32_t dpp_next32(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, false); }  // wave_shl:1
-// the same with a chosen value for lane 63, which has no lane to read from
-BL_DEV uint32_t dpp_next32_or(uint32_t v, uint32_t last) { return (uint32_t)__builtin_amdgcn_update_dpp((int)last, (int)v, 0x130, 0xf, 0xf, false); }
-BL_DEV uint32_t dpp_prev32(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, false); }  // wave_shr:1
+BL_DEV uint32_t dpp_next32(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, true); }  // wave_shl:1
+// the same as a rotation: lane 63 reads lane 0 (wave_rol:1)
+BL_DEV uint32_t dpp_next32_rot(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x134, 0xf, 0xf, true); }
+BL_DEV uint32_t dpp_prev32(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, true); }  // wave_shr:1
 #endif
 
 // Window argmins of a lane that owns NS elements: the W - 1 halo elements come from the following lanes, NS per hop.
@@ -136,10 +136,12 @@ BL_DEV void lane_window_argmin_frl(const ThreadState* all, int tid, const Thread
         for (int hop = 0; hop * NS < NE; ++hop) {
             BL_UNROLL
             for (int x = 0; x < NS; ++x) {
-                // lane 63 owns windows too (64 = rpw * lpr lanes at work) but has no lane to take a halo from: it gets pad
-                // keys whose prefixes are pairwise two or more apart, so that its (non-existent) halo windows never look like a hash tie
+                // lane 63 owns windows too (64 = rpw * lpr lanes at work) but has no lane to take a halo from: the shift is a ROTATION
+                // and it gets lane 0's keys — some other read's, as good as random — so that its (non-existent) halo windows look
+                // like a hash tie no more often than real ones; what they choose is cleared (phase_window_frl_a).  (A rotation reads
+                // a lane everywhere: no `old` operand to initialise, one v_mov per element less than a shift with pad keys.)
                 if (hop * NS + x < NE || (hop + 1) * NS + x < NE || (hop + 2) * NS + x < NE)
-                    cur[x] = dpp_next32_or(cur[x], (0x03fffff0u - (uint32_t)(2 * (4 * x + hop))) << 6) + (uint32_t)NS;
+                    cur[x] = dpp_next32_rot(cur[x]) + (uint32_t)NS;
                 if (hop * NS + x < NE) key[(hop + 1) * NS + x] = cur[x];
             }
         }

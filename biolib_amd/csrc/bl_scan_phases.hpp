@@ -261,8 +261,8 @@ BL_DEV void phase_hash(const ScanParams& p, TileShared<MODE, W>& sh, int tid, Th
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(BL_CPU_EMU)
 BL_DEV uint64_t lane_next(uint64_t v)
 {
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, 0x130, 0xf, 0xf, false);
-    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(v >> 32), 0x130, 0xf, 0xf, false);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, 0x130, 0xf, 0xf, true);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(v >> 32), 0x130, 0xf, 0xf, true);
     return ((uint64_t)hi << 32) | lo;
 }
 #endif
@@ -325,7 +325,7 @@ BL_DEV void gather_halo_keys(uint32_t* key)
         BL_UNROLL
         for (int x = 0; x < S; ++x) {
             if (hop * S + x < NE || (hop + 1) * S + x < NE || (hop + 2) * S + x < NE || (hop + 3) * S + x < NE) {
-                const uint32_t nb = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cur[x], 0x130, 0xf, 0xf, false);
+                const uint32_t nb = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cur[x], 0x130, 0xf, 0xf, true);
                 cur[x] = LEFT ? nb + 16u : nb - 16u;
             }
             if (hop * S + x < NE) key[(hop + 1) * S + x] = cur[x];
@@ -493,7 +493,7 @@ BL_DEV void lane_window_argmin_generic(const ScanParams& p, TileShared<MODE, W>&
             BL_UNROLL
             for (int x = 0; x < S; ++x) {
                 if (hop * S + x < NH || (hop + 1) * S + x < NH || (hop + 2) * S + x < NH || (hop + 3) * S + x < NH || (hop + 4) * S + x < NH) {
-                    const uint32_t nb = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cur[x], 0x130, 0xf, 0xf, false);
+                    const uint32_t nb = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cur[x], 0x130, 0xf, 0xf, true);
                     cur[x] = LEFT ? nb + 16u : nb - 16u;
                 }
                 if (hop * S + x < NH) key[(hop + 1) * S + x] = cur[x];
@@ -620,7 +620,7 @@ BL_DEV uint32_t phase_window(const ScanParams& p, TileShared<MODE, W>& sh, int t
             occ = cnt ? occ : 0u;
         }
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(BL_CPU_EMU)
-        const uint32_t prev_cnt = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cnt, 0x138, 0xf, 0xf, false);  // wave_shr:1, lane 0 gets 0
+        const uint32_t prev_cnt = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cnt, 0x138, 0xf, 0xf, true);  // wave_shr:1, lane 0 gets 0
 #else
         const uint32_t prev_cnt = lane > 0 ? all[tid - 1].vmask : 0u;
 #endif
@@ -636,8 +636,8 @@ BL_DEV uint32_t phase_window(const ScanParams& p, TileShared<MODE, W>& sh, int t
         st.occ = occ;
         st.a_first = kill;
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(BL_CPU_EMU)
-        const uint32_t prev_occ = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)occ, 0x138, 0xf, 0xf, false);
-        const uint32_t prev_kill = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)kill, 0x138, 0xf, 0xf, false);
+        const uint32_t prev_occ = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)occ, 0x138, 0xf, 0xf, true);
+        const uint32_t prev_kill = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)kill, 0x138, 0xf, 0xf, true);
 #else
         const uint32_t prev_occ = lane > 0 ? all[tid - 1].occ : 0u, prev_kill = lane > 0 ? all[tid - 1].a_first : 0u;
 #endif
@@ -870,7 +870,7 @@ BL_DEV void gather_halo_hi(const ThreadState* all, int tid, uint32_t* key)
         BL_UNROLL
         for (int x = 0; x < S; ++x) {
             if (hop * S + x < NE || (hop + 1) * S + x < NE || (hop + 2) * S + x < NE || (hop + 3) * S + x < NE)
-                cur[x] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cur[x], 0x130, 0xf, 0xf, false);  // wave_shl:1
+                cur[x] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cur[x], 0x130, 0xf, 0xf, true);  // wave_shl:1
             if (hop * S + x < NE) key[(hop + 1) * S + x] = cur[x];
         }
     }
