@@ -393,11 +393,15 @@ __global__ __launch_bounds__(TPB) void scan_emit_kernel(const ScanParams p, Grou
     // digest: wave reduce (DPP xor-scan), then one set of atomics per WAVE into a shard line.  Measured alternatives: an LDS stage
     // with two more barriers per tile (no gain); folding the 256 threads' words with LDS atomics on three addresses (-30 % on the
     // whole scan: same-address LDS atomics serialise)
-    const unsigned long long xv = wave_xor_to_last_u64(dg.xv), xh = wave_xor_to_last_u64(dg.xh), xp = wave_xor_to_last_u64(dg.xp);
+    // (a syncmer record is a position: no value, no hash to fold — two of the three 64-bit wave reductions less, a third of that kernel)
+    const unsigned long long xv = MODE == MODE_SYNCMER ? 0ull : wave_xor_to_last_u64(dg.xv), xh = MODE == MODE_SYNCMER ? 0ull : wave_xor_to_last_u64(dg.xh);
+    const unsigned long long xp = wave_xor_to_last_u64(dg.xp);
     if ((tid & 63) == 63 && (xv | xh | xp)) {
         unsigned long long* shard = p.shards + 8 * ((blockIdx.x * NWAVE + (tid >> 6)) % NSHARD);
-        atomicXor(&shard[1], xv);
-        atomicXor(&shard[2], xh);
+        if (MODE != MODE_SYNCMER) {
+            atomicXor(&shard[1], xv);
+            atomicXor(&shard[2], xh);
+        }
         atomicXor(&shard[3], xp);
     }
 }

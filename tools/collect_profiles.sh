@@ -11,6 +11,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof
 rm -rf $OUT && mkdir -p $OUT
 (hostname; date -u +%Y-%m-%dT%H:%M:%SZ; /opt/rocm/bin/rocminfo 2>/dev/null | grep -m1 "Marketing Name.*MI3" ) > $OUT/box.txt 2>&1
+python3 -c "import sys; sys.path.insert(0, '$ROOT'); import bench; print(bench.kernel_sources_digest())" > $OUT/sources.sha256 || exit 1  # what was measured
 cd /tmp && export TMPDIR=/tmp
 $ROOT/tools/_build/ubench_valu --json $OUT/ubench_valu.json > $OUT/ubench_valu.txt 2>&1 || exit 1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_lanes2 -o s -- python3 $ROOT/bench.py --no-cpu-baseline --no-next-rows --no-h2d > $OUT/stats_lanes2.log 2>&1 || exit 1

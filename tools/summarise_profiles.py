@@ -11,6 +11,12 @@ dst = os.path.join(ROOT, "profiles")
 sys.path.insert(0, ROOT)
 from bench import kernel_sources_digest  # what bench.py compares at run time: traffic_stale / valu_stale
 
+# the collection must have been made on the kernel sources of this tree (a refused or failed gpurun call leaves the previous one in place)
+_stamp = os.path.join(src, "sources.sha256")
+if os.path.exists(_stamp):
+    assert open(_stamp).read().strip() == kernel_sources_digest(), "gpurun_out/prof was collected on other kernel sources than this tree's: run tools/collect_profiles.sh again"
+else:
+    print("warning: gpurun_out/prof/sources.sha256 missing (collected by an older tools/collect_profiles.sh): cannot check what was measured", file=sys.stderr)
 git = lambda *a: subprocess.run(["git", "-C", ROOT, *a], capture_output=True, text=True).stdout.strip()
 box = open(os.path.join(src, "box.txt")).read().split("\n")
 prov = {"commit": git("rev-parse", "--short", "HEAD") + ("+dirty" if git("status", "--porcelain", "--untracked-files=no") else ""),

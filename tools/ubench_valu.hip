@@ -212,12 +212,16 @@ int main(int argc, char** argv)
             // the chip settles its clock under load over tens of milliseconds: run the kernel back to back for ~0.2 s first
             for (int rep = 0; rep < (k.compound ? 3 : 10); ++rep) hipLaunchKernelGGL(k.fn, dim3(blocks), dim3(256), 0, 0, d_out, d_sink, 1u);
             CHECK(hipDeviceSynchronize());
-            CHECK(hipEventRecord(e0));
-            hipLaunchKernelGGL(k.fn, dim3(blocks), dim3(256), 0, 0, d_out, d_sink, 1u);
-            CHECK(hipEventRecord(e1));
-            CHECK(hipEventSynchronize(e1));
             float wall_ms = 0.f;
-            CHECK(hipEventElapsedTime(&wall_ms, e0, e1));
+            for (int t = 0; t < 3; ++t) {  // the best of three launches: one launch in a few hundred is held up by something else on the box
+                CHECK(hipEventRecord(e0));
+                hipLaunchKernelGGL(k.fn, dim3(blocks), dim3(256), 0, 0, d_out, d_sink, 1u);
+                CHECK(hipEventRecord(e1));
+                CHECK(hipEventSynchronize(e1));
+                float ms = 0.f;
+                CHECK(hipEventElapsedTime(&ms, e0, e1));
+                wall_ms = (t == 0 || ms < wall_ms) ? ms : wall_ms;
+            }
             std::vector<Stamp> h((size_t)blocks * 4);
             CHECK(hipMemcpy(h.data(), d_out, h.size() * sizeof(Stamp), hipMemcpyDeviceToHost));
             std::vector<double> cyc, ghz;
