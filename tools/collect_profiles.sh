@@ -5,6 +5,8 @@
 #      with the DEFAULT bench command's workloads (C3 at 50 Gbp, the others at their stated sizes) over ONE lane, so that every
 #      counter belongs to exactly one kernel; one timed step (the counters do not need repetitions)
 #   3. the VALU issue-cost table (tools/ubench_valu.hip)
+# Before sending (in the build container, which has hipcc but no GPU; tools/_build/ travels with the snapshot):
+#   mkdir -p tools/_build && hipcc --offload-arch=gfx950 -O3 -std=c++17 -Ibiolib_amd/csrc tools/ubench_valu.hip -o tools/_build/ubench_valu
 # Outputs under gpurun_out/prof/; tools/summarise_profiles.py (in the build container, where git is) turns them into profiles/.
 set -o pipefail
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
