@@ -87,7 +87,12 @@ struct bl_ctx {
     Lane* cur = nullptr;               // lane of the scan being issued / issued last
     int next_lane = 0;
     int n_lanes = 1;                   // 2: consecutive async scans alternate lanes, staggered (bl_ctx_set_lanes, env BL_LANES)
-    uint32_t emit_lds_per_wg = 16384;  // two-lane mode: LDS footprint pass-2 workgroups are padded to (caps their residency per CU; swept on MI355X: 0 -> 214, 16 K -> 449, 25 K -> 438 Gbp/s at C3)
+    // two-lane mode: LDS footprint pass-2 workgroups are padded to, which caps how many of them a CU holds beside the next scan's pass 1
+    // (uncapped, the memory-bound record pass crowds the ALU-bound one out of the SIMDs: 214 Gbp/s at C3 in round 1).  0 = by mode
+    // (emit_lds_default); BL_EMIT_LDS overrides.  Swept on MI355X with the round-3 kernels — minimizers on 150-bp reads (pass 1 holds
+    // 12.4 KB per workgroup): 16 K -> 497, 22-26 K -> 517, 28 K -> 495, 40 K -> 460 Gbp/s; super-k-mers on 10-kbp reads (pass 1: 28.7 KB):
+    // 16 K -> 400, 24 K -> 383.
+    uint32_t emit_lds_per_wg = 0;
     hipStream_t user_stream = nullptr; // borrowed (bl_ctx_set_stream); NULL while borrowed = the legacy default stream
     bool borrowed = false;             // scans run on user_stream instead of the lanes' own streams
     hipStream_t stream = nullptr;      // stream of `cur`
@@ -935,7 +940,8 @@ static int scan_windows(int mode, bl_ctx* c, const bl_batch* b, uint64_t first, 
     if (rc != BL_OK) return rc;
     e = bl::launch_tile_scan(p, all, block_tot, carry, c->stream);
     if (e != hipSuccess) return fail(BL_ERR_HIP, std::string("tile_scan: ") + hipGetErrorString(e));
-    e = bl::launch_scan_emit(mode, p, all, c->stream, staggered ? c->emit_lds_per_wg : 0);  // pass 2
+    const uint32_t emit_lds_default = mode == bl::MODE_SUPERKMER ? 16384u : 24576u;
+    e = bl::launch_scan_emit(mode, p, all, c->stream, staggered ? (c->emit_lds_per_wg ? c->emit_lds_per_wg : emit_lds_default) : 0);  // pass 2
     if (e != hipSuccess) return fail(BL_ERR_HIP, std::string("scan_emit_kernel: ") + hipGetErrorString(e));
     return BL_OK;
 }
