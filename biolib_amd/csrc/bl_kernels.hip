@@ -357,8 +357,11 @@ template <int W, int NS, int U, int L>
 constexpr int frl_lim_last() { return L != 0 ? (L - U + 1 - W + 1) - ((L - U + 1 + S - 1) / S - 1) * NS : 0; }
 
 // APPROX: see count_tile_frl; the launcher follows such a launch with scan_redo_frl_kernel
+#ifndef BL_FRL_WAVES
+#define BL_FRL_WAVES 5  // waves per SIMD the read-tiled pass 1 with a window of at most 11 is compiled for (6: 80 registers, 60 bytes of scratch, 427 against 486 Gbp/s; 4: the same code as 5)
+#endif
 template <int MODE, int W, int NS, int U, int L, int C, bool APPROX = false>
-__global__ __launch_bounds__(TPB, (W <= 11 ? 5 : 4)) void scan_count_frl_kernel(const ScanParams pin, GroupRange g)
+__global__ __launch_bounds__(TPB, (W <= 11 ? BL_FRL_WAVES : 4)) void scan_count_frl_kernel(const ScanParams pin, GroupRange g)
 {
     __shared__ TileShared<MODE, W> sh;
     const ScanParams p = frl_params<MODE, W, NS, U, L, C>(pin);
