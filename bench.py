@@ -88,6 +88,60 @@ def valu_ceiling(model, kernels, bases, seconds, ghz):
             "kernels": parts, "issue_cycles": model["issue_cycles"], "source": model["provenance"]}
 
 
+def free_port():
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n, child_cmd, env=None, poll_s=0.2):
+    """Start `n` fresh rank processes of `child_cmd` on this node (RANK / LOCAL_RANK / WORLD_SIZE / LOCAL_WORLD_SIZE / MASTER_ADDR /
+    MASTER_PORT set as torch.distributed.run would set them), relay rank 0's stdout (the one JSON line) to ours and everything else
+    to stderr, and return the WORST exit code.  When a rank fails, the ranks it started — those exact PIDs — are terminated, so that
+    nobody waits in a collective for ever.  The caller has not touched the GPU: the ranks are children, never an exec of this process
+    (one stream + one host thread per GPU in SURVEY.md §7 step 5 is one process per GPU here; the reference's own drivers are one
+    process, tests/test_kmer_view.cpp:23-42)."""
+    import subprocess
+
+    base = dict(os.environ if env is None else env)
+    base.setdefault("MASTER_ADDR", "127.0.0.1")
+    base.setdefault("MASTER_PORT", str(free_port()))
+    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    procs = []
+    for r in range(n):
+        e = dict(base, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), GROUP_RANK="0")
+        procs.append(subprocess.Popen(child_cmd, env=e, stdout=None if r == 0 else sys.stderr))
+    codes = [None] * n
+    try:
+        while any(c is None for c in codes):
+            for i, p in enumerate(procs):
+                if codes[i] is None:
+                    codes[i] = p.poll()
+            if any(c not in (None, 0) for c in codes):
+                break
+            time.sleep(poll_s)
+    finally:
+        ended_here = []
+        for i, p in enumerate(procs):  # only after a failure or an interrupt is anything still running here
+            if codes[i] is None and p.poll() is None:
+                p.terminate()
+                ended_here.append(i)
+        for i, p in enumerate(procs):
+            if codes[i] is None:
+                try:
+                    codes[i] = p.wait(timeout=30)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+                    codes[i] = p.wait()
+    worst = 0
+    for i, c in enumerate(codes):
+        if c != 0 and i not in ended_here:  # the ranks this function ended are a consequence, not the failure
+            worst = max(worst, c if c > 0 else 128 - c)  # a rank ended by signal s reads as 128 + s
+    return worst or (1 if any(codes) else 0)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -104,6 +158,17 @@ def main():
     ap.add_argument("--other-gbp", type=float, default=0.0, help="size of the other configs (0 = as BASELINE.json states them: 10 / 50 / 50 Gbp)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # invoked without a launcher (`python bench.py --gpus N`): this process becomes the launcher, BEFORE anything touches the GPU
+        if os.environ.get("BL_BENCH_REHEARSE") != "1":
+            import torch  # device_count() reads the driver's node list, it does not initialise the GPU
+
+            have = torch.cuda.device_count()
+            if have < args.gpus:
+                print(f"bench.py: --gpus {args.gpus} but {have} device(s) visible: not running a {have}-rank line under an {args.gpus}-GPU label", file=sys.stderr)
+                sys.exit(2)
+        sys.exit(launch_ranks(args.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]))
+
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -116,6 +181,13 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     rehearse = world > 1 and os.environ.get("BL_BENCH_REHEARSE") == "1"
     coll_dev = "cpu" if rehearse else "cuda"
+    if args.gpus != world:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} rank(s): refusing to print a line whose n_gpus is not what was asked for", file=sys.stderr)
+        sys.exit(2)
+    if world > 1 and not rehearse and torch.cuda.device_count() < world:
+        print(f"bench.py: rank {rank}: {world} ranks but {torch.cuda.device_count()} device(s) visible", file=sys.stderr)
+        sys.exit(2)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -127,8 +199,6 @@ def main():
             torch.cuda.set_device(local_rank)
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # nccl == RCCL on ROCm
     n_gpus = world
-    if args.gpus != world and rank == 0:
-        print(f"# note: --gpus {args.gpus} but WORLD_SIZE={world}; running {world} rank(s)", file=sys.stderr)
 
     dev = local_rank if (world > 1 and not rehearse) else 0
     torch.cuda.set_device(dev)
@@ -255,6 +325,8 @@ def main():
             "value": round(value, 3),
             "unit": "Gbp/s",
             "n_gpus": n_gpus,
+            "rccl_ranks": dist.get_world_size() if world > 1 else 1,
+            "collective_backend": (dist.get_backend() + (" (RCCL)" if dist.get_backend() == "nccl" else "")) if world > 1 else None,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(t_max / args.steps * 1e3, 3),

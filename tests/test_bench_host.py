@@ -37,3 +37,50 @@ def test_committed_profiles_say_which_sources_they_were_measured_on():
         assert stale in (True, False)
         if not stale:
             assert prov_of(d)["kernel_sources_sha256"] == digest
+
+
+# ---- `python bench.py --gpus N` without a launcher: the process starts its own N ranks ----
+
+_CHILD = r"""
+import os, sys, time
+r, w = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+assert os.environ["LOCAL_RANK"] == str(r) and os.environ["MASTER_ADDR"] == "127.0.0.1" and int(os.environ["MASTER_PORT"]) > 0
+mode = sys.argv[1]
+if mode == "fail" and r == 1:
+    sys.exit(7)
+if mode == "fail":
+    time.sleep(60)   # a rank stuck in a collective its peer never joins: the launcher must end it
+print('{"rank": %d, "world": %d}' % (r, w), flush=True)
+"""
+
+
+def test_launch_ranks_relays_rank0_and_sets_the_rendezvous(capfd):
+    rc = bench.launch_ranks(3, [sys.executable, "-c", _CHILD, "ok"])
+    out, err = capfd.readouterr()
+    assert rc == 0
+    assert out.strip() == '{"rank": 0, "world": 3}'          # ONE line on stdout: rank 0's
+    assert '{"rank": 1, "world": 3}' in err and '{"rank": 2, "world": 3}' in err
+
+
+def test_launch_ranks_worst_exit_code_and_no_orphans(capfd):
+    import time
+
+    t0 = time.time()
+    rc = bench.launch_ranks(2, [sys.executable, "-c", _CHILD, "fail"])
+    assert rc == 7
+    assert time.time() - t0 < 30  # rank 0 (sleeping) was terminated, not waited for
+    capfd.readouterr()
+
+
+def test_bench_refuses_a_line_with_fewer_ranks_than_asked_for():
+    """no launcher, --gpus 2, fewer than 2 devices visible (none here): exit code 2 and no JSON line, instead of an n_gpus:1 line"""
+    import subprocess
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "BL_BENCH_REHEARSE")}
+    env["HIP_VISIBLE_DEVICES"] = ""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 2 and "{" not in r.stdout and "--gpus 2" in r.stderr
+    # a launcher that started another number of ranks than --gpus says
+    env.update(WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 2 and "{" not in r.stdout and "WORLD_SIZE=1" in r.stderr

@@ -224,6 +224,17 @@ def test_bench_two_rank_flow_on_one_gpu():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["vs_baseline"] is None and "rehearsal" in d and d["value"] > 0
     assert "cpu_baseline" not in d and d["roofline"]["bound"] == "hbm"
+    # the same line WITHOUT a launcher: `python bench.py --gpus 2` starts its two ranks itself (what the driver's N > 1 call
+    # looks like when it does not go through torch.distributed.run); n_gpus is what was asked for, digests as above
+    env2 = {k: v for k, v in env.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    out2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--gbp", "1.5"],
+                          capture_output=True, text=True, timeout=900, env=env2, cwd=root)
+    assert out2.returncode == 0, out2.stdout[-2000:] + out2.stderr[-3000:]
+    lines2 = [x for x in out2.stdout.splitlines() if x.startswith("{")]
+    assert len(lines2) == 1
+    d2 = json.loads(lines2[0])
+    assert d2["n_gpus"] == 2 and d2["rccl_ranks"] == 2 and d2["collective_backend"] == "gloo"
+    assert (d2["records_per_step"], d2["xor_hash"]) == (d["records_per_step"], d["xor_hash"])
     # the reduced digest = the two shards (seed 42 and 43) scanned directly
     c = B.Context(0)
     n = d["config"]["bases_per_gpu"]
