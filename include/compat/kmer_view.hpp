@@ -238,18 +238,20 @@ class minimizer_position_extractor
         std::size_t operator()(wrapper::kmer_context_t<KmerType> const& kmer) const noexcept
         {
             if (!kmer.value) return klen + 1;
-            uint64_t km = static_cast<uint64_t>(*kmer.value);
-            uint64_t mval = bl_hash64_u64(km & mask, 0);
-            uint8_t minpos = 0;
-            for (std::size_t i = 0; i < static_cast<uint8_t>(klen - mlen + 1); ++i) {
-                const uint64_t val = bl_hash64_u64(km & mask, 0);
-                if (mval >= val) {  // '>=': the later (more leftward) m-mer wins ties
-                    mval = val;
-                    minpos = static_cast<uint8_t>(i);
+            // the k-mer packs its first base in the most significant pair: the m-mer at offset o from the left end is the 2m bits
+            // that start 2 * (k - m - o) bits up.  Left to right with a strict '<': the leftmost of equal minima stays.
+            const uint64_t packed = static_cast<uint64_t>(*kmer.value);
+            const unsigned last = static_cast<unsigned>(klen - mlen);
+            unsigned best = 0;
+            uint64_t best_hash = bl_hash64_u64((packed >> (2 * last)) & mask, 0);
+            for (unsigned o = 1; o <= last; ++o) {
+                const uint64_t h = bl_hash64_u64((packed >> (2 * (last - o))) & mask, 0);
+                if (h < best_hash) {
+                    best_hash = h;
+                    best = o;
                 }
-                km >>= 2;
             }
-            return klen - mlen - minpos;
+            return best;
         }
         uint8_t get_k() const noexcept {return klen;}
         uint8_t get_m() const noexcept {return mlen;}

@@ -26,7 +26,7 @@ def test_cpp_compat_views():
 
 @pytest.mark.gpu
 def test_cpp_compat_jaccard(tmp_path):
-    """the reference's Jaccard tool body (tests/test_jaccard.cpp:55-130) over external_memory_vector / ordered_unique_sampler /
+    """a Jaccard workflow (what the reference's tests/test_jaccard.cpp does, written as our own caller) over external_memory_vector / ordered_unique_sampler /
     jaccard from include/compat/, on two fixture files"""
     exe = built("test_compat_jaccard")
     ing = os.path.join(ROOT, "tests", "golden", "ingest")
