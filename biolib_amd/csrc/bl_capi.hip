@@ -730,6 +730,8 @@ int bl_batch_set_origin(bl_batch* b, uint64_t origin)
     return BL_OK;
 }
 
+uint64_t bl_batch_origin(const bl_batch* b) { return b ? b->origin : 0; }
+
 int bl_batch_synth(bl_ctx* c, uint64_t seed, uint64_t n_bases, uint64_t read_len, bl_batch** out)
 {
     bl_batch* b = nullptr;

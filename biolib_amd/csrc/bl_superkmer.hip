@@ -72,11 +72,14 @@ __device__ __forceinline__ unsigned long long codes8(const unsigned char* __rest
 
 __global__ __launch_bounds__(256) void pack_kernel(const unsigned char* __restrict__ bases, unsigned long long n_bases,
                                                    const unsigned long long* __restrict__ first_pos, const unsigned char* __restrict__ sizes,
-                                                   const unsigned char* __restrict__ mm_pos, unsigned long long n, int k, ulonglong2* __restrict__ out)
+                                                   const unsigned char* __restrict__ mm_pos, unsigned long long n, int k, ulonglong2* __restrict__ out,
+                                                   unsigned long long origin)
 {
     const unsigned long long g = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= n) return;
-    const unsigned long long p = first_pos[g];
+    // the scan reported origin + the position inside the batch (bl_batch_set_origin); a position in front of the origin wraps to a
+    // huge value and takes the "beyond the batch" exit below
+    const unsigned long long p = first_pos[g] - origin;
     const int size = sizes[g];
     int nb = size + k - 1;
     if (p + (unsigned long long)nb > n_bases) nb = p < n_bases ? (int)(n_bases - p) : 0;  // never read past the batch (a caller error; the record is then short)
@@ -624,7 +627,7 @@ int bl_pack_super_kmers(bl_ctx* ctx, const bl_batch* batch, const uint64_t* d_fi
     hipStream_t s = bl_ctx_stream(ctx);
     hipLaunchKernelGGL(pack_kernel, dim3((unsigned)((n_groups + 255) / 256)), dim3(256), 0, s, static_cast<const unsigned char*>(bl_batch_device_bases(batch)),
                        (unsigned long long)bl_batch_n_bases(batch), reinterpret_cast<const unsigned long long*>(d_first_pos), d_sizes, d_mm_pos,
-                       (unsigned long long)n_groups, (int)k, reinterpret_cast<ulonglong2*>(d_records));
+                       (unsigned long long)n_groups, (int)k, reinterpret_cast<ulonglong2*>(d_records), (unsigned long long)bl_batch_origin(batch));
     SK_HIP(hipGetLastError());
     return BL_OK;
 }

@@ -123,6 +123,7 @@ const void* bl_batch_device_bases(const bl_batch* batch);
  * origin + the position inside the batch, so the records of the pieces concatenate to the records of the whole; the
  * ranges [first, first+n) of the scan calls stay relative to the batch.  Default 0. */
 int bl_batch_set_origin(bl_batch* batch, uint64_t origin);
+uint64_t bl_batch_origin(const bl_batch* batch);
 /* Copy bases [first, first+n) back to the host (synchronous). */
 int bl_batch_download(bl_batch* batch, uint64_t first, uint64_t n, char* out);
 
@@ -275,7 +276,8 @@ int bl_count_allreduce(bl_ctx* const* ctxs, int n_gpu, uint64_t* counters, int n
  * bl_pack_super_kmers: one 16-byte record per group of bl_scan_super_kmers — d_records[2g] = bases 0..31 of the group's
  *   size + k - 1 bases (2 bits each, first base most significant), d_records[2g+1] = bases 32.. in bits 63..10, mm_pos in
  *   bits 9..5 (d_mm_pos is REQUIRED: bl_count_super_kmers finds a record's minimizer through it), size - 1 in bits 4..0.
- *   Needs 2k - m <= 59.
+ *   Needs 2k - m <= 59.  d_first_pos holds what the scan of THIS batch reported: positions in the caller's whole when the batch
+ *   has an origin (bl_batch_set_origin); a position in front of the origin or beyond the batch packs an empty record.
  * bl_partition_records: reorder 16-byte records into `parts` (<= 64) contiguous buckets by d_hashes[g] % parts (the
  *   minimizer hash the scan returned = the owner rank); counts[b] (host) = records in bucket b.
  * bl_expand_super_kmers: records -> their k-mers (canonical with BL_FLAG_CANONICAL), group after group;

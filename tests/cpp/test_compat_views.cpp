@@ -96,6 +96,26 @@ int main()
                 }
     }
 
+    // ---- a1 over the WHOLE byte domain (reference constants.hpp:12-21; it indexes the table with a signed char, kmer_view.hpp:191, so
+    // bytes >= 0x80 are outside its table: this build's contract for them is "break"): every byte value 1..255 at every position
+    // of a 16-byte load (0 would end the C string), through the view, against the oracle's item protocol
+    {
+        std::string s(255 * 16 * 48, 'A');
+        blo_synth(4242, 0, s.size(), s.data());
+        for (int v = 1; v < 256; ++v)
+            for (int o = 0; o < 16; ++o) s[(size_t)((v - 1) * 16 + o) * 48 + 16 + o] = (char)v;
+        for (uint8_t k : {(uint8_t)4, (uint8_t)31})
+            for (int canon = 0; canon < 2; ++canon) {
+                std::vector<uint64_t> v(s.size() + 2), p(s.size() + 2), id(s.size() + 2);
+                std::vector<uint8_t> nul(s.size() + 2);
+                size_t n = blo_kmer_items(s.data(), s.size(), k, canon, 0, v.data(), nul.data(), p.data(), id.data(), v.size());
+                auto got = collect(s, k, canon, false);
+                CHECK(got.size() == n, "all bytes k %d c %d: %zu items vs %zu", k, canon, got.size(), n);
+                for (size_t i = 0; i < n && i < got.size(); ++i)
+                    CHECK(got[i].position == (long)p[i] && got[i].id == (long)id[i] && got[i].value == (nul[i] ? -1 : (long)v[i]), "all bytes k %d item %zu", k, i);
+            }
+    }
+
     // ---- hash functors: reference KATs
     CHECK(hash::hash64::hash<uint64_t>(0, 0) == 0x28df63b7cc57c3cbULL, "hash64(0,0)");
     CHECK(hash::hash64::hash<uint64_t>(0x0123456789abcdefULL, 42) == 0xccbfe31ee09a27dbULL, "hash64 seed 42");

@@ -35,10 +35,13 @@ std::vector<uint32_t> make_start_bits(uint64_t n_bases, const uint64_t* offsets,
 }
 
 // pass 1 (scan_count_kernel) for every tile, the tile-count prefix scan, pass 2 (scan_emit_kernel)
-int g_closed_redone = 0;
-template <int MODE, int W, bool CS = false, int U = 0>
+int g_closed_redone = 0, g_sy2_redone = 0;
+// SY: the syncmer form of count_tile (bl_kernels.hip): 0 = argmins with the exact form inline, 1 = closed syncmers on murmur64_top,
+// 2 = argmins from phase_hash_closed<BOTH> with the exact form deferred to a second run of the tile (scan_redo_kernel)
+template <int MODE, int W, int SY = 0, int U = 0>
 void run_tiles(ScanParams p, unsigned long long* result)
 {
+    constexpr bool CS = SY == 1;
     const size_t nt = (size_t)p.n_tiles;
     std::vector<unsigned long long> counts(nt), base(nt);
     std::vector<uint16_t> sa(nt * p.stride), sj(MODE == MODE_SUPERKMER ? nt * p.stride : 1), se(MODE == MODE_SUPERKMER ? nt * p.stride : 1);
@@ -54,9 +57,12 @@ void run_tiles(ScanParams p, unsigned long long* result)
             const int64_t q0 = p.origin + (int64_t)tile * p.stride;
             for (int tid = 0; tid < TPB; ++tid) phase_load<MODE, W>(p, *sh, tid, q0);
             for (int c = 0; c < staged_chunks(p); ++c) sc[tile * p.slot_chunks + c] = sh->codes[c];  // codes spill
-            constexpr int CSU = (MODE == MODE_SYNCMER && CS) ? 11 : 0;  // the closed-syncmer kernel is instantiated for s = 11 (launch_count_mode)
-            if (CSU) {
+            constexpr int CSU = (MODE == MODE_SYNCMER && SY != 0) ? 11 : 0;  // the closed-syncmer kernels are instantiated for s = 11 (launch_count_mode)
+            bool sy2_tie = false;
+            if (CSU && CS) {
                 for (int tid = 0; tid < TPB; ++tid) phase_hash_closed<MODE, W, (CSU ? CSU : 1), false, true>(p, *sh, tid, st[tid]);
+            } else if (CSU) {
+                for (int tid = 0; tid < TPB; ++tid) phase_hash_closed<MODE, W, (CSU ? CSU : 1), true, false>(p, *sh, tid, st[tid], &sy2_tie);
             } else {
                 for (int tid = 0; tid < TPB; ++tid) phase_hash<MODE, W, (MODE != MODE_SYNCMER ? U : 0)>(p, *sh, tid, st[tid]);
             }
@@ -69,6 +75,18 @@ void run_tiles(ScanParams p, unsigned long long* result)
                 }
                 if (any) {
                     ++g_closed_redone;
+                    std::memset(st.data(), 0x5A, st.size() * sizeof(ThreadState));
+                    for (int tid = 0; tid < TPB; ++tid) phase_hash<MODE, W>(p, *sh, tid, st[tid]);
+                    for (int tid = 0; tid < TPB; ++tid) phase_sync_fwd<MODE, W>(p, *sh, tid, st[tid], st.data(), &af[tid * (S + 1)]);
+                    for (int tid = 0; tid < TPB; ++tid)
+                        packed[tid] = phase_sync_rev<MODE, W>(p, *sh, tid, q0, st[tid], st.data(), &af[tid * (S + 1)]);
+                }
+            } else if (MODE == MODE_SYNCMER && SY == 2) {  // count_tile's SY = 2 branch: ties reported, the whole tile decided again exactly
+                for (int tid = 0; tid < TPB; ++tid) phase_sync_fwd<MODE, W, true>(p, *sh, tid, st[tid], st.data(), &af[tid * (S + 1)], &sy2_tie);
+                for (int tid = 0; tid < TPB; ++tid)
+                    packed[tid] = phase_sync_rev<MODE, W, true>(p, *sh, tid, q0, st[tid], st.data(), &af[tid * (S + 1)], &sy2_tie);
+                if (sy2_tie) {
+                    ++g_sy2_redone;
                     std::memset(st.data(), 0x5A, st.size() * sizeof(ThreadState));
                     for (int tid = 0; tid < TPB; ++tid) phase_hash<MODE, W>(p, *sh, tid, st[tid]);
                     for (int tid = 0; tid < TPB; ++tid) phase_sync_fwd<MODE, W>(p, *sh, tid, st[tid], st.data(), &af[tid * (S + 1)]);
@@ -241,12 +259,16 @@ void run_mode(const ScanParams& p, unsigned long long* result)
         case 19: if (MODE != MODE_SYNCMER) { run_tiles<MODE, 19>(p, result); break; } run_tiles<MODE, -16>(p, result); break;
         case 11: run_tiles<MODE, 11>(p, result); break;
         case 17:
-            if (MODE == MODE_SUPERKMER && p.unit == 15 && p.canonical) { run_tiles<MODE_SUPERKMER, 17, false, 15>(p, result); break; }  // the BASELINE C4 kernel
+            if (MODE == MODE_SUPERKMER && p.unit == 15 && p.canonical) { run_tiles<MODE_SUPERKMER, 17, 0, 15>(p, result); break; }  // the BASELINE C4 kernel
             run_tiles<MODE, 17>(p, result);
             break;
         case 21:
             if (MODE == MODE_SYNCMER && p.unit == 11 && p.canonical && ((p.soff == 0 && p.eoff == 20) || (p.soff == 20 && p.eoff == 0))) {
-                run_tiles<MODE_SYNCMER, 21, true>(p, result);  // the BASELINE C5 kernel (launch_count_mode)
+                run_tiles<MODE_SYNCMER, 21, 1>(p, result);  // the BASELINE C5 kernel (launch_count_mode)
+                break;
+            }
+            if (MODE == MODE_SYNCMER && p.unit == 11 && p.canonical) {
+                run_tiles<MODE_SYNCMER, 21, 2>(p, result);  // any other pair of offsets: argmins, the exact form deferred (launch_count_mode)
                 break;
             }
             run_tiles<MODE, 21>(p, result);
@@ -342,6 +364,7 @@ void emu_top_check(const uint64_t* keys, uint64_t n, uint32_t seed, uint64_t* ba
 int emu_frl_scans() { return g_frl_scans; }
 int emu_frl_redone() { return g_frl_redone; }
 int emu_closed_redone() { return g_closed_redone; }
+int emu_sy2_redone() { return g_sy2_redone; }
 int emu_frl_tiles() { return g_frl_tiles; }
 
 void emu_hash_sample(const EmuBatch* b, uint64_t first, uint64_t n, unsigned k, uint64_t seed, uint64_t threshold, unsigned flags,

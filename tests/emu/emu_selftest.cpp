@@ -31,6 +31,7 @@ uint64_t emu_hash64(uint64_t v, uint64_t seed);
 int emu_frl_scans();
 int emu_frl_redone();
 int emu_closed_redone();
+int emu_sy2_redone();
 int emu_frl_tiles();
 }
 
@@ -122,7 +123,9 @@ static void check_case(const Case& c, std::mt19937_64& rng)
 
     struct SY { unsigned k, s, a, b; int canon; };
     const SY sys[] = {{31, 11, 0, 20, 1}, {31, 11, 0, 20, 0}, {21, 8, 0, 13, 1}, {7, 4, 0, 3, 1}, {15, 15, 0, 0, 1}, {31, 15, 0, 16, 1},
-                      {32, 12, 3, 9, 1}, {9, 1, 0, 8, 0}, {28, 12, 5, 5, 1}};
+                      {32, 12, 3, 9, 1}, {9, 1, 0, 8, 0}, {28, 12, 5, 5, 1},
+                      // k = 31, s = 11 with offsets other than {0, 20}: count_tile's SY = 2 form (exact argmins deferred to a second run)
+                      {31, 11, 3, 9, 1}, {31, 11, 0, 0, 1}, {31, 11, 20, 20, 1}, {31, 11, 5, 20, 1}};
     for (const SY& y : sys) {
         for (int drop = 0; drop < 2; ++drop) {
             size_t cnt = blo_syncmers(s, c.offsets.data(), n_seqs, y.k, y.s, y.a, y.b, y.canon, drop, 1, op.data(), cap);
@@ -287,7 +290,8 @@ int main(int argc, char** argv)
         }
     }
     CHECK(emu_frl_scans() > 100, "the read-tiled path was hardly exercised: %d scans", emu_frl_scans());
-    std::printf("read-tiled scans run: %d (tiles %d, of which decided again on the hashes: %d; tiles of closed-syncmer scans decided again: %d)\n", emu_frl_scans(), emu_frl_tiles(), emu_frl_redone(), emu_closed_redone());
+    std::printf("read-tiled scans run: %d (tiles %d, of which decided again on the hashes: %d; tiles of closed-syncmer scans decided again: %d, of argmin syncmer scans with the exact form deferred: %d)\n", emu_frl_scans(), emu_frl_tiles(), emu_frl_redone(), emu_closed_redone(), emu_sy2_redone());
+    CHECK(emu_sy2_redone() > 0, "no tile of a deferred-argmin syncmer scan was decided again: the tie path did not run");
     if (g_fail) {
         std::printf("emu_selftest: %d mismatches\n", g_fail);
         return 1;

@@ -85,6 +85,47 @@ def test_kmers_dense_vs_reference_arrays(ctx, golden_arrays, name):
             assert out["count"] == int(ok.sum()) and out["xor_hash"] == O.xor_reduce(exp_h)
 
 
+def _all_bytes_sequence(spacing):
+    """random ACGT with every byte value 0..255 planted once at every position of a 16-byte load (position mod 16), `spacing`
+    bases apart (a multiple of 16): the encoder's whole input domain (reference constants.hpp:12-21; the reference indexes its
+    table with a signed char, kmer_view.hpp:191, so bytes >= 0x80 lie outside it: this build's contract for them is "break")"""
+    assert spacing % 16 == 0
+    seq = O.synth(77, 256 * 16 * spacing).copy()
+    i = np.arange(256 * 16)
+    seq[i * spacing + 16 + (i % 16)] = (i // 16).astype(np.uint8)
+    return seq
+
+
+def test_encoder_over_the_whole_byte_domain(ctx):
+    """a1 on the device: the SWAR encoder (encode4 / encode16) sees all 256 byte values in all 16 lanes of its loads, in both
+    staging paths (position-tiled and read-tiled), and inside k-mers that straddle lane, wave-tile and workgroup-tile edges"""
+    # dense k-mers (kmer_kernel: stage_chunk): validity and values per position for short and long k
+    seq = _all_bytes_sequence(48)
+    offs = np.array([0, len(seq)], np.uint64)
+    b = ctx.upload(seq)
+    letters = set(b"ACGTUacgtu")
+    for k in (1, 4, 31, 32):
+        for canon in (False, True):
+            val, ok = O.units(seq, offs, k, canon)
+            out = b.kmers(k, seed=3, canonical=canon)
+            assert np.array_equal(out["valid"], ok), (k, canon)
+            assert np.array_equal(out["values"], val), (k, canon)
+            if k == 1:  # the table itself: a position is valid iff its byte is one of the ten letters
+                assert np.array_equal(ok.astype(bool), np.isin(seq, list(letters)))
+    # window scans: position-tiled (one sequence), read-tiled (fixed 192-bp reads: stage_chunk_frl) and ragged
+    for kw, batch in (("one", b), ("reads192", ctx.upload(seq, read_len=192)), ("reads150", ctx.upload(seq[: len(seq) // 150 * 150], read_len=150))):
+        s = seq if kw != "reads150" else seq[: len(seq) // 150 * 150]
+        o = offs if kw == "one" else np.arange(0, len(s) + 1, 192 if kw == "reads192" else 150, dtype=np.uint64)
+        for (unit, w, canon) in ((31, 11, True), (5, 10, False), (15, 17, True)):
+            v, p, h = O.minimizers(s, o, unit, w, 42, canon, brute=False)
+            got = batch.minimizers(unit, w, seed=42, canonical=canon)
+            assert got["count"] == len(v), (kw, unit, w)
+            assert np.array_equal(got["values"], v) and np.array_equal(got["positions"], p) and np.array_equal(got["hashes"], h), (kw, unit, w)
+        n, pos = O.syncmers(s, o, 31, 11, 0, 20, True)
+        got = batch.syncmers(31, 11, 0, 20, canonical=True)
+        assert got["count"] == n and np.array_equal(got["positions"], pos), kw
+
+
 @pytest.mark.parametrize("name", ["clean_one", "broken_one", "clean_reads150", "broken_reads150", "clean_ragged", "broken_ragged"])
 def test_minimizers_and_super_kmers_vs_golden(ctx, golden_arrays, name):
     A = golden_arrays
@@ -174,7 +215,10 @@ def test_all_scans_vs_oracle_random(ctx, flavour):
             assert got["count"] == len(mn) == got["aux"], (flavour, n, k, m)
             assert np.array_equal(got["minimizers"], mn) and np.array_equal(got["first_pos"], fp) and np.array_equal(got["hashes"], hs)
             assert np.array_equal(got["mm_pos"], mp) and np.array_equal(got["sizes"], sz)
-        for (k, s, a, e, canon) in ((31, 11, 0, 20, 1), (31, 11, 0, 20, 0), (21, 8, 0, 13, 1), (15, 15, 0, 0, 1), (32, 12, 3, 9, 1)):
+        # (31, 11) canonical with offsets other than {0, 20}: scan_count_kernel<SYNCMER,21,11,1,SY=2> (argmins, exact form in scan_redo_kernel);
+        # (31, 11) not canonical and the other shapes: the closed form where the offsets are {0, k - s}, else the general argmin kernels
+        for (k, s, a, e, canon) in ((31, 11, 0, 20, 1), (31, 11, 0, 20, 0), (21, 8, 0, 13, 1), (15, 15, 0, 0, 1), (32, 12, 3, 9, 1),
+                                    (31, 11, 3, 9, 1), (31, 11, 0, 0, 1), (31, 11, 20, 20, 1), (31, 11, 7, 20, 1), (31, 11, 3, 9, 0)):
             for drop in (False, True):
                 cnt, pos = O.syncmers(seq, offs, k, s, a, e, canon, drop_last=drop)
                 got = b.syncmers(k, s, a, e, canonical=bool(canon), drop_last=drop)

@@ -261,6 +261,12 @@ def test_super_kmer_records_from_the_scan_equal_scan_then_pack(ctx, layout, k, m
     f2, _ = b.super_kmer_records(k, m, seed=5, canonical=canon, first=first, n=cnt)
     p2, _ = b.super_kmer_records(k, m, seed=5, canonical=canon, first=first, n=cnt, fused=False)
     assert f2.shape == p2.shape and bool((f2 == p2).all())
+    # a batch that is a piece of a longer whole (bl_batch_set_origin): the scan reports origin + position, and the unfused path packs
+    # from those positions — the same records as without an origin (the records hold bases, not positions)
+    b.set_origin(10**12 + 7)
+    f3, _ = b.super_kmer_records(k, m, seed=5, canonical=canon, first=first, n=cnt)
+    p3, _ = b.super_kmer_records(k, m, seed=5, canonical=canon, first=first, n=cnt, fused=False)
+    assert f3.shape == f2.shape and bool((f3 == f2).all()) and bool((p3 == f2).all())
     b.close()
 
 
