@@ -77,8 +77,9 @@ def lib():
     L.bl_batch_device_bases.argtypes = [vp]
     L.bl_batch_download.argtypes = [vp, u64, u64, vp]
     L.bl_batch_set_origin.argtypes = [vp, u64]
-    L.bl_batch_origin.argtypes = [vp]
-    L.bl_batch_origin.restype = u64
+    if "BIOLIB_AMD_LIB" not in os.environ or hasattr(L, "bl_batch_origin"):  # (an A/B build of an older revision may lack it)
+        L.bl_batch_origin.argtypes = [vp]
+        L.bl_batch_origin.restype = u64
     L.bl_batch_upload_reads.argtypes = [vp, vp, u64, u64, C.POINTER(vp)]
     L.bl_scan_kmers.argtypes = [vp, vp, u64, u64, u32, u64, u32, vp, vp, vp, C.POINTER(Result)]
     L.bl_scan_minimizers.argtypes = [vp, vp, u64, u64, u32, u32, u64, u32, vp, vp, vp, u64, C.POINTER(Result)]

@@ -88,6 +88,13 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
     return v;
 }
 
+// a value every lane of the wave holds alike, moved to scalar registers
+__device__ __forceinline__ unsigned long long uniform64(unsigned long long v)
+{
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
+
 // exclusive scan over the workgroup of a value that packs two 16-bit counters (sums stay < 65536)
 __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* wave_tot, int tid, uint32_t& total)
 {
@@ -247,8 +254,10 @@ __device__ __forceinline__ void emit_tile(const ScanParams& p, uint32_t* codes, 
     // (speculatively: a tile of 150-bp reads holds ~600) — is issued before the first one is consumed
     const int64_t q0 = tile_q0(p, tile);
     const size_t slot = (size_t)tile * p.stride;
-    const unsigned long long cnt = p.tile_counts[tile];
-    const unsigned long long base = p.tile_base[tile] + p.block_base[tile / SCAN_BLK];
+    // (uniform64: inside scan_emit_kernel's tile loop the compiler reads these through vector loads and keeps counts, offsets and every
+    // comparison with them in vector registers — 34-40 registers instead of 23)
+    const unsigned long long cnt = uniform64(p.tile_counts[tile]);
+    const unsigned long long base = uniform64(p.tile_base[tile] + p.block_base[tile / SCAN_BLK]);
     const int needed = staged_chunks(p);
     const uint32_t* sc = p.slots_c + (size_t)tile * p.slot_chunks;
     const uint32_t c0 = (MODE != MODE_SYNCMER && tid < needed) ? sc[tid] : 0;
@@ -263,7 +272,10 @@ __device__ __forceinline__ void emit_tile(const ScanParams& p, uint32_t* codes, 
         j1 = in1 ? lj[TPB + tid] : 0;
     }
     const uint32_t n_s = (uint32_t)cnt, n_e = (uint32_t)(cnt >> 32);
-    if (n_s == 0 && n_e == 0) return;  // uniform for the workgroup
+    if (n_s == 0 && n_e == 0) {  // uniform for the workgroup
+        if (MODE != MODE_SYNCMER) __syncthreads();  // (the caller's tile loop counts on one barrier per tile: scan_emit_kernel)
+        return;
+    }
     const uint64_t base_s = base & 0xffffffffull, base_e = base >> 32;
     if (MODE != MODE_SYNCMER) {  // (syncmers: no codes, no barrier — a record is its list entry's position)
         if (tid < needed) codes[tid] = c0;
@@ -283,8 +295,12 @@ __device__ __forceinline__ void emit_tile(const ScanParams& p, uint32_t* codes, 
             if (p.out_records) emit_record(p, codes, needed - 1, q0, rec, size, base_s + r);
         }
     };
+    // (fences: left alone the scheduler interleaves the two records for instruction-level parallelism — 30 registers instead of 22, and
+    // this kernel's registers decide how many of its waves fit a SIMD beside the hashing pass: 96 x 4 or 5 waves of the 512 there are)
     if ((uint32_t)tid < n_s) one(tid, a0, j0);
+    BL_SCHED_FENCE();
     if ((uint32_t)(TPB + tid) < n_s) one(TPB + tid, a1, j1);
+    BL_SCHED_FENCE();
 #pragma unroll 1
     for (uint32_t r = 2 * TPB + tid; r < n_s; r += TPB) one(r, la[r], MODE == MODE_SUPERKMER ? lj[r] : 0u);  // rarely any
 }
@@ -384,14 +400,45 @@ __global__ __launch_bounds__(TPB, (W <= 11 ? 5 : 4)) void scan_redo_frl_kernel(c
     }
 }
 
-template <int MODE>
-__global__ __launch_bounds__(TPB) void scan_emit_kernel(const ScanParams p, GroupRange g)
+// A workgroup takes BL_EMIT_TILES consecutive tiles: the digest's wave reductions and atomics, a third of this kernel's instructions
+// when paid per tile, are paid once per workgroup.  No loads of a later tile are in flight while a tile is built (that form, tried
+// in round 3, needs 52 registers for 22 and crowds the hashing pass); the codes ping-pong between two LDS buffers so that the loop
+// needs no barrier of its own (tile k + 2 overwrites what tile k read only after every thread has passed tile k + 1's barrier).
+// U, C, FRL: unit length, canonical flag and layout as compile-time constants for the BASELINE C3 shape (0 / -1 / -1: from the arguments).
+#ifndef BL_EMIT_TILES
+#define BL_EMIT_TILES 4
+#endif
+template <int MODE, int U = 0, int C = -1, int FRL = -1>
+__global__ __launch_bounds__(TPB) void scan_emit_kernel(const ScanParams pin, GroupRange g)
 {
-    __shared__ uint32_t codes[NCHUNK];
+    __shared__ uint32_t codes[2][NCHUNK];
     const int tid = threadIdx.x;
-    if (blockIdx.x >= g.count) return;
+    ScanParams p = pin;
+    if (U != 0) p.unit = U;
+    if (C >= 0) p.canonical = C;
+    if (FRL >= 0) p.frl = FRL;
+    // the thread's digest words live in LDS between tiles (six dwords per thread, read-xor-written once per tile): kept in registers across
+    // the loop they, and what the compiler then hoists out of it, take the kernel from 23 registers to 38-46
+    __shared__ uint32_t acc[6][TPB];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) acc[i][tid] = 0;
+    const uint32_t t0 = blockIdx.x * BL_EMIT_TILES;
+#pragma unroll 1
+    for (uint32_t k = 0; k < BL_EMIT_TILES && t0 + k < g.count; ++k) {
+        Digest d1{0, 0, 0};
+        emit_tile<MODE>(p, codes[k & 1], g.first + t0 + k, tid, d1);
+        if (MODE != MODE_SYNCMER) {
+            acc[0][tid] ^= (uint32_t)d1.xv; acc[1][tid] ^= (uint32_t)(d1.xv >> 32);
+            acc[2][tid] ^= (uint32_t)d1.xh; acc[3][tid] ^= (uint32_t)(d1.xh >> 32);
+        }
+        acc[4][tid] ^= (uint32_t)d1.xp; acc[5][tid] ^= (uint32_t)(d1.xp >> 32);
+    }
     Digest dg{0, 0, 0};
-    emit_tile<MODE>(p, codes, g.first + blockIdx.x, tid, dg);
+    if (MODE != MODE_SYNCMER) {
+        dg.xv = ((unsigned long long)acc[1][tid] << 32) | acc[0][tid];
+        dg.xh = ((unsigned long long)acc[3][tid] << 32) | acc[2][tid];
+    }
+    dg.xp = ((unsigned long long)acc[5][tid] << 32) | acc[4][tid];
 
     // digest: wave reduce (DPP xor-scan), then one set of atomics per WAVE into a shard line.  Measured alternatives: an LDS stage
     // with two more barriers per tile (no gain); folding the 256 threads' words with LDS atomics on three addresses (-30 % on the
@@ -706,9 +753,14 @@ hipError_t launch_scan_count(int mode, const ScanParams& p, GroupRange g, hipStr
 template <int MODE>
 static void launch_emit_mode(const ScanParams& p, GroupRange g, hipStream_t stream, uint32_t lds_per_wg)
 {
-    const uint32_t have = (uint32_t)(NCHUNK * sizeof(uint32_t));
+    const uint32_t have = (uint32_t)(2 * NCHUNK * sizeof(uint32_t));
     const uint32_t pad = lds_per_wg > have ? lds_per_wg - have : 0;
-    hipLaunchKernelGGL((scan_emit_kernel<MODE>), dim3(g.count), dim3(TPB), pad, stream, p, g);
+    const dim3 grid((g.count + BL_EMIT_TILES - 1) / BL_EMIT_TILES), block(TPB);
+    if (MODE == MODE_MINIMIZER && p.frl && p.unit == 31 && p.canonical) {  // BASELINE C3
+        hipLaunchKernelGGL((scan_emit_kernel<MODE_MINIMIZER, 31, 1, 1>), grid, block, pad, stream, p, g);
+        return;
+    }
+    hipLaunchKernelGGL((scan_emit_kernel<MODE>), grid, block, pad, stream, p, g);
 }
 
 hipError_t launch_scan_emit(int mode, const ScanParams& p, GroupRange g, hipStream_t stream, uint32_t lds_per_wg)

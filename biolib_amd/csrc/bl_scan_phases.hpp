@@ -1056,7 +1056,9 @@ BL_DEV Record emit_prepare(const ScanParams& p, const uint32_t* codes, int64_t q
     dg.xp ^= rec.pos + (uint64_t)p.pos_base;
     if (MODE != MODE_SYNCMER) {
         rec.v = extract_unit(p.frl ? codes : codes + wave_chunk0(p, wv), ap, p.unit, p.canonical);
+        BL_SCHED_FENCE();  // (pass 2 lives on few registers: see scan_emit_kernel)
         rec.h = murmur64(rec.v, p.seed);
+        BL_SCHED_FENCE();
         dg.xv ^= rec.v;
         dg.xh ^= rec.h;
         if (MODE == MODE_SUPERKMER) {
