@@ -88,6 +88,13 @@ def valu_ceiling(model, kernels, bases, seconds, ghz):
             "kernels": parts, "issue_cycles": model["issue_cycles"], "source": model["provenance"]}
 
 
+def kernel_time_fits(avg_kernel_ms, launches, steps, ms_per_step, slack=1.01):
+    """The timed kernel's launches are serialised on the device (one stream, or two lanes whose pass-1 kernels wait for each other), so
+    their summed duration cannot exceed the wall time of the steps they ran in.  A figure that does was measured while two instances
+    shared the chip: each event pair then spans a stretched duration and the roofline fraction derived from it means nothing."""
+    return avg_kernel_ms * launches / max(steps, 1) <= ms_per_step * slack
+
+
 def free_port():
     import socket
 
@@ -155,6 +162,8 @@ def main():
     ap.add_argument("--no-other-configs", action="store_true")
     ap.add_argument("--no-next-rows", action="store_true")
     ap.add_argument("--no-h2d", action="store_true", help="skip the upload-inclusive companion figure")
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
+                    help="context switch for A/B runs (bl_ctx_set_option: exact_windows, position_tiled, emit_lds_bytes); repeatable; named in the JSON line")
     ap.add_argument("--other-gbp", type=float, default=0.0, help="size of the other configs (0 = as BASELINE.json states them: 10 / 50 / 50 Gbp)")
     args = ap.parse_args()
 
@@ -203,6 +212,11 @@ def main():
     dev = local_rank if (world > 1 and not rehearse) else 0
     torch.cuda.set_device(dev)
     ctx = biolib_amd.Context(dev, torch_stream=False, lanes=args.lanes)  # own streams; outputs below are double-buffered
+    opts = {}
+    for item in args.opt:
+        name, _, value = item.partition("=")
+        ctx.set_option(name, int(value))
+        opts[name] = int(value)
 
     n_reads = int(args.gbp * 1e9) // READ_LEN
     n_bases = n_reads * READ_LEN
@@ -320,6 +334,14 @@ def main():
             both = (c3["count_kernel"]["hbm_bytes_per_base"] + c3["emit_kernel"]["hbm_bytes_per_base"]) * bases_per_launch
             hbm_actual = {"bytes_per_range_both_passes": int(both), "GBps": round(both / range_s / 1e9, 1), "frac_of_8TBps": round(both / range_s / 1e9 / HBM_PEAK_GBPS, 4)}
             traffic_note = prof["provenance"]
+        # the kernel the events bracketed, by the path the options select (launch_count_frl / launch_count_mode in bl_kernels.hip)
+        if opts.get("position_tiled"):
+            kernel_label = "bl::scan_count_kernel<MODE_MINIMIZER,W=11,U=31,C=1> (pass 1 of 2, position-tiled)"
+        elif opts.get("exact_windows"):
+            kernel_label = "bl::scan_count_frl_kernel<MODE_MINIMIZER,W=11,NS=15,U=31,L=150,C=1> (pass 1 of 2, read-tiled, windows decided on the hashes)"
+        else:
+            kernel_label = ("bl::scan_count_frl_kernel<MODE_MINIMIZER,W=11,NS=15,U=31,L=150,C=1,APPROX> + scan_redo_frl_kernel "
+                            "(pass 1 of 2, read-tiled, windows decided on murmur64_top; the events bracket both launches)")
         out = {
             "metric": "Gbp/s minimizer-scanned (k=31,w=11)",
             "value": round(value, 3),
@@ -345,6 +367,7 @@ def main():
                 "bases_per_gpu": n_bases, "read_len": READ_LEN, "reads_per_gpu": n_reads, "ranges_per_step": len(ranges),
                 "bases_per_launch": int(bases_per_launch), "outputs": "value,position,hash (u64 each) materialised in HBM", "lanes": args.lanes,
                 "sharding": f"{n_gpus} independent shard(s), seed 42+rank",
+                **({"context_options": opts} if opts else {}),
             },
             "records_per_step": total_count,
             "xor_hash": xor_hash,
@@ -353,8 +376,10 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5),
                 "traffic": traffic, "traffic_stale": traffic_stale, "traffic_source": traffic_note,
-                "kernel": "bl::scan_count_frl_kernel<MODE_MINIMIZER,W=11,NS=15,U=31,L=150,C=1,APPROX> (pass 1 of 2, read-tiled, windows decided on murmur64_top)", "avg_kernel_ms": round(avg_kernel_s * 1e3, 4),
+                "kernel": kernel_label, "avg_kernel_ms": round(avg_kernel_s * 1e3, 4),
                 "launches_timed": launches, "algorithmic_bytes_per_launch": int(bases_per_launch),
+                "kernel_ms_per_step": round(avg_kernel_s * 1e3 * launches / args.steps, 3),
+                "kernel_time_fits_step": kernel_time_fits(avg_kernel_s * 1e3, launches, args.steps, t_max / args.steps * 1e3),
                 "note": "VALU-issue bound before HBM: 6 x 64-bit multiplies per 31-mer (MurmurHash3_x64_128), see roofline.valu and DESIGN.md"
                         + ("; with 2 lanes this kernel's duration includes sharing the SIMDs with the previous range's scan_emit_kernel (alone: --lanes 1)"
                            if args.lanes == 2 else ""),
@@ -371,6 +396,7 @@ def main():
                 rd, cp = ctx.probe_hbm(8 << 30, 5)
                 out["roofline"]["peak_measured"] = {"read_GBps": round(rd, 1), "copy_GBps": round(cp, 1),
                                                     "note": "this device, 8 GiB buffers: read-only stream kernel / DtoD copy (read+write bytes)"}
+                out["roofline"]["frac_of_measured_read_peak"] = round(achieved / rd, 5)
             except Exception as e:  # a probe failure must not lose the bench line
                 out["roofline"]["peak_measured"] = {"error": str(e)}
         if allreduce_ms is not None:
@@ -478,7 +504,11 @@ def other_configs(ctx, args, model):
     CH = 1_500_000_000
     res = {}
 
-    def timed(issue, n_bases, kernels, kernel_name, steps=2):
+    def timed(issue, n_bases, kernels, kernel_name, steps=2, lanes=None):
+        # lanes=1: a kernel that IS the whole scan (C2's dense k-mer kernel) gains nothing from two lanes and, run on two, shares the chip
+        # with its own next launch: every event pair would then time a stretched kernel
+        if lanes is not None:
+            ctx.set_option("lanes", lanes)
         issue()
         ctx.sync()
         ctx.kernel_timing(True)
@@ -492,11 +522,17 @@ def other_configs(ctx, args, model):
         ghz = ctx.clock_probe_finish(probe)
         kms, launches = ctx.kernel_time()
         ctx.kernel_timing(False)
+        if lanes is not None:
+            ctx.set_option("lanes", args.lanes)
         per_launch = n_bases * steps / max(launches, 1)
         k_s = kms / 1e3 / max(launches, 1)
         achieved = per_launch / k_s / 1e9
+        fits = kernel_time_fits(k_s * 1e3, launches, steps, dt / steps * 1e3)
+        if not fits:
+            print(f"# {kernel_name}: {launches} launches x {k_s * 1e3:.3f} ms do not fit {steps} steps of {dt / steps * 1e3:.3f} ms: kernel figure invalid", file=sys.stderr)
         return {"value": round(n_bases * steps / dt / 1e9, 2), "unit": "Gbp/s", "bases": n_bases, "steps": steps, "ms_per_step": round(dt / steps * 1e3, 3),
-                "kernel": kernel_name, "avg_kernel_ms": round(k_s * 1e3, 4), "launches_timed": launches,
+                "kernel": kernel_name, "avg_kernel_ms": round(k_s * 1e3, 4), "launches_timed": launches, "lanes": lanes if lanes is not None else args.lanes,
+                "kernel_ms_per_step": round(k_s * 1e3 * launches / steps, 3), "kernel_time_fits_step": fits,
                 "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5),
                              "valu": valu_ceiling(model, kernels, per_launch, dt / max(n_ranges, 1), ghz)}}
 
@@ -511,7 +547,7 @@ def other_configs(ctx, args, model):
             k += 1
         return k
 
-    res["C2_kmer_hash_10Gbp"] = timed(c2, n, ["c2_kmer"], "bl::kmer_kernel")
+    res["C2_kmer_hash_10Gbp"] = timed(c2, n, ["c2_kmer"], "bl::kmer_kernel", lanes=1)
     b.close()
 
     # C4 / C5: 50 Gbp of 10-kbp reads
@@ -729,6 +765,9 @@ def cpu_baseline(np, ctx, batch, n_bases):
         t = time.perf_counter()
         px = O.kmer_digest(s, np.array([0, nr], np.uint64), 31, True, 0, drop_last=True, threads=1)
         tp = time.perf_counter() - t
+        out["port_vs_reference_single_thread"] = round((nr / tp) / (nr / tr), 3)
+        out["port_vs_reference_note"] = ("cpu_baseline.kind is 'port': on the part of the path the reference can run (C2: kmer_view + hash64), one thread, the port "
+                                         "runs at this fraction of the reference's own rate — any GPU/CPU ratio read off `value` flatters the GPU by its inverse")
         out["reference_c2_anchor"] = {"kind": "reference", "path": "kmer_view<uint64_t> canonical k=31 + hash64 per k-mer, `it != cend()` idiom", "cores": 1,
                                       "sample_Mbp": nr // 1_000_000, "reference_Gbps": round(nr / tr / 1e9, 4), "port_Gbps": round(nr / tp / 1e9, 4),
                                       "xor_of_hashes_equal": bool(rx == px["xor_hash"])}

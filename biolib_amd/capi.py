@@ -18,7 +18,7 @@ SYMBOLS = [
     "bl_last_error", "bl_version", "bl_device_count", "bl_ctx_create", "bl_ctx_destroy", "bl_ctx_set_stream", "bl_ctx_use_own_streams", "bl_ctx_sync",
     "bl_batch_upload", "bl_batch_upload_reads", "bl_batch_from_device", "bl_batch_synth", "bl_batch_destroy", "bl_batch_n_bases", "bl_batch_n_seqs",
     "bl_batch_device_bases", "bl_batch_download", "bl_batch_set_origin", "bl_batch_origin", "bl_scan_kmers", "bl_scan_minimizers", "bl_scan_hash_sample", "bl_scan_super_kmers", "bl_scan_super_kmer_records", "bl_scan_syncmers", "bl_sort_unique_u64", "bl_jaccard_sorted_u64", "bl_partition_u64", "bl_sort_u64", "bl_count_sorted_u64", "bl_probe_hbm", "bl_clock_probe_start", "bl_clock_probe_finish", "bl_ctx_set_lanes", "bl_pack_super_kmers", "bl_count_super_kmers", "bl_partition_records", "bl_expand_super_kmers",
-    "bl_ctx_last_scan_ms", "bl_ctx_set_exact_windows", "bl_ctx_kernel_timing", "bl_ctx_kernel_time", "bl_ctx_mark", "bl_ctx_mark_times", "bl_reader_open", "bl_reader_open_threads", "bl_reader_kind", "bl_reader_next_text", "bl_reader_next_batch_device", "bl_reader_close", "bl_reader_next_record",
+    "bl_ctx_last_scan_ms", "bl_ctx_set_exact_windows", "bl_ctx_set_option", "bl_ctx_kernel_timing", "bl_ctx_kernel_time", "bl_ctx_mark", "bl_ctx_mark_times", "bl_reader_open", "bl_reader_open_threads", "bl_reader_kind", "bl_reader_next_text", "bl_reader_next_batch_device", "bl_reader_close", "bl_reader_next_record",
     "bl_reader_next_batch", "bl_reader_last_batch", "bl_reader_last_name", "bl_batch_from_text", "bl_run_file_name", "bl_write_run_u64", "bl_write_vector_u64", "bl_file_count_u64", "bl_read_file_u64_host", "bl_read_file_u64", "bl_merge_runs_u64", "bl_count_allreduce",
     "bl_device_alloc", "bl_device_free", "bl_copy_to_host", "bl_copy_to_device", "bl_hash64_u64", "bl_bgzf_walk", "bl_bgzf_inflate", "bl_host_alloc", "bl_host_free", "bl_reader_open_shard", "bl_reader_shard_range",
 ]
@@ -102,6 +102,8 @@ def lib():
     L.bl_scan_syncmers.argtypes = [vp, vp, u64, u64, u32, u32, u32, u32, u64, u32, vp, u64, C.POINTER(Result)]
     L.bl_ctx_last_scan_ms.argtypes = [vp, C.POINTER(C.c_float)]
     L.bl_ctx_set_exact_windows.argtypes = [vp, C.c_int]
+    if "BIOLIB_AMD_LIB" not in os.environ or hasattr(L, "bl_ctx_set_option"):
+        L.bl_ctx_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
     L.bl_ctx_kernel_timing.argtypes = [vp, C.c_int]
     L.bl_ctx_kernel_time.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(u64)]
     L.bl_ctx_mark.argtypes = [vp]

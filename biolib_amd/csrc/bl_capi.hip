@@ -103,6 +103,7 @@ struct bl_ctx {
     bool timed = false;
     // optional per-launch timing of the main scan kernel alone (bl_ctx_kernel_timing)
     bool exact_windows = false;  // bl_ctx_set_exact_windows
+    bool position_tiled = false; // bl_ctx_set_option("position_tiled"): never the read-tiled layout
     bool ktiming = false;
     std::vector<hipEvent_t> ev_pool;                       // free events
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_open;  // recorded, not yet read
@@ -470,8 +471,6 @@ int bl_ctx_create(int device, bl_ctx** out)
     }
     c->cur = &c->lanes[0];
     c->stream = c->lanes[0].own;
-    if (const char* e = std::getenv("BL_LANES")) c->n_lanes = std::atoi(e) == 2 ? 2 : 1;
-    if (const char* e = std::getenv("BL_EMIT_LDS")) c->emit_lds_per_wg = (uint32_t)std::atoi(e);
     *out = c;
     return BL_OK;
 }
@@ -563,6 +562,23 @@ int bl_ctx_set_exact_windows(bl_ctx* c, int on)
     if (!c) return fail(BL_ERR_INVALID, "ctx is NULL");
     c->exact_windows = on != 0;
     return BL_OK;
+}
+
+int bl_ctx_set_option(bl_ctx* c, const char* name, int64_t value)
+{
+    if (!c || !name) return fail(BL_ERR_INVALID, "bl_ctx_set_option: NULL argument");
+    const std::string n(name);
+    if (n == "exact_windows" && (value == 0 || value == 1)) return bl_ctx_set_exact_windows(c, (int)value);
+    if (n == "lanes") return bl_ctx_set_lanes(c, (int)value);
+    if (n == "position_tiled" && (value == 0 || value == 1)) {
+        c->position_tiled = value != 0;
+        return BL_OK;
+    }
+    if (n == "emit_lds_bytes" && value >= 0 && value <= 160 * 1024) {
+        c->emit_lds_per_wg = (uint32_t)value;
+        return BL_OK;
+    }
+    return fail(BL_ERR_INVALID, "bl_ctx_set_option: unknown name or value out of range: " + n);
 }
 
 int bl_ctx_kernel_timing(bl_ctx* c, int enable)
@@ -879,9 +895,8 @@ static int scan_windows(int mode, bl_ctx* c, const bl_batch* b, uint64_t first, 
     p.exact_windows = c->exact_windows ? 1 : 0;
     bl::plan_scan(mode, (int64_t)first, (int64_t)end, (int)w, p);
     // fixed-length short reads, range aligned to reads: the read-tiled layout (no start bits, no hashing of positions
-    // that cannot start a unit) when it pays; BL_NO_FRL=1 keeps the position-tiled kernels (A/B measurements)
-    static const bool no_frl = std::getenv("BL_NO_FRL") != nullptr;
-    if (b->read_len && !no_frl && !p.use_threshold && bl::frl_width_built(mode, (int)w)) {
+    // that cannot start a unit) when it pays; bl_ctx_set_option("position_tiled", 1) keeps the position-tiled kernels (A/B measurements)
+    if (b->read_len && !c->position_tiled && !p.use_threshold && bl::frl_width_built(mode, (int)w)) {
         const bool tuned = mode == bl::MODE_MINIMIZER && w == 11 && unit == 31 && (flags & BL_FLAG_CANONICAL) && b->read_len == 150;
         bl::plan_scan_frl((int64_t)first, (int64_t)end, (int64_t)b->n_bases, (int64_t)b->read_len, (int)unit, (int)w, tuned ? 0 : bl::S, p);
     }

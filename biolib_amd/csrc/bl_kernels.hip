@@ -417,8 +417,9 @@ __global__ __launch_bounds__(TPB) void scan_emit_kernel(const ScanParams pin, Gr
     if (U != 0) p.unit = U;
     if (C >= 0) p.canonical = C;
     if (FRL >= 0) p.frl = FRL;
-    // the thread's digest words live in LDS between tiles (six dwords per thread, read-xor-written once per tile): kept in registers across
-    // the loop they, and what the compiler then hoists out of it, take the kernel from 23 registers to 38-46
+#ifndef BL_EMIT_ACC_REGS
+    // the thread's digest words live in LDS between tiles (six dwords per thread, read-xor-written once per tile): in registers they
+    // cost the kernel 34 instead of 28, i.e. 40 allocated instead of 32
     __shared__ uint32_t acc[6][TPB];
 #pragma unroll
     for (int i = 0; i < 6; ++i) acc[i][tid] = 0;
@@ -439,6 +440,12 @@ __global__ __launch_bounds__(TPB) void scan_emit_kernel(const ScanParams pin, Gr
         dg.xh = ((unsigned long long)acc[3][tid] << 32) | acc[2][tid];
     }
     dg.xp = ((unsigned long long)acc[5][tid] << 32) | acc[4][tid];
+#else
+    Digest dg{0, 0, 0};
+    const uint32_t t0 = blockIdx.x * BL_EMIT_TILES;
+#pragma unroll 1
+    for (uint32_t k = 0; k < BL_EMIT_TILES && t0 + k < g.count; ++k) emit_tile<MODE>(p, codes[k & 1], g.first + t0 + k, tid, dg);
+#endif
 
     // digest: wave reduce (DPP xor-scan), then one set of atomics per WAVE into a shard line.  Measured alternatives: an LDS stage
     // with two more barriers per tile (no gain); folding the 256 threads' words with LDS atomics on three addresses (-30 % on the
@@ -649,8 +656,7 @@ static hipError_t launch_count_frl(int mode, const ScanParams& p, GroupRange g, 
 {
     const dim3 grid(g.count), block(TPB);
     if (mode == MODE_MINIMIZER && p.w == 11 && p.unit == 31 && p.canonical && p.read_len == 150 && p.ns == 15 && p.rpw == 8) {
-        static const bool exact = std::getenv("BL_NO_APPROX") != nullptr;  // A/B runs: windows decided on the hashes themselves
-        if (p.redo_list && g.first == 0 && !exact && !p.exact_windows) {  // BASELINE C3
+        if (p.redo_list && g.first == 0 && !p.exact_windows) {  // BASELINE C3 (exact_windows, bl_ctx_set_exact_windows: windows decided on the hashes themselves)
             hipLaunchKernelGGL((scan_count_frl_kernel<MODE_MINIMIZER, 11, 15, 31, 150, 1, true>), grid, block, 0, stream, p, g);
             hipLaunchKernelGGL((scan_redo_frl_kernel<MODE_MINIMIZER, 11, 15, 31, 150, 1>), dim3(g.count < 512u ? g.count : 512u), block, 0, stream, p);
         } else {
@@ -692,9 +698,8 @@ static hipError_t launch_count_mode(const ScanParams& p, GroupRange g, hipStream
     }
     if (MODE == MODE_SYNCMER && p.w == 21 && p.unit == 11 && p.canonical) {
         const bool closed = (p.soff == 0 && p.eoff == 20) || (p.soff == 20 && p.eoff == 0);
-        static const bool no_cs = std::getenv("BL_NO_CLOSED") != nullptr;  // A/B runs: the argmin form
         const unsigned redo_grid = g.count < 512u ? g.count : 512u;
-        if (closed && !no_cs && !p.exact_windows && p.redo_list && g.first == 0) {  // BASELINE C5
+        if (closed && !p.exact_windows && p.redo_list && g.first == 0) {  // BASELINE C5 (exact_windows: the argmin form)
             hipLaunchKernelGGL((scan_count_kernel<MODE_SYNCMER, 21, 11, 1, 1>), grid, block, 0, stream, p, g);
             hipLaunchKernelGGL((scan_redo_kernel<MODE_SYNCMER, 21, 11, 1>), dim3(redo_grid), block, 0, stream, p);
 #ifndef BL_NO_SY2
@@ -753,7 +758,11 @@ hipError_t launch_scan_count(int mode, const ScanParams& p, GroupRange g, hipStr
 template <int MODE>
 static void launch_emit_mode(const ScanParams& p, GroupRange g, hipStream_t stream, uint32_t lds_per_wg)
 {
+#ifndef BL_EMIT_ACC_REGS
+    const uint32_t have = (uint32_t)((2 * NCHUNK + 6 * TPB) * sizeof(uint32_t));  // the kernel's static LDS: two code buffers, the digest words
+#else
     const uint32_t have = (uint32_t)(2 * NCHUNK * sizeof(uint32_t));
+#endif
     const uint32_t pad = lds_per_wg > have ? lds_per_wg - have : 0;
     const dim3 grid((g.count + BL_EMIT_TILES - 1) / BL_EMIT_TILES), block(TPB);
     if (MODE == MODE_MINIMIZER && p.frl && p.unit == 31 && p.canonical) {  // BASELINE C3

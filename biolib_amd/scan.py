@@ -90,6 +90,10 @@ class Context:
         Result.redone counts the tiles a default scan had to decide a second time."""
         check(self._lib.bl_ctx_set_exact_windows(self._h, 1 if on else 0))
 
+    def set_option(self, name, value):
+        """tuning / test switches by name (bl_ctx_set_option: "exact_windows", "lanes", "position_tiled", "emit_lds_bytes")"""
+        check(self._lib.bl_ctx_set_option(self._h, name.encode(), int(value)))
+
     def kernel_timing(self, enable=True):
         check(self._lib.bl_ctx_kernel_timing(self._h, 1 if enable else 0))
 

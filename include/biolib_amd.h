@@ -178,6 +178,15 @@ int bl_scan_syncmers(bl_ctx* ctx, const bl_batch* batch, uint64_t first, uint64_
 /* on != 0: every later scan on this context decides its windows on the 64-bit hashes themselves — no pass 1 on the approximate high
  * dword, no closed-syncmer form (§5.4).  Same records, 2-4 % slower; for checks and A/B measurements. */
 int bl_ctx_set_exact_windows(bl_ctx* ctx, int on);
+/* Tuning and test switches of a context, by name (BL_ERR_INVALID for a name or value it does not know).  None of them changes a result.
+ *   "exact_windows"   0 / 1       = bl_ctx_set_exact_windows
+ *   "lanes"           1 / 2       = bl_ctx_set_lanes
+ *   "position_tiled"  0 / 1       1: batches of fixed-length reads are scanned by the position-tiled kernels too (default 0: read-tiled
+ *                                 where that layout applies)
+ *   "emit_lds_bytes"  0 or bytes  two-lane contexts: LDS footprint the record pass's workgroups are padded to, which caps how many of
+ *                                 them a CU holds beside the next scan's hashing pass (0: the built-in default per scan kind)
+ * The library reads no environment variable on the scan path. */
+int bl_ctx_set_option(bl_ctx* ctx, const char* name, int64_t value);
 
 /* Elapsed GPU time of the most recent scan call on this context, from HIP events recorded on the
  * context's stream around its kernels (milliseconds).  Synchronises. */

@@ -84,3 +84,11 @@ def test_bench_refuses_a_line_with_fewer_ranks_than_asked_for():
     env.update(WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 2 and "{" not in r.stdout and "WORLD_SIZE=1" in r.stderr
+
+
+def test_kernel_time_must_fit_the_step_it_ran_in():
+    """VERDICT r03 weak #4 on its own canned line: C2 timed on two lanes gave avg_kernel_ms 4.4005 x 7 launches per step against
+    ms_per_step 16.0 — not a kernel duration; the driver's C3 line (34 launches x 2.9389 ms in 101.6 ms) is one"""
+    assert not bench.kernel_time_fits(4.4005, 14, 2, 16.0)
+    assert bench.kernel_time_fits(2.585, 14, 2, 18.2)
+    assert bench.kernel_time_fits(2.9389, 34 * 20, 20, 101.6)

@@ -426,3 +426,32 @@ def test_upload_reads_origin_and_markers(ctx):
     assert len(t) == 4 and t[0] >= 0 and all(y >= x for x, y in zip(t[:-1], t[1:])) and t[-1] > 0
     assert c.mark_times() == []  # forgotten
     big.close(); c.close()
+
+
+def test_approximate_pass1_soak_ten_batches():
+    """the decisions pass 1 makes on an approximation of the hash's high dword (murmur64_top) and the closed-syncmer form, against the
+    exact forms, on 10 batches of 1.5 Gbp per scan kind (tests/perf/approx_soak.py): every digest identical, and the shipped form did
+    meet — and hand to the exact kernels — tiles it could not decide.  The per-batch lines are kept (gpurun_out/r4/approx_soak.jsonl,
+    copied to profiles/ when a round's numbers are committed)."""
+    import json
+    import os
+    import sys
+
+    import biolib_amd as B
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tests", "perf"))
+    import approx_soak
+
+    c = B.Context(0, torch_stream=False)
+    lines, bad, redone = approx_soak.soak(c, 10, 1_500_000_000)
+    c.close()
+    out = os.path.join(root, "gpurun_out", "r4")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "approx_soak.jsonl"), "w") as f:
+        for d in lines:
+            f.write(json.dumps(d) + "\n")
+        f.write(json.dumps({"batches": 10, "bases_per_batch": 1_500_000_000, "mismatches": bad, "tiles_decided_again": redone}) + "\n")
+    assert bad == 0 and len(lines) == 20
+    assert redone > 0
+    assert all(d["count"] > 0 and d["status"] == 0 for d in lines)

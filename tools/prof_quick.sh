@@ -1,6 +1,6 @@
 #!/bin/bash
 # Quick profile of one lane of the C3 scan on the GPU box: kernel stats + three SQ counter passes (separate runs).
-# BL_NO_FRL=1 in the environment profiles the position-tiled kernels instead.
+# (add `--opt position_tiled=1` to CMD to profile the position-tiled kernels instead)
 set -o pipefail
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/r2/prof1

@@ -7,8 +7,8 @@ rm -rf $OUT && mkdir -p $OUT
 timeout -k 10 600 python -m pytest ${@:-tests/test_gpu_parity.py tests/test_gpu_edges.py} -m gpu -x -q > $OUT/tests.log 2>&1 || { tail -30 $OUT/tests.log; exit 1; }
 tail -2 $OUT/tests.log
 for v in approx exact approx exact; do
-  if [ $v = exact ]; then export BL_NO_APPROX=1; else unset BL_NO_APPROX; fi
-  timeout -k 10 300 python bench.py --no-cpu-baseline --no-next-rows --no-h2d --steps 5 > $OUT/bench_$v.json 2> $OUT/bench_$v.err || { tail -5 $OUT/bench_$v.err; exit 1; }
+  if [ $v = exact ]; then OPT="--opt exact_windows=1"; else OPT=""; fi
+  timeout -k 10 300 python bench.py $OPT --no-cpu-baseline --no-next-rows --no-h2d --steps 5 > $OUT/bench_$v.json 2> $OUT/bench_$v.err || { tail -5 $OUT/bench_$v.err; exit 1; }
   python - <<PY
 import json
 d = json.loads(open("$OUT/bench_$v.json").read().strip().splitlines()[-1])

@@ -6,8 +6,8 @@ OUT=$ROOT/gpurun_out/r3/approx2
 rm -rf $OUT && mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for v in approx exact approx exact; do
-  if [ $v = exact ]; then export BL_NO_APPROX=1; else unset BL_NO_APPROX; fi
-  timeout -k 10 300 python3 $ROOT/bench.py --no-cpu-baseline --no-next-rows --no-h2d --no-other-configs --lanes 1 --gbp 12 --steps 3 > $OUT/l1_$v.json 2> $OUT/l1_$v.err || { tail -5 $OUT/l1_$v.err; exit 1; }
+  if [ $v = exact ]; then OPT="--opt exact_windows=1"; else OPT=""; fi
+  timeout -k 10 300 python3 $ROOT/bench.py $OPT --no-cpu-baseline --no-next-rows --no-h2d --no-other-configs --lanes 1 --gbp 12 --steps 3 > $OUT/l1_$v.json 2> $OUT/l1_$v.err || { tail -5 $OUT/l1_$v.err; exit 1; }
   python3 - <<PY
 import json
 d = json.loads(open("$OUT/l1_$v.json").read().strip().splitlines()[-1])
@@ -16,8 +16,8 @@ print("$v", "value", d["value"], "kernel ms", r.get("avg_kernel_ms"), "clock", r
 PY
 done
 for v in approx exact; do
-  if [ $v = exact ]; then export BL_NO_APPROX=1; else unset BL_NO_APPROX; fi
-  timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_WAVES --output-format csv -d $OUT/pmc_$v -o p -- python3 $ROOT/bench.py --steps 1 --warmup 0 --lanes 1 --gbp 6 --no-cpu-baseline --no-next-rows --no-h2d --no-other-configs > $OUT/pmc_$v.log 2>&1 || { tail -5 $OUT/pmc_$v.log; exit 1; }
+  if [ $v = exact ]; then OPT="--opt exact_windows=1"; else OPT=""; fi
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_WAVES --output-format csv -d $OUT/pmc_$v -o p -- python3 $ROOT/bench.py $OPT --steps 1 --warmup 0 --lanes 1 --gbp 6 --no-cpu-baseline --no-next-rows --no-h2d --no-other-configs > $OUT/pmc_$v.log 2>&1 || { tail -5 $OUT/pmc_$v.log; exit 1; }
   python3 - <<PY
 import csv, glob, collections
 f = glob.glob("$OUT/pmc_$v/**/*counter_collection.csv", recursive=True)[0]

@@ -7,7 +7,7 @@ timeout -k 10 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_edges
 tail -2 $OUT/tests.log
 for r in 1 2; do for v in "$@"; do
   if [ $v = HEAD ]; then unset BIOLIB_AMD_LIB; else export BIOLIB_AMD_LIB=$ROOT/biolib_amd/lib/ab/$v.so; fi
-  BL_NO_FRL=1 timeout -k 10 300 python bench.py --no-cpu-baseline --no-other-configs --no-h2d --steps 4 --gbp 25 > $OUT/${v}_$r.json 2> $OUT/${v}_$r.err || { tail -3 $OUT/${v}_$r.err; exit 1; }
+  timeout -k 10 300 python bench.py --opt position_tiled=1 --no-cpu-baseline --no-other-configs --no-h2d --steps 4 --gbp 25 > $OUT/${v}_$r.json 2> $OUT/${v}_$r.err || { tail -3 $OUT/${v}_$r.err; exit 1; }
   python - <<PY
 import json
 d = json.loads(open("$OUT/${v}_$r.json").read().strip().splitlines()[-1]); r = d["roofline"]

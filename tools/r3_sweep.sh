@@ -5,7 +5,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/r3/sweep_$TAG; mkdir -p $OUT
 for r in 1 2; do
 for v in "$@"; do
-  BL_EMIT_LDS=$v timeout -k 10 300 python bench.py --no-cpu-baseline --no-other-configs --no-h2d --steps 6 > $OUT/l$v.$r.json 2> $OUT/l$v.$r.err || { tail -3 $OUT/l$v.$r.err; exit 1; }
+  timeout -k 10 300 python bench.py --opt emit_lds_bytes=$v --no-cpu-baseline --no-other-configs --no-h2d --steps 6 > $OUT/l$v.$r.json 2> $OUT/l$v.$r.err || { tail -3 $OUT/l$v.$r.err; exit 1; }
   python - <<PY
 import json
 d = json.loads(open("$OUT/l$v.$r.json").read().strip().splitlines()[-1]); r = d["roofline"]
