@@ -681,6 +681,36 @@ def next_rows(ctx):
                                "workload": "FASTQ text (binned qualities), zlib level 6, 65280-byte BGZF members, inflate + CRC-32 on the device"}
     except Exception as e:
         res["bgzf_inflate"] = {"error": repr(e)[:200]}
+    try:  # file -> scanned batches, the way the reference's drivers start (tests/test_kmer_view.cpp:23-42 read a file, then iterate): the reader's
+          # device path (text spans -> H2D -> parsed on the GPU; BGZF members inflated on the GPU) with the minimizer scan behind every batch
+        import tempfile
+        times = 6  # the text six times over (records and BGZF members concatenate): ~370 MB of text, 167 Mbp
+        with tempfile.TemporaryDirectory() as d:
+            for name, blob in (("plain_fastq_to_scan", text), ("bgzf_file_to_scan", data)):
+                path = os.path.join(d, name)
+                with open(path, "wb") as f:
+                    for _ in range(times):
+                        f.write(blob)
+                    if name.startswith("bgzf"):
+                        f.write(b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00\x1b\x00\x03\x00\x00\x00\x00\x00\x00\x00\x00\x00")  # BGZF end-of-file marker
+                best, ok = None, True
+                for _ in range(2):
+                    ctx.sync(); t0 = time.perf_counter()
+                    r = B.Reader(path)
+                    n_seqs = n_b = cnt = 0
+                    for batch in r.device_batches(ctx):
+                        n_seqs += batch.n_seqs; n_b += batch.n_bases
+                        cnt += int(batch.minimizers_raw(UNIT, W, SEED, B.FLAG_CANONICAL | B.FLAG_SYNC).count)
+                        batch.close()
+                    ctx.sync(); dt = time.perf_counter() - t0
+                    r.close()
+                    ok = ok and n_seqs == n_reads * times and n_b == n_reads * L * times
+                    best = dt if best is None else min(best, dt)
+                res[name] = {"value": round(n_reads * L * times / best / 1e9, 2), "unit": "Gbp/s", "file_MB": round(os.path.getsize(path) / 1e6), "text_GB_per_s": round(len(text) * times / best / 1e9, 2),
+                             "minimizers": cnt, "reads_and_bases_as_written": bool(ok),
+                             "path": "file -> bl_reader_next_batch_device (host reads the file, " + ("members inflated and" if name.startswith("bgzf") else "text") + " parsed on the GPU) -> bl_scan_minimizers per batch, best of 2"}
+    except Exception as e:
+        res["file_to_scan"] = {"error": repr(e)[:200]}
     try:  # a plain gzip file (ONE deflate stream per member, no BGZF) -> device batches: the host decodes the stream in parts on all its cores
         import tempfile
         packed = zlib.compressobj(6, zlib.DEFLATED, 31)

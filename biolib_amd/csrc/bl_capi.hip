@@ -897,8 +897,7 @@ static int scan_windows(int mode, bl_ctx* c, const bl_batch* b, uint64_t first, 
     // fixed-length short reads, range aligned to reads: the read-tiled layout (no start bits, no hashing of positions
     // that cannot start a unit) when it pays; bl_ctx_set_option("position_tiled", 1) keeps the position-tiled kernels (A/B measurements)
     if (b->read_len && !c->position_tiled && !p.use_threshold && bl::frl_width_built(mode, (int)w)) {
-        const bool tuned = mode == bl::MODE_MINIMIZER && w == 11 && unit == 31 && (flags & BL_FLAG_CANONICAL) && b->read_len == 150;
-        bl::plan_scan_frl((int64_t)first, (int64_t)end, (int64_t)b->n_bases, (int64_t)b->read_len, (int)unit, (int)w, tuned ? 0 : bl::S, p);
+        bl::plan_scan_frl_for(mode, (int64_t)first, (int64_t)end, (int64_t)b->n_bases, (int64_t)b->read_len, (int)unit, (int)w, (flags & BL_FLAG_CANONICAL) != 0, p);
     }
     if (!p.frl) {
         rc = ensure_start_bits(c, b);

@@ -14,6 +14,9 @@
 #ifndef BL_CS_WAVES
 #define BL_CS_WAVES 3  // waves per SIMD the closed-syncmer kernel is compiled for
 #endif
+#ifndef BL_CSRT_WAVES
+#define BL_CSRT_WAVES 3  // ... and the closed-syncmer kernels for a window count given at run time
+#endif
 
 namespace bl {
 
@@ -138,7 +141,8 @@ __device__ __forceinline__ void fill_list(uint16_t* dst, const uint16_t* src, ui
 // tile's record counts and u16 lists in global scratch.  Tiles are independent: no ticket, no
 // inter-workgroup wait, any dispatch order.
 // SY (syncmer scans): 0 = tagged argmins with the exact form inline (also what scan_redo_kernel runs), 1 = closed syncmers
-// (sliding minima), 2 = tagged argmins WITHOUT the exact form: a tile that met a prefix tie is listed for scan_redo_kernel
+// (sliding minima), 2 = tagged argmins WITHOUT the exact form: a tile that met a prefix tie is listed for scan_redo_kernel;
+// W = -8 / -16 with SY = 1: closed syncmers for a window count given at run time (phase_sync_closed_rt), two size groups
 template <int MODE, int W, int SY = 0, int U = 0>
 __device__ __forceinline__ void count_tile(const ScanParams& p, TileShared<MODE, W>& sh, uint32_t tile, int tid)
 {
@@ -167,7 +171,9 @@ __device__ __forceinline__ void count_tile(const ScanParams& p, TileShared<MODE,
     else phase_hash<MODE, W, (MODE != MODE_SYNCMER && U >= 1 && U <= 16 ? U : 0), U == 0>(p, sh, tid, st);
 
     uint32_t packed;
-    if (MODE == MODE_SYNCMER && CS) {  // closed syncmers: sliding minima of the high dwords, no argmin
+    if constexpr (MODE == MODE_SYNCMER && CS && W < 0) {  // closed syncmers for any (k, s): w by run time (W = -8: w <= 17, W = -16: 18 <= w <= 32)
+        packed = phase_sync_closed_rt<MODE, (W == -16 ? -16 : -8)>(p, reinterpret_cast<TileShared<MODE, (W == -16 ? -16 : -8)>&>(sh), tid, q0, st, nullptr);
+    } else if (MODE == MODE_SYNCMER && CS) {  // closed syncmers: sliding minima of the high dwords, no argmin
         bool undecided;
         packed = phase_sync_closed<MODE, (W > 1 ? W : 2), (DIRECT ? U : 0), AP>(p, reinterpret_cast<TileShared<MODE, (W > 1 ? W : 2)>&>(sh), tid, q0, st, nullptr, undecided);
         // equal high dwords somewhere in the wave: the tile is listed and counted again, in the exact form, by scan_redo_kernel — a
@@ -315,7 +321,7 @@ __device__ __forceinline__ void emit_tile(const ScanParams& p, uint32_t* codes, 
 // (constant shifts and masks in the roller, no strand selects).  U = 0 / C = -1: taken from the arguments.
 // SY: the syncmer form (count_tile): 1 = closed syncmers (offsets {0, W - 1}; phase_sync_closed), 2 = argmins with the exact form deferred
 template <int MODE, int W, int U, int C, int SY = 0>
-__global__ __launch_bounds__(TPB, (SY == 1 ? BL_CS_WAVES : SY == 2 ? BL_SY2_WAVES : (MODE == MODE_SYNCMER && W > 0 ? BL_SY0_WAVES : MODE == MODE_SYNCMER || (MODE == MODE_SUPERKMER && W == -32) ? 2 : (W == -32 || (W < 0 && MODE == MODE_SUPERKMER) ? 3 : (W == -16 ? 5 : (W < 0 ? 4 : (W <= 11 ? 5 : 4))))))) void scan_count_kernel(const ScanParams pin, GroupRange g)
+__global__ __launch_bounds__(TPB, (SY == 1 && W < 0 ? BL_CSRT_WAVES : SY == 1 ? BL_CS_WAVES : SY == 2 ? BL_SY2_WAVES : (MODE == MODE_SYNCMER && W > 0 ? BL_SY0_WAVES : MODE == MODE_SYNCMER || (MODE == MODE_SUPERKMER && W == -32) ? 2 : (W == -32 || (W < 0 && MODE == MODE_SUPERKMER) ? 3 : (W == -16 ? 5 : (W < 0 ? 4 : (W <= 11 ? 5 : 4))))))) void scan_count_kernel(const ScanParams pin, GroupRange g)
 {
     __shared__ TileShared<MODE, W> sh;
     ScanParams p = pin;
@@ -336,8 +342,10 @@ __global__ __launch_bounds__(TPB, 2) void scan_redo_kernel(const ScanParams pin)
     __shared__ TileShared<MODE, W> sh;
     ScanParams p = pin;
     if (U != 0) p.unit = U;
-    p.w = W;
-    p.stride = NWAVE * (64 * S - 16 * ((W + 15) / 16));
+    if (W > 0) {  // (W < 0: one of the run-time width groups, w and stride as given)
+        p.w = W;
+        p.stride = NWAVE * (64 * S - 16 * ((W + 15) / 16));
+    }
     if (C >= 0) p.canonical = C;
     const unsigned long long n = *p.redo_count;
     for (unsigned long long i = blockIdx.x; i < n; i += gridDim.x) {
@@ -664,6 +672,22 @@ static hipError_t launch_count_frl(int mode, const ScanParams& p, GroupRange g, 
         }
         return hipGetLastError();
     }
+    // the BASELINE shape (canonical 31-mers, window 11) on reads of ANY fixed length the planner gives 14, 15 or 16 units per lane for
+    // (every length from 100 to 300 bp, 151 among them): the same kernel with the read geometry taken from the arguments
+    if (mode == MODE_MINIMIZER && p.w == 11 && p.unit == 31 && p.canonical && p.ns >= 14 && p.ns <= 16) {
+        const bool approx = p.redo_list && g.first == 0 && !p.exact_windows;
+        const dim3 redo_grid(g.count < 512u ? g.count : 512u);
+#define BL_FRL_SHAPE(NSV)                                                                                                                \
+    if (approx) {                                                                                                                        \
+        hipLaunchKernelGGL((scan_count_frl_kernel<MODE_MINIMIZER, 11, NSV, 31, 0, 1, true>), grid, block, 0, stream, p, g);               \
+        hipLaunchKernelGGL((scan_redo_frl_kernel<MODE_MINIMIZER, 11, NSV, 31, 0, 1>), redo_grid, block, 0, stream, p);                    \
+    } else {                                                                                                                             \
+        hipLaunchKernelGGL((scan_count_frl_kernel<MODE_MINIMIZER, 11, NSV, 31, 0, 1>), grid, block, 0, stream, p, g);                     \
+    }
+        if (p.ns == 14) { BL_FRL_SHAPE(14) } else if (p.ns == 15) { BL_FRL_SHAPE(15) } else { BL_FRL_SHAPE(16) }
+#undef BL_FRL_SHAPE
+        return hipGetLastError();
+    }
     if (p.ns != S) return hipErrorInvalidValue;  // the general kernels give every lane S unit starts
     if (mode == MODE_MINIMIZER) {
         switch (p.w) {
@@ -711,6 +735,26 @@ static hipError_t launch_count_mode(const ScanParams& p, GroupRange g, hipStream
             hipLaunchKernelGGL((scan_count_kernel<MODE, 21, 11, 1>), grid, block, 0, stream, p, g);
         }
         return hipGetLastError();
+    }
+    if (MODE == MODE_SYNCMER && p.w <= 32 && !p.exact_windows && ((p.soff == 0 && p.eoff == p.w - 1) || (p.soff == p.w - 1 && p.eoff == 0))) {
+        // closed syncmers of any (k, s): sliding minima over the hashes' high dwords, w by run time; a k-mer whose comparison meets equal
+        // dwords is decided on the 64-bit hashes inside the kernel (short s-mers repeat within a window: no second kernel, no listed tiles)
+        if (p.w <= 17) hipLaunchKernelGGL((scan_count_kernel<MODE_SYNCMER, -8, 0, -1, 1>), grid, block, 0, stream, p, g);
+        else hipLaunchKernelGGL((scan_count_kernel<MODE_SYNCMER, -16, 0, -1, 1>), grid, block, 0, stream, p, g);
+        return hipGetLastError();
+    }
+    if (MODE == MODE_MINIMIZER && p.w >= 2 && p.w <= 32) {
+        // minimizer scans: every window width up to 32 has its own kernel — van Herk / Gil-Werman on packed keys in registers, the
+        // element-centric decisions up to 16.  (The sparse-table kernels below, which take the width at run time, ran these widths at
+        // 220-340 Gbp/s where a width of its own gives 390-420; 27 more kernels cost the build 17 seconds.)
+        constexpr int MM = MODE_MINIMIZER;
+        switch (p.w) {
+#define BL_W(WV) case WV: hipLaunchKernelGGL((scan_count_kernel<MM, WV, 0, -1>), grid, block, 0, stream, p, g); return hipGetLastError();
+            BL_W(2) BL_W(3) BL_W(4) BL_W(5) BL_W(6) BL_W(7) BL_W(8) BL_W(9) BL_W(10) BL_W(11) BL_W(12) BL_W(13) BL_W(14) BL_W(15) BL_W(16)
+            BL_W(17) BL_W(18) BL_W(19) BL_W(20) BL_W(21) BL_W(22) BL_W(23) BL_W(24) BL_W(25) BL_W(26) BL_W(27) BL_W(28) BL_W(29) BL_W(30)
+            BL_W(31) BL_W(32)
+#undef BL_W
+        }
     }
     if (MODE != MODE_SYNCMER) {
         // more window sizes in registers for the minimizer / super-k-mer scans: the widths of minimap2's presets

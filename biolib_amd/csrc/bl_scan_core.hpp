@@ -156,6 +156,20 @@ BL_DEV bool plan_scan_frl(int64_t first, int64_t end, int64_t n_bases, int64_t r
     return true;
 }
 
+// The read-tiled plan the C ABI and the emulation harness use: the BASELINE shape (canonical 31-mers, window 11) takes the units per lane
+// the read length asks for when kernels are built for it (14, 15, 16: launch_count_frl), everything else S per lane.
+BL_DEV bool plan_scan_frl_for(int mode, int64_t first, int64_t end, int64_t n_bases, int64_t read_len, int unit, int w, bool canonical, ScanParams& p)
+{
+    if (mode == MODE_MINIMIZER && w == 11 && unit == 31 && canonical) {
+        ScanParams q = p;
+        if (plan_scan_frl(first, end, n_bases, read_len, unit, w, 0, q) && q.ns >= 14 && q.ns <= 16) {
+            p = q;
+            return true;
+        }
+    }
+    return plan_scan_frl(first, end, n_bases, read_len, unit, w, S, p);
+}
+
 // a contiguous group of tiles handled by one stage of the software pipeline
 struct GroupRange {
     uint32_t first, count;

@@ -975,6 +975,175 @@ BL_DEV uint32_t phase_sync_closed(const ScanParams& p, TileShared<MODE, W>& sh, 
 }
 
 // ------------------------------------------------------------------------------------------------
+// Closed syncmers for ANY (k, s) — the window count w = k - s + 1 is a run-time value, 1 <= w <= 32.  Same test as closed_hits,
+// on the hashes' own high dwords: per strand the sliding minimum `mid` of the w - 2 s-mers between the k-mer's two ends comes from a
+// sparse table inside the lane (doubling levels up to P, the largest power of two <= w - 2, then min(t[i], t[i + (w - 2) - P]):
+// window_argmin_doubling on plain values), and both the second table entry and the k-mer's last s-mer sit at a run-time offset
+// from the first — the same offset, (w - 2) - P, applied bit by bit with uniform branches over register moves (shift_stage).
+// Short s-mers repeat inside a window as a matter of course (s = 8: the smaller end equals the minimum between in one k-mer of
+// 3,000; s = 5: in most), so a comparison that meets equal dwords is not handed to another kernel, tile and all: the K-MER is decided
+// again where it stands, on the 64-bit hashes, which the wave publishes in LDS when — and only when — one of its lanes asks.
+// hashes: phase_hash (rolling registers, both strands).
+
+// dst[i] = src[i + sh] for i < S, 0 <= sh <= MAXSH (MAXSH + 1 a power of two or MAXSH = 0); src holds S + MAXSH entries
+template <int MAXSH>
+BL_DEV void shifted_slice(const uint32_t* src, int sh, uint32_t* dst)
+{
+    uint32_t t[S + (MAXSH > 0 ? MAXSH : 1)];
+    BL_UNROLL
+    for (int i = 0; i < S + MAXSH; ++i) t[i] = src[i];
+    // after the stage of bit B the shifts still to come sum to at most B - 1: t[0 .. S + B - 1) stays valid
+    if (MAXSH >= 16) shift_stage<S + 15, 16>(t, sh);
+    if (MAXSH >= 8) shift_stage<S + 7, 8>(t, sh);
+    if (MAXSH >= 4) shift_stage<S + 3, 4>(t, sh);
+    if (MAXSH >= 2) shift_stage<S + 1, 2>(t, sh);
+    if (MAXSH >= 1) shift_stage<S, 1>(t, sh);
+    BL_UNROLL
+    for (int i = 0; i < S; ++i) dst[i] = t[i];
+}
+
+// one strand's verdicts (bit s: k-mer s has its minimum s-mer at one of its two ends, if this strand is the canonical one) from the
+// lane's dwords key[0 .. S + 2P): P <= w - 2 < 2P.  tie: bit s set where the smaller end and the minimum between share their dword.
+template <int P>
+BL_DEV uint32_t closed_hits_rt(const uint32_t* key, int w, uint32_t& tie)
+{
+    constexpr int NT = S + 2 * P - 1;  // entries of the table: t[j] covers key[j + 1 .. j + P]
+    uint32_t t[NT];
+    BL_UNROLL
+    for (int j = 0; j < NT; ++j) t[j] = key[j + 1];
+    uint32_t unused = ~0u;
+    if (P > 1) doubling_level<NT, 1>(t, unused);
+    if (P > 2) doubling_level<NT, 2>(t, unused);
+    if (P > 4) doubling_level<NT, 4>(t, unused);
+    if (P > 8) doubling_level<NT, 8>(t, unused);
+    const int sh = (w - 2) - P;  // 0 .. P - 1
+    uint32_t t2[S], last[S];
+    shifted_slice<P - 1>(t, sh, t2);              // t2[i] = t[i + sh]: covers key[i + 1 + sh .. i + sh + P] = up to key[i + w - 2]
+    shifted_slice<P - 1>(key + P + 1, sh, last);  // last[i] = key[i + P + 1 + sh] = key[i + w - 1]
+    uint32_t hit = 0, eq = 0;
+    BL_UNROLL
+    for (int i = S - 1; i >= 0; --i) {
+        const uint32_t mid = t[i] < t2[i] ? t[i] : t2[i];
+        const uint32_t e = key[i] < last[i] ? key[i] : last[i];
+        hit = hit + hit + (e < mid ? 1u : 0u);
+        eq = eq + eq + (e == mid ? 1u : 0u);
+    }
+    tie = eq;
+    return hit;
+}
+
+// w by run time, in the size group of the kernel: GROUP_B false: w <= 17 (one halo hop), true: 18 <= w <= 32 (two hops)
+template <bool GROUP_B>
+BL_DEV uint32_t closed_hits_any(const uint32_t* key, int w, uint32_t& tie)
+{
+    tie = 0;
+    if (w <= 2) return 0xffffu;  // one or two s-mers: the minimum sits at an end
+    const int wm = w - 2;
+    if (GROUP_B) return closed_hits_rt<16>(key, w, tie);
+    if (wm >= 8) return closed_hits_rt<8>(key, w, tie);
+    if (wm >= 4) return closed_hits_rt<4>(key, w, tie);
+    if (wm >= 2) return closed_hits_rt<2>(key, w, tie);
+    return closed_hits_rt<1>(key, w, tie);
+}
+
+// The k-mers of `todo` (bit s = the lane's k-mer s), decided on the wave's 64-bit hashes through LDS: the position of the minimum
+// among the k-mer's w s-mers — the leftmost of equals on the forward strand, the rightmost on the reverse one (SECOND) — is its first or
+// its last.  The wave's hashes are published first (wave-local region of sh.half, as window_argmin_lds_exact does).
+template <int MODE, int W, bool SECOND>
+BL_DEV uint32_t closed_exact_kmers(TileShared<MODE, W>& sh, const ThreadState* all, int tid, const ThreadState& st, int w, uint32_t todo)
+{
+    const int wbase = tid & ~63, lane = tid & 63;
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(BL_CPU_EMU)
+    (void)all;
+    BL_UNROLL
+    for (int s = 0; s < S; ++s) sh.half[s][W < 0 ? tid : 0] = SECOND ? st.h2[s] : st.h[s];
+#else
+    (void)st;
+    for (int t = wbase; t < wbase + 64; ++t)
+        for (int s = 0; s < S; ++s) sh.half[s][W < 0 ? t : 0] = SECOND ? all[t].h2[s] : all[t].h[s];
+#endif
+    uint32_t hit = 0;
+    while (todo) {
+        const int i = __builtin_ctz(todo);
+        todo &= todo - 1;
+        uint64_t best = 0;
+        int arg = 0;
+        for (int x = 0; x < w; ++x) {
+            int pos = 16 * lane + i + x;
+            pos = pos < WH ? pos : WH - 1;  // beyond the wave tile: never part of an owned k-mer
+            const uint64_t v = sh.half[pos & 15][W < 0 ? wbase + (pos >> 4) : 0];
+            if (x == 0 || (SECOND ? v <= best : v < best)) { best = v; arg = x; }
+        }
+        if (arg == 0 || arg == w - 1) hit |= 1u << i;
+    }
+    return hit;
+}
+
+// W: the run-time width group of the kernel (-8: w <= 17, -16: 18 <= w <= 32; the TileShared of these groups carries the LDS
+// region for the wave's hashes)
+template <int MODE, int W>
+BL_DEV uint32_t phase_sync_closed_rt(const ScanParams& p, TileShared<MODE, W>& sh, int tid, int64_t q0, ThreadState& st, const ThreadState* all)
+{
+    static_assert(W == -8 || W == -16, "run-time width groups");
+    constexpr bool GROUP_B = W == -16;
+    const int wv = wave_index(tid), lane = tid & 63;
+    const int w = p.w;
+    constexpr int NE = GROUP_B ? 2 * S : S;  // halo elements: keys up to index w + 14
+    uint32_t hit_f, tie_f, hit_r = 0, tie_r = 0;
+    {
+        uint32_t key[S + NE];
+        BL_UNROLL
+        for (int s = 0; s < S; ++s) key[s] = (uint32_t)(st.h[s] >> 32);
+        gather_halo_hi<NE, false>(all, tid, key);
+        hit_f = closed_hits_any<GROUP_B>(key, w, tie_f);
+    }
+    if (p.canonical) {
+        uint32_t key[S + NE];
+        BL_UNROLL
+        for (int s = 0; s < S; ++s) key[s] = (uint32_t)(st.h2[s] >> 32);
+        gather_halo_hi<NE, true>(all, tid, key);
+        hit_r = closed_hits_any<GROUP_B>(key, w, tie_r);
+    }
+    const uint32_t rev = p.canonical ? st.strand : 0u;  // bit s: the reverse strand is the canonical one for k-mer s
+    Bits128 good, start;
+    gather_flags(sh.flags + wave_chunk0(p, wv), lane, good, start);
+    const int k = p.unit + w - 1;
+    const uint32_t valid = window_valid_mask(good, start, k) & 0xffffu;
+    const int64_t j0 = wave_origin(p, q0, wv) + 16 * (int64_t)lane;
+    const int64_t wj0 = wave_origin(p, q0, wv);
+    uint32_t inrange = 0x1ffffu;
+    if (!(wj0 >= p.win_first && wj0 + WH + 1 <= p.win_end)) inrange = range_mask(p.win_first - j0, p.win_end - j0);
+    uint32_t keepable = valid & owned_mask(p, lane) & inrange;
+    if (p.drop_last) {  // the k-mer that ends its sequence is never examined by the idiom (Q1)
+        uint32_t last = (uint32_t)b128_shr(start, k).lo & 0xffffu;
+        last |= range_mask(p.n_bases - k - j0, S + 1);
+        keepable &= ~last;
+    }
+    // equal dwords on the strand that counts, in a k-mer that could be reported: the 64-bit hashes decide
+    const uint32_t todo_f = tie_f & ~rev & keepable, todo_r = tie_r & rev & keepable;
+    if (BL_COLD(wave_any((todo_f | todo_r) != 0u))) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(BL_CPU_EMU)
+        // the hashes are computed a second time here: kept from phase_hash, their low dwords would sit in 32 registers all through the
+        // sliding minima above (the kernel then spills at three waves per SIMD)
+        ThreadState full;
+        phase_hash<MODE, W>(p, sh, tid, full);
+#else
+        const ThreadState& full = st;
+#endif
+        const uint32_t xf = closed_exact_kmers<MODE, W, false>(sh, all, tid, full, w, todo_f);
+        hit_f = (hit_f & ~todo_f) | xf;
+        if (p.canonical) {
+            const uint32_t xr = closed_exact_kmers<MODE, W, true>(sh, all, tid, full, w, todo_r);
+            hit_r = (hit_r & ~todo_r) | xr;
+        }
+    }
+    const uint32_t emit = ((rev & hit_r) | (~rev & hit_f)) & keepable;
+    st.emit = emit;
+    st.endm = 0;
+    return (uint32_t)__builtin_popcount(emit);
+}
+
+// ------------------------------------------------------------------------------------------------
 // Phase 4: tile-local compaction into LDS lists (position-ordered: rank = exclusive prefix + local index)
 template <int MODE, int W>
 BL_DEV void phase_list(TileShared<MODE, W>& sh, int tid, const ThreadState& st, uint32_t excl_s, uint32_t excl_e)

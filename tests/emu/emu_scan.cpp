@@ -36,6 +36,7 @@ std::vector<uint32_t> make_start_bits(uint64_t n_bases, const uint64_t* offsets,
 
 // pass 1 (scan_count_kernel) for every tile, the tile-count prefix scan, pass 2 (scan_emit_kernel)
 int g_closed_redone = 0, g_sy2_redone = 0;
+
 // SY: the syncmer form of count_tile (bl_kernels.hip): 0 = argmins with the exact form inline, 1 = closed syncmers on murmur64_top,
 // 2 = argmins from phase_hash_closed<BOTH> with the exact form deferred to a second run of the tile (scan_redo_kernel)
 template <int MODE, int W, int SY = 0, int U = 0>
@@ -57,16 +58,21 @@ void run_tiles(ScanParams p, unsigned long long* result)
             const int64_t q0 = p.origin + (int64_t)tile * p.stride;
             for (int tid = 0; tid < TPB; ++tid) phase_load<MODE, W>(p, *sh, tid, q0);
             for (int c = 0; c < staged_chunks(p); ++c) sc[tile * p.slot_chunks + c] = sh->codes[c];  // codes spill
-            constexpr int CSU = (MODE == MODE_SYNCMER && SY != 0) ? 11 : 0;  // the closed-syncmer kernels are instantiated for s = 11 (launch_count_mode)
+            constexpr int CSU = (MODE == MODE_SYNCMER && SY != 0 && W > 0) ? 11 : 0;  // the closed-syncmer kernels are instantiated for s = 11 (launch_count_mode)
             bool sy2_tie = false;
-            if (CSU && CS) {
+            constexpr bool RT = MODE == MODE_SYNCMER && W < 0 && SY == 1;  // closed syncmers, window count by run time (count_tile)
+            if (RT) {
+                for (int tid = 0; tid < TPB; ++tid) phase_hash<MODE, W>(p, *sh, tid, st[tid]);
+            } else if (CSU && CS) {
                 for (int tid = 0; tid < TPB; ++tid) phase_hash_closed<MODE, W, (CSU ? CSU : 1), false, true>(p, *sh, tid, st[tid]);
             } else if (CSU) {
                 for (int tid = 0; tid < TPB; ++tid) phase_hash_closed<MODE, W, (CSU ? CSU : 1), true, false>(p, *sh, tid, st[tid], &sy2_tie);
             } else {
                 for (int tid = 0; tid < TPB; ++tid) phase_hash<MODE, W, (MODE != MODE_SYNCMER ? U : 0)>(p, *sh, tid, st[tid]);
             }
-            if (MODE == MODE_SYNCMER && CS) {  // closed syncmers on murmur64_top; a tile with an undecided lane again in the argmin form (scan_redo_kernel)
+            if constexpr (RT) {
+                for (int tid = 0; tid < TPB; ++tid) packed[tid] = phase_sync_closed_rt<MODE, (W == -16 ? -16 : -8)>(p, reinterpret_cast<TileShared<MODE, (W == -16 ? -16 : -8)>&>(*sh), tid, q0, st[tid], st.data());
+            } else if (MODE == MODE_SYNCMER && CS) {  // closed syncmers on murmur64_top; a tile with an undecided lane again in the argmin form (scan_redo_kernel)
                 bool any = false;
                 for (int tid = 0; tid < TPB; ++tid) {
                     bool undecided;
@@ -235,7 +241,16 @@ void run_tiles_frl(ScanParams p, unsigned long long* result)
 template <int MODE>
 void run_mode_frl(const ScanParams& p, unsigned long long* result)
 {
-    if (MODE == MODE_MINIMIZER && p.ns == 15) { run_tiles_frl<MODE_MINIMIZER, 11, 15, 5, true>(p, result); return; }  // the BASELINE C3 kernel
+    if (MODE == MODE_MINIMIZER && p.w == 11 && p.unit == 31 && p.canonical && p.read_len == 150 && p.ns == 15 && p.rpw == 8) {
+        run_tiles_frl<MODE_MINIMIZER, 11, 15, 5, true>(p, result);  // the BASELINE C3 kernel
+        return;
+    }
+    if (MODE == MODE_MINIMIZER && p.w == 11 && p.unit == 31 && p.canonical && p.ns >= 14 && p.ns <= 16) {  // the same shape on other read lengths
+        if (p.ns == 14) run_tiles_frl<MODE_MINIMIZER, 11, 14, 0, true>(p, result);
+        else if (p.ns == 15) run_tiles_frl<MODE_MINIMIZER, 11, 15, 0, true>(p, result);
+        else run_tiles_frl<MODE_MINIMIZER, 11, 16, 0, true>(p, result);
+        return;
+    }
     if (MODE == MODE_MINIMIZER) {
         switch (p.w) {
             case 5: run_tiles_frl<MODE_MINIMIZER, 5, S>(p, result); return;
@@ -252,6 +267,22 @@ template <int MODE>
 void run_mode(const ScanParams& p, unsigned long long* result)
 {
     if (p.frl) { run_mode_frl<MODE == MODE_SYNCMER ? MODE_MINIMIZER : MODE>(p, result); return; }
+    if (MODE == MODE_SYNCMER && p.w <= 32 && ((p.soff == 0 && p.eoff == p.w - 1) || (p.soff == p.w - 1 && p.eoff == 0)) &&
+        !(p.w == 21 && p.unit == 11 && p.canonical)) {  // closed syncmers of any (k, s) (launch_count_mode; the (31, 11) shape has its own kernel)
+        if (p.w <= 17) run_tiles<MODE_SYNCMER, -8, 1>(p, result);
+        else run_tiles<MODE_SYNCMER, -16, 1>(p, result);
+        return;
+    }
+    if (MODE == MODE_MINIMIZER && p.w >= 2 && p.w <= 32) {  // a kernel per width (launch_count_mode)
+        constexpr int MM = MODE_MINIMIZER;
+        switch (p.w) {
+#define BL_W(WV) case WV: run_tiles<MM, WV>(p, result); return;
+            BL_W(2) BL_W(3) BL_W(4) BL_W(5) BL_W(6) BL_W(7) BL_W(8) BL_W(9) BL_W(10) BL_W(11) BL_W(12) BL_W(13) BL_W(14) BL_W(15) BL_W(16)
+            BL_W(17) BL_W(18) BL_W(19) BL_W(20) BL_W(21) BL_W(22) BL_W(23) BL_W(24) BL_W(25) BL_W(26) BL_W(27) BL_W(28) BL_W(29) BL_W(30)
+            BL_W(31) BL_W(32)
+#undef BL_W
+        }
+    }
     switch (p.w) {
         case 1: run_tiles<MODE, 1>(p, result); break;
         case 5: if (MODE != MODE_SYNCMER) { run_tiles<MODE, 5>(p, result); break; } run_tiles<MODE, -8>(p, result); break;
@@ -293,8 +324,7 @@ void fill_common(ScanParams& p, const uint8_t* bases, uint64_t n_bases, const ui
     p.start_bits = bits;
     plan_scan(mode, (int64_t)first, (int64_t)end, (int)w, p);
     if (read_len && !p.use_threshold && frl_width_built(mode, (int)w)) {  // the decision of bl_capi.hip: scan_windows
-        const bool tuned = mode == MODE_MINIMIZER && w == 11 && unit == 31 && (flags & 1) && read_len == 150;
-        if (plan_scan_frl((int64_t)first, (int64_t)end, (int64_t)n_bases, (int64_t)read_len, (int)unit, (int)w, tuned ? 0 : S, p)) ++g_frl_scans;
+        if (plan_scan_frl_for(mode, (int64_t)first, (int64_t)end, (int64_t)n_bases, (int64_t)read_len, (int)unit, (int)w, (flags & 1) != 0, p)) ++g_frl_scans;
     }
     p.unit = (int)unit;
     p.w = (int)w;

@@ -77,7 +77,10 @@ static void check_case(const Case& c, std::mt19937_64& rng)
     struct MM { unsigned unit, w; uint64_t seed; int canon; };
     const MM mms[] = {{31, 11, 42, 1}, {15, 17, 42, 1}, {15, 10, 7, 1}, {19, 19, 8, 1}, {21, 5, 9, 0}, {11, 21, 0, 0}, {5, 4, 1, 1}, {32, 2, 9, 1}, {8, 1, 3, 0}, {1, 1, 0, 1},
                       {32, 64, 5, 1}, {21, 33, 6, 0}, {3, 16, 7, 1}, {16, 17, 8, 0}};
-    for (const MM& m : mms) {
+    std::vector<MM> mm_cases(mms, mms + sizeof(mms) / sizeof(mms[0]));
+    for (int extra = 0; extra < 3; ++extra)  // every width from 2 to 32 has a kernel of its own: three of them, at random, per case
+        mm_cases.push_back(MM{(unsigned)(1 + rng() % 32), (unsigned)(2 + rng() % 31), rng() % 100, (int)(rng() % 2)});
+    for (const MM& m : mm_cases) {
         // whole batch
         size_t cnt = blo_minimizers(s, c.offsets.data(), n_seqs, m.unit, m.w, m.seed, m.canon, 1, ov.data(), op.data(), oh.data(), cap);
         emu_minimizers(b, 0, 0, m.unit, m.w, m.seed, m.canon ? 1 : 0, ev.data(), ep.data(), eh.data(), cap, res);
@@ -125,7 +128,10 @@ static void check_case(const Case& c, std::mt19937_64& rng)
     const SY sys[] = {{31, 11, 0, 20, 1}, {31, 11, 0, 20, 0}, {21, 8, 0, 13, 1}, {7, 4, 0, 3, 1}, {15, 15, 0, 0, 1}, {31, 15, 0, 16, 1},
                       {32, 12, 3, 9, 1}, {9, 1, 0, 8, 0}, {28, 12, 5, 5, 1},
                       // k = 31, s = 11 with offsets other than {0, 20}: count_tile's SY = 2 form (exact argmins deferred to a second run)
-                      {31, 11, 3, 9, 1}, {31, 11, 0, 0, 1}, {31, 11, 20, 20, 1}, {31, 11, 5, 20, 1}};
+                      {31, 11, 3, 9, 1}, {31, 11, 0, 0, 1}, {31, 11, 20, 20, 1}, {31, 11, 5, 20, 1},
+                      // closed syncmers of other shapes: the run-time width kernels (phase_sync_closed_rt), every doubling width and both groups
+                      {31, 8, 0, 23, 1}, {31, 8, 23, 0, 0}, {32, 1, 0, 31, 1}, {20, 16, 0, 4, 1}, {25, 12, 0, 13, 1}, {21, 11, 0, 10, 1}, {15, 5, 0, 10, 0},
+                      {31, 15, 16, 0, 1}, {12, 10, 0, 2, 1}, {9, 8, 0, 1, 1}, {30, 13, 0, 17, 1}, {32, 14, 0, 18, 1}, {16, 13, 0, 3, 1}, {14, 9, 0, 5, 0}};
     for (const SY& y : sys) {
         for (int drop = 0; drop < 2; ++drop) {
             size_t cnt = blo_syncmers(s, c.offsets.data(), n_seqs, y.k, y.s, y.a, y.b, y.canon, drop, 1, op.data(), cap);
@@ -292,6 +298,7 @@ int main(int argc, char** argv)
     CHECK(emu_frl_scans() > 100, "the read-tiled path was hardly exercised: %d scans", emu_frl_scans());
     std::printf("read-tiled scans run: %d (tiles %d, of which decided again on the hashes: %d; tiles of closed-syncmer scans decided again: %d, of argmin syncmer scans with the exact form deferred: %d)\n", emu_frl_scans(), emu_frl_tiles(), emu_frl_redone(), emu_closed_redone(), emu_sy2_redone());
     CHECK(emu_sy2_redone() > 0, "no tile of a deferred-argmin syncmer scan was decided again: the tie path did not run");
+
     if (g_fail) {
         std::printf("emu_selftest: %d mismatches\n", g_fail);
         return 1;

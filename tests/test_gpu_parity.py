@@ -384,6 +384,42 @@ def test_random_parameters_vs_oracle(ctx):
         b.close()
 
 
+@pytest.mark.parametrize("read_len", [100, 101, 125, 150, 151, 250, 300, 76, 10_000])
+def test_shape_sweep_shapes_vs_oracle(ctx, read_len):
+    """the shapes of tests/perf/shape_sweep.py (profiles/r04_shape_sweep.json) against the oracle, record for record: the BASELINE
+    minimizer shape on every fixed read length (the read-tiled kernels for 14 / 15 / 16 units per lane, windows decided on murmur64_top),
+    every window width from 2 to 32 (a kernel each) and beyond, closed syncmers of any (k, s) (run-time width kernels) and open ones —
+    on clean reads, reads with breaks and reads of repeats (where the approximate forms hand every tile to the exact kernels)"""
+    rng = np.random.default_rng(read_len)
+    n_reads = max(3, 60_000 // read_len)
+    n = n_reads * read_len
+    for flavour in ("plain", "breaks", "repeats"):
+        seq = O.synth(900 + read_len, n).copy()
+        if flavour == "breaks":
+            seq[rng.integers(0, n, n // 400 + 1)] = ord("N")
+        if flavour == "repeats":
+            for p0 in rng.integers(0, n, 12):
+                ln = min(int(rng.integers(50, 2500)), n - int(p0))
+                seq[p0:p0 + ln] = np.resize(np.frombuffer([b"A", b"CA", b"ACGTTACA", b"GATTACAGATTACC"][int(rng.integers(4))], np.uint8), ln)
+        offs = O.fixed_offsets(n, read_len)
+        b = ctx.upload(seq, read_len=read_len)
+        widths = [(31, 11), (15, 10), (25, 5)] + [(int(rng.integers(1, 33)), w) for w in rng.permutation(np.arange(2, 33))[:6]] + [(15, 33), (31, 64)]
+        for (unit, w) in widths:
+            if unit + w - 1 > read_len:
+                continue
+            v, p, h = O.minimizers(seq, offs, unit, w, 42, True, brute=False)
+            got = b.minimizers(unit, w, seed=42, canonical=True)
+            assert got["count"] == len(v), (read_len, flavour, unit, w)
+            assert np.array_equal(got["positions"], p) and np.array_equal(got["values"], v) and np.array_equal(got["hashes"], h), (read_len, flavour, unit, w)
+        for (k, s, a, e) in ((31, 11, 0, 20), (31, 15, 0, 16), (21, 11, 0, 10), (31, 8, 0, 23), (31, 8, 23, 0), (25, 12, 0, 13), (20, 16, 0, 4), (15, 5, 0, 10),
+                             (32, 1, 0, 31), (12, 11, 0, 1), (31, 11, 3, 9), (21, 8, 2, 5)):
+            for canon in (True, False):
+                cnt, pos = O.syncmers(seq, offs, k, s, a, e, canon)
+                gs = b.syncmers(k, s, a, e, canonical=canon)
+                assert gs["count"] == cnt and np.array_equal(gs["positions"], pos), (read_len, flavour, k, s, a, e, canon)
+        b.close()
+
+
 @pytest.mark.gpu
 def test_read_tiled_scan_on_tiles_of_repeats(ctx):
     """C3's kernel pair on a batch in which whole tiles are low-complexity reads — nearly every window starts an occurrence,
