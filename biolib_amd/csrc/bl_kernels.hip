@@ -253,7 +253,8 @@ __device__ __forceinline__ void count_tile_frl(const ScanParams& p, TileShared<M
 // straight from the tile's global slots — each exactly once, by the thread that builds the record — so the kernel's LDS
 // footprint is the 2 KB of codes and its residency is set by launch_scan_emit's padding alone (it used to stage up to
 // three 8 KB lists per tile, which, beside a hashing kernel that needs 12 KB per workgroup, decided who got the CU).
-template <int MODE>
+// LOOPED: called from scan_emit_kernel's tile loop (one barrier per tile whatever the tile holds; scheduling fences that hold the registers down)
+template <int MODE, bool LOOPED = false>
 __device__ __forceinline__ void emit_tile(const ScanParams& p, uint32_t* codes, uint32_t tile, int tid, Digest& dg)
 {
     // one memory round trip for the common case: every load of the tile — counts, offsets, codes, the first 2 * TPB list entries
@@ -279,7 +280,7 @@ __device__ __forceinline__ void emit_tile(const ScanParams& p, uint32_t* codes, 
     }
     const uint32_t n_s = (uint32_t)cnt, n_e = (uint32_t)(cnt >> 32);
     if (n_s == 0 && n_e == 0) {  // uniform for the workgroup
-        if (MODE != MODE_SYNCMER) __syncthreads();  // (the caller's tile loop counts on one barrier per tile: scan_emit_kernel)
+        if (LOOPED && MODE != MODE_SYNCMER) __syncthreads();  // (the caller's tile loop counts on one barrier per tile: scan_emit_kernel)
         return;
     }
     const uint64_t base_s = base & 0xffffffffull, base_e = base >> 32;
@@ -292,7 +293,7 @@ __device__ __forceinline__ void emit_tile(const ScanParams& p, uint32_t* codes, 
     TileLists L{codes, la, lj, MODE == MODE_SUPERKMER ? p.slots_e + slot : nullptr, MODE == MODE_SUPERKMER ? p.slots_e + slot + p.stride : nullptr};
     const uint32_t d = (uint32_t)(base_s - base_e);  // 0 or 1 (see end_position)
     auto one = [&](uint32_t r, uint32_t ent, uint32_t ent_j) {
-        const Record rec = emit_prepare<MODE>(p, codes, q0, ent, ent_j, dg);
+        const Record rec = emit_prepare<MODE, LOOPED>(p, codes, q0, ent, ent_j, dg);
         if (fits) emit_store<MODE, false>(p, rec, base_s + r);
         else emit_store<MODE, true>(p, rec, base_s + r);
         if (MODE == MODE_SUPERKMER && (p.out_size || p.out_records) && (fits || base_s + r < p.capacity)) {
@@ -304,9 +305,9 @@ __device__ __forceinline__ void emit_tile(const ScanParams& p, uint32_t* codes, 
     // (fences: left alone the scheduler interleaves the two records for instruction-level parallelism — 30 registers instead of 22, and
     // this kernel's registers decide how many of its waves fit a SIMD beside the hashing pass: 96 x 4 or 5 waves of the 512 there are)
     if ((uint32_t)tid < n_s) one(tid, a0, j0);
-    BL_SCHED_FENCE();
+    if (LOOPED) BL_SCHED_FENCE();
     if ((uint32_t)(TPB + tid) < n_s) one(TPB + tid, a1, j1);
-    BL_SCHED_FENCE();
+    if (LOOPED) BL_SCHED_FENCE();
 #pragma unroll 1
     for (uint32_t r = 2 * TPB + tid; r < n_s; r += TPB) one(r, la[r], MODE == MODE_SUPERKMER ? lj[r] : 0u);  // rarely any
 }
@@ -408,52 +409,52 @@ __global__ __launch_bounds__(TPB, (W <= 11 ? 5 : 4)) void scan_redo_frl_kernel(c
     }
 }
 
-// A workgroup takes BL_EMIT_TILES consecutive tiles: the digest's wave reductions and atomics, a third of this kernel's instructions
-// when paid per tile, are paid once per workgroup.  No loads of a later tile are in flight while a tile is built (that form, tried
-// in round 3, needs 52 registers for 22 and crowds the hashing pass); the codes ping-pong between two LDS buffers so that the loop
-// needs no barrier of its own (tile k + 2 overwrites what tile k read only after every thread has passed tile k + 1's barrier).
+// Minimizer scans: a workgroup takes BL_EMIT_TILES consecutive tiles, so that the digest's wave reductions and atomics, a third of this
+// kernel's instructions when paid per tile, are paid once per workgroup.  No loads of a later tile are in flight while a tile is built
+// (that form, tried in round 3, needs 52 registers for 22 and crowds the hashing pass); the codes ping-pong between two LDS buffers so
+// that the loop needs no barrier of its own (tile k + 2 overwrites what tile k read only after every thread has passed tile k + 1's
+// barrier), and the thread's digest words live in LDS between tiles (in registers they cost 34 instead of 28, i.e. 40 allocated for 32).
+// Measured on C3 (two lanes, 20 steps, A/B on one box): the same 500 Gbp/s as one tile per workgroup — the scan is held by the card's
+// power limit — with 2.3 fewer lane-instructions per base.  Super-k-mer and syncmer scans keep one tile per workgroup:
+// their record code is longer, the loop took it from 32 to 45 registers and C4 from 391 to 384 Gbp/s.
 // U, C, FRL: unit length, canonical flag and layout as compile-time constants for the BASELINE C3 shape (0 / -1 / -1: from the arguments).
 #ifndef BL_EMIT_TILES
 #define BL_EMIT_TILES 4
 #endif
+template <int MODE>
+constexpr int emit_tiles() { return MODE == MODE_MINIMIZER ? BL_EMIT_TILES : 1; }
+
 template <int MODE, int U = 0, int C = -1, int FRL = -1>
 __global__ __launch_bounds__(TPB) void scan_emit_kernel(const ScanParams pin, GroupRange g)
 {
-    __shared__ uint32_t codes[2][NCHUNK];
+    constexpr int K = emit_tiles<MODE>();
+    __shared__ uint32_t codes[K > 1 ? 2 : 1][NCHUNK];
     const int tid = threadIdx.x;
     ScanParams p = pin;
     if (U != 0) p.unit = U;
     if (C >= 0) p.canonical = C;
     if (FRL >= 0) p.frl = FRL;
-#ifndef BL_EMIT_ACC_REGS
-    // the thread's digest words live in LDS between tiles (six dwords per thread, read-xor-written once per tile): in registers they
-    // cost the kernel 34 instead of 28, i.e. 40 allocated instead of 32
-    __shared__ uint32_t acc[6][TPB];
+    Digest dg{0, 0, 0};
+    if constexpr (K > 1) {
+        __shared__ uint32_t acc[6][TPB];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) acc[i][tid] = 0;
-    const uint32_t t0 = blockIdx.x * BL_EMIT_TILES;
+        for (int i = 0; i < 6; ++i) acc[i][tid] = 0;
+        const uint32_t t0 = blockIdx.x * K;
 #pragma unroll 1
-    for (uint32_t k = 0; k < BL_EMIT_TILES && t0 + k < g.count; ++k) {
-        Digest d1{0, 0, 0};
-        emit_tile<MODE>(p, codes[k & 1], g.first + t0 + k, tid, d1);
-        if (MODE != MODE_SYNCMER) {
+        for (uint32_t k = 0; k < (uint32_t)K && t0 + k < g.count; ++k) {
+            Digest d1{0, 0, 0};
+            emit_tile<MODE, true>(p, codes[k & 1], g.first + t0 + k, tid, d1);
             acc[0][tid] ^= (uint32_t)d1.xv; acc[1][tid] ^= (uint32_t)(d1.xv >> 32);
             acc[2][tid] ^= (uint32_t)d1.xh; acc[3][tid] ^= (uint32_t)(d1.xh >> 32);
+            acc[4][tid] ^= (uint32_t)d1.xp; acc[5][tid] ^= (uint32_t)(d1.xp >> 32);
         }
-        acc[4][tid] ^= (uint32_t)d1.xp; acc[5][tid] ^= (uint32_t)(d1.xp >> 32);
-    }
-    Digest dg{0, 0, 0};
-    if (MODE != MODE_SYNCMER) {
         dg.xv = ((unsigned long long)acc[1][tid] << 32) | acc[0][tid];
         dg.xh = ((unsigned long long)acc[3][tid] << 32) | acc[2][tid];
+        dg.xp = ((unsigned long long)acc[5][tid] << 32) | acc[4][tid];
+    } else {
+        if (blockIdx.x >= g.count) return;
+        emit_tile<MODE, false>(p, codes[0], g.first + blockIdx.x, tid, dg);
     }
-    dg.xp = ((unsigned long long)acc[5][tid] << 32) | acc[4][tid];
-#else
-    Digest dg{0, 0, 0};
-    const uint32_t t0 = blockIdx.x * BL_EMIT_TILES;
-#pragma unroll 1
-    for (uint32_t k = 0; k < BL_EMIT_TILES && t0 + k < g.count; ++k) emit_tile<MODE>(p, codes[k & 1], g.first + t0 + k, tid, dg);
-#endif
 
     // digest: wave reduce (DPP xor-scan), then one set of atomics per WAVE into a shard line.  Measured alternatives: an LDS stage
     // with two more barriers per tile (no gain); folding the 256 threads' words with LDS atomics on three addresses (-30 % on the
@@ -802,13 +803,10 @@ hipError_t launch_scan_count(int mode, const ScanParams& p, GroupRange g, hipStr
 template <int MODE>
 static void launch_emit_mode(const ScanParams& p, GroupRange g, hipStream_t stream, uint32_t lds_per_wg)
 {
-#ifndef BL_EMIT_ACC_REGS
-    const uint32_t have = (uint32_t)((2 * NCHUNK + 6 * TPB) * sizeof(uint32_t));  // the kernel's static LDS: two code buffers, the digest words
-#else
-    const uint32_t have = (uint32_t)(2 * NCHUNK * sizeof(uint32_t));
-#endif
+    constexpr int K = emit_tiles<MODE>();
+    const uint32_t have = (uint32_t)(((K > 1 ? 2 : 1) * NCHUNK + (K > 1 ? 6 * TPB : 0)) * sizeof(uint32_t));  // the kernel's static LDS: code buffers, digest words
     const uint32_t pad = lds_per_wg > have ? lds_per_wg - have : 0;
-    const dim3 grid((g.count + BL_EMIT_TILES - 1) / BL_EMIT_TILES), block(TPB);
+    const dim3 grid((g.count + K - 1) / K), block(TPB);
     if (MODE == MODE_MINIMIZER && p.frl && p.unit == 31 && p.canonical) {  // BASELINE C3
         hipLaunchKernelGGL((scan_emit_kernel<MODE_MINIMIZER, 31, 1, 1>), grid, block, pad, stream, p, g);
         return;

@@ -206,7 +206,9 @@ BL_DEV uint32_t revcomp16(uint32_t c)
 // GENERIC: the kernel takes the unit length at run time (64-bit rolling registers with run-time shifts).  Those kernels hash with the
 // compiler's own multiply: the split one (mul64c) holds more register pairs alive, and compiled for five waves per SIMD they
 // spilled into the hashing loop with it (unit 15, w 10 on 150-bp reads: 381 -> 218 Gbp/s until this was noticed).
-template <int MODE, int W, int U = 0, bool GENERIC = false>
+// SPLIT (syncmer scans): hash with the split multiply (mul64c).  Not used: the argmin kernels run at two waves per SIMD (see murmur64_plain) and the
+// closed-syncmer kernels for a run-time width, at three, spill five times as much with it (149 scratch accesses against 32)
+template <int MODE, int W, int U = 0, bool GENERIC = false, bool SPLIT = false>
 BL_DEV void phase_hash(const ScanParams& p, TileShared<MODE, W>& sh, int tid, ThreadState& st)
 {
     const int wv = wave_index(tid), lane = tid & 63;
@@ -224,8 +226,8 @@ BL_DEV void phase_hash(const ScanParams& p, TileShared<MODE, W>& sh, int tid, Th
         for (int s = 0; s < S; ++s) {
             roller_step(r, s);
             roller_step(rk, s);
-            st.h[s] = murmur64_plain(roller_fwd(r), p.seed);  // (the compiler's multiply here: see murmur64_plain)
-            st.h2[s] = murmur64_plain(roller_rc(r), p.seed);
+            st.h[s] = SPLIT ? murmur64(roller_fwd(r), p.seed) : murmur64_plain(roller_fwd(r), p.seed);  // (the compiler's multiply: see murmur64_plain)
+            st.h2[s] = SPLIT ? murmur64(roller_rc(r), p.seed) : murmur64_plain(roller_rc(r), p.seed);
             if (p.canonical && roller_rc(rk) < roller_fwd(rk)) strand |= 1u << s;  // kmer_view.hpp:196
         }
         st.strand = strand;
@@ -1215,7 +1217,7 @@ BL_DEV int64_t end_position(const ScanParams& p, const TileLists& L, uint32_t ti
 
 // 5a: one record from its list entries.  Entries: (wave << 12) | wave-relative position, or — read-tiled scans — a flat
 // tile-relative position.
-template <int MODE>
+template <int MODE, bool FENCED = false>
 BL_DEV Record emit_prepare(const ScanParams& p, const uint32_t* codes, int64_t q0, uint32_t ent, uint32_t ent_j, Digest& dg)
 {
     Record rec{0, 0, 0, 0, 0};
@@ -1225,9 +1227,9 @@ BL_DEV Record emit_prepare(const ScanParams& p, const uint32_t* codes, int64_t q
     dg.xp ^= rec.pos + (uint64_t)p.pos_base;
     if (MODE != MODE_SYNCMER) {
         rec.v = extract_unit(p.frl ? codes : codes + wave_chunk0(p, wv), ap, p.unit, p.canonical);
-        BL_SCHED_FENCE();  // (pass 2 lives on few registers: see scan_emit_kernel)
+        if (FENCED) BL_SCHED_FENCE();  // (the looped form of pass 2 lives on few registers: see scan_emit_kernel)
         rec.h = murmur64(rec.v, p.seed);
-        BL_SCHED_FENCE();
+        if (FENCED) BL_SCHED_FENCE();
         dg.xv ^= rec.v;
         dg.xh ^= rec.h;
         if (MODE == MODE_SUPERKMER) {
