@@ -78,8 +78,12 @@ def valu_ceiling(model, kernels, bases, seconds, ghz):
     if model is None:
         return {"error": "profiles/valu_model.json missing: run tools/collect_profiles.sh on the GPU box and tools/valu_model.py"}
     need, parts = 0.0, {}
+    # the kernels that decide listed tiles a second time run inside the same region: counted where the model holds them
+    kernels = list(kernels) + [k.replace("_count", "_redo") for k in kernels if k.endswith("_count") and k.replace("_count", "_redo") in model["kernels"]]
     for k in kernels:
         km = model["kernels"][k]
+        if "cycles_per_base" not in km:
+            continue
         need += km["cycles_per_base"] * bases
         parts[k] = {"valu_lane_instr_per_base": round(km["valu_per_base"] * 64, 1), "simd_cycles_per_base": round(km["cycles_per_base"], 4),
                     "avg_issue_cycles": round(km["cycles_per_base"] / km["valu_per_base"], 3)}

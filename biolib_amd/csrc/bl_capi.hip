@@ -604,20 +604,24 @@ int bl_ctx_kernel_time(bl_ctx* c, double* total_ms, uint64_t* launches)
 
 // Markers on the device's own timeline, without stopping it: where a caller wants the time at which "everything issued so far" had
 // finished — a step of a benchmark — but must not synchronise there, because the next step's first kernels overlap this one's last.
+// at most this many markers wait for bl_ctx_mark_times (two events each): a caller that never collects them gets an error, not a leak
+static constexpr size_t MAX_MARKS = 4096;
+
 int bl_ctx_mark(bl_ctx* c)
 {
     if (!c) return fail(BL_ERR_INVALID, "ctx is NULL");
+    if (c->marks.size() >= MAX_MARKS) return fail(BL_ERR_CAPACITY, "bl_ctx_mark: 4096 markers outstanding: collect them with bl_ctx_mark_times");
     BL_HIP(hipSetDevice(c->device));
     std::pair<hipEvent_t, hipEvent_t> m{nullptr, nullptr};
-    BL_HIP(hipEventCreate(&m.first));
-    if (c->borrowed) {
-        BL_HIP(hipEventRecord(m.first, c->user_stream));
-    } else {
-        BL_HIP(hipEventRecord(m.first, c->lanes[0].own));
-        if (c->n_lanes == 2 && c->lanes[1].own) {
-            BL_HIP(hipEventCreate(&m.second));
-            BL_HIP(hipEventRecord(m.second, c->lanes[1].own));
-        }
+    const bool two = !c->borrowed && c->n_lanes == 2 && c->lanes[1].own;
+    hipError_t e = hipEventCreate(&m.first);
+    if (e == hipSuccess && two) e = hipEventCreate(&m.second);
+    if (e == hipSuccess) e = hipEventRecord(m.first, c->borrowed ? c->user_stream : c->lanes[0].own);
+    if (e == hipSuccess && two) e = hipEventRecord(m.second, c->lanes[1].own);
+    if (e != hipSuccess) {  // nothing of a failed marker stays behind
+        if (m.first) (void)hipEventDestroy(m.first);
+        if (m.second) (void)hipEventDestroy(m.second);
+        return fail(BL_ERR_HIP, std::string("bl_ctx_mark: ") + hipGetErrorString(e));
     }
     c->marks.push_back(m);
     return BL_OK;
@@ -629,6 +633,10 @@ int bl_ctx_mark_times(bl_ctx* c, double* ms, uint32_t capacity, uint32_t* n)
     int rc = sync_ctx(c);
     if (rc != BL_OK) return rc;
     *n = (uint32_t)c->marks.size();
+    if (capacity < c->marks.size()) {  // (the markers stay: ask again with room for *n)
+        if (capacity == 0) return BL_OK;
+        return fail(BL_ERR_CAPACITY, "bl_ctx_mark_times: more markers than the buffer holds (*n says how many)");
+    }
     hipError_t e = hipSuccess;
     for (size_t i = 0; i < c->marks.size(); ++i) {
         float a = 0.f, b = 0.f;  // since marker 0's event on the first stream: timestamps are the device's, whatever the stream

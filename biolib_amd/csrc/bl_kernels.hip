@@ -14,6 +14,9 @@
 #ifndef BL_CS_WAVES
 #define BL_CS_WAVES 3  // waves per SIMD the closed-syncmer kernel is compiled for
 #endif
+#ifndef BL_POSAX_WAVES
+#define BL_POSAX_WAVES 5  // ... and the position-tiled minimizer kernel that decides on murmur64_top
+#endif
 #ifndef BL_CSRT_WAVES
 #define BL_CSRT_WAVES 3  // ... and the closed-syncmer kernels for a window count given at run time
 #endif
@@ -167,8 +170,9 @@ __device__ __forceinline__ void count_tile(const ScanParams& p, TileShared<MODE,
 #else
     constexpr bool AP = DIRECT && CS;  // ... on murmur64_top (phase_hash_closed)
 #endif
+    constexpr bool MAX = MODE == MODE_MINIMIZER && SY == 2;  // minimizer scans: windows decided on murmur64_top, the exact form in scan_redo_kernel
     if (DIRECT) phase_hash_closed<MODE, W, (DIRECT ? U : 1), SY == 2, AP>(p, sh, tid, st, &tie);
-    else phase_hash<MODE, W, (MODE != MODE_SYNCMER && U >= 1 && U <= 16 ? U : 0), U == 0>(p, sh, tid, st);
+    else phase_hash<MODE, W, (MODE != MODE_SYNCMER && U >= 1 && U <= 16 ? U : 0), U == 0, MAX>(p, sh, tid, st);
 
     uint32_t packed;
     if constexpr (MODE == MODE_SYNCMER && CS && W < 0) {  // closed syncmers for any (k, s): w by run time (W = -8: w <= 17, W = -16: 18 <= w <= 32)
@@ -188,6 +192,9 @@ __device__ __forceinline__ void count_tile(const ScanParams& p, TileShared<MODE,
         uint32_t af[S + 1];
         phase_sync_fwd<MODE, W>(p, sh, tid, st, nullptr, af);
         packed = phase_sync_rev<MODE, W>(p, sh, tid, q0, st, nullptr, af);
+    } else if (MAX) {
+        packed = phase_window<MODE, W, MAX>(p, sh, tid, q0, st, nullptr, &tie);
+        if (BL_COLD(wave_any(tie)) && (tid & 63) == 0) sh.redo = 1;
     } else {
         packed = phase_window<MODE, W>(p, sh, tid, q0, st, nullptr);
     }
@@ -322,7 +329,7 @@ __device__ __forceinline__ void emit_tile(const ScanParams& p, uint32_t* codes, 
 // (constant shifts and masks in the roller, no strand selects).  U = 0 / C = -1: taken from the arguments.
 // SY: the syncmer form (count_tile): 1 = closed syncmers (offsets {0, W - 1}; phase_sync_closed), 2 = argmins with the exact form deferred
 template <int MODE, int W, int U, int C, int SY = 0>
-__global__ __launch_bounds__(TPB, (SY == 1 && W < 0 ? BL_CSRT_WAVES : SY == 1 ? BL_CS_WAVES : SY == 2 ? BL_SY2_WAVES : (MODE == MODE_SYNCMER && W > 0 ? BL_SY0_WAVES : MODE == MODE_SYNCMER || (MODE == MODE_SUPERKMER && W == -32) ? 2 : (W == -32 || (W < 0 && MODE == MODE_SUPERKMER) ? 3 : (W == -16 ? 5 : (W < 0 ? 4 : (W <= 11 ? 5 : 4))))))) void scan_count_kernel(const ScanParams pin, GroupRange g)
+__global__ __launch_bounds__(TPB, (MODE == MODE_MINIMIZER && SY == 2 ? BL_POSAX_WAVES : SY == 1 && W < 0 ? BL_CSRT_WAVES : SY == 1 ? BL_CS_WAVES : SY == 2 ? BL_SY2_WAVES : (MODE == MODE_SYNCMER && W > 0 ? BL_SY0_WAVES : MODE == MODE_SYNCMER || (MODE == MODE_SUPERKMER && W == -32) ? 2 : (W == -32 || (W < 0 && MODE == MODE_SUPERKMER) ? 3 : (W == -16 ? 5 : (W < 0 ? 4 : (W <= 11 ? 5 : 4))))))) void scan_count_kernel(const ScanParams pin, GroupRange g)
 {
     __shared__ TileShared<MODE, W> sh;
     ScanParams p = pin;
@@ -711,9 +718,15 @@ static hipError_t launch_count_mode(const ScanParams& p, GroupRange g, hipStream
 {
     const dim3 grid(g.count), block(TPB);
     // the BASELINE.json configurations, fully specialised
-    // (pass 1 on murmur64_top, as in the read-tiled headline kernel, was tried for these two: the minimizer kernel then needs 100
-    // registers where five waves per SIMD leave 96, and the super-k-mer scan ran no faster with it, 394 against 397 Gbp/s)
+    // (pass 1 on murmur64_top for the super-k-mer scan: no faster, 394 against 397 Gbp/s)
     if (MODE == MODE_MINIMIZER && p.w == 11 && p.unit == 31 && p.canonical) {
+#ifndef BL_NO_POSAX
+        if (p.redo_list && g.first == 0 && !p.exact_windows) {  // long reads, contigs, reads of mixed lengths: windows decided on murmur64_top here too
+            hipLaunchKernelGGL((scan_count_kernel<MODE_MINIMIZER, 11, 31, 1, 2>), grid, block, 0, stream, p, g);
+            hipLaunchKernelGGL((scan_redo_kernel<MODE_MINIMIZER, 11, 31, 1>), dim3(g.count < 512u ? g.count : 512u), block, 0, stream, p);
+            return hipGetLastError();
+        }
+#endif
         hipLaunchKernelGGL((scan_count_kernel<MODE, 11, 31, 1>), grid, block, 0, stream, p, g);
         return hipGetLastError();
     }

@@ -3,9 +3,20 @@
 // (the Python binding uses torch.distributed for the same reduction; biolib_amd/shard.py).  Compiled against the installed
 // <rccl/rccl.h>; librccl.so.1 itself is opened on first use — a one-GPU deployment does not need it at run time — and must
 // report the header's major version.
+//
+// Build-time requirement: the RCCL development header.  A ROCm install without it still builds the library — bl_count_allreduce then
+// returns BL_ERR_HIP with a message that says so (every other entry point is unaffected: one-GPU deployments need neither the
+// header nor the library).
 #include <dlfcn.h>
 #include <hip/hip_runtime_api.h>
+#if defined(__has_include)
+#if __has_include(<rccl/rccl.h>) && !defined(BL_NO_RCCL_HEADER)
+#define BL_HAVE_RCCL_HEADER 1
+#endif
+#endif
+#ifdef BL_HAVE_RCCL_HEADER
 #include <rccl/rccl.h>  // types, enumerators and prototypes of the INSTALLED RCCL; the library itself is opened on first use
+#endif
 
 #include <map>
 #include <memory>
@@ -17,6 +28,13 @@
 #include "../../include/biolib_amd.h"
 
 extern int bl_set_error(int code, const char* msg);  // bl_capi.hip
+
+#ifndef BL_HAVE_RCCL_HEADER
+extern "C" int bl_count_allreduce(bl_ctx* const*, int, uint64_t*, int)
+{
+    return bl_set_error(BL_ERR_HIP, "bl_count_allreduce: this library was built without <rccl/rccl.h> (RCCL development header absent at build time)");
+}
+#else
 struct bl_ctx;
 hipStream_t bl_ctx_stream(bl_ctx* ctx);
 int bl_ctx_device(bl_ctx* ctx);
@@ -151,3 +169,5 @@ extern "C" int bl_count_allreduce(bl_ctx* const* ctxs, int n_gpu, uint64_t* coun
     if (e != hipSuccess) return bl_set_error(BL_ERR_HIP, hipGetErrorString(e));
     return BL_OK;
 }
+
+#endif  // BL_HAVE_RCCL_HEADER

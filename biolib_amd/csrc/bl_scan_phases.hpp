@@ -206,9 +206,9 @@ BL_DEV uint32_t revcomp16(uint32_t c)
 // GENERIC: the kernel takes the unit length at run time (64-bit rolling registers with run-time shifts).  Those kernels hash with the
 // compiler's own multiply: the split one (mul64c) holds more register pairs alive, and compiled for five waves per SIMD they
 // spilled into the hashing loop with it (unit 15, w 10 on 150-bp reads: 381 -> 218 Gbp/s until this was noticed).
-// SPLIT (syncmer scans): hash with the split multiply (mul64c).  Not used: the argmin kernels run at two waves per SIMD (see murmur64_plain) and the
-// closed-syncmer kernels for a run-time width, at three, spill five times as much with it (149 scratch accesses against 32)
-template <int MODE, int W, int U = 0, bool GENERIC = false, bool SPLIT = false>
+// APPROX (minimizer scans, rolling registers): st.h[s] holds murmur64_top in its high dword (low dword 0) and st.hmax the largest of them, as in
+// phase_hash_frl: the window phase works on those and reports what it cannot decide
+template <int MODE, int W, int U = 0, bool GENERIC = false, bool APPROX = false>
 BL_DEV void phase_hash(const ScanParams& p, TileShared<MODE, W>& sh, int tid, ThreadState& st)
 {
     const int wv = wave_index(tid), lane = tid & 63;
@@ -226,8 +226,8 @@ BL_DEV void phase_hash(const ScanParams& p, TileShared<MODE, W>& sh, int tid, Th
         for (int s = 0; s < S; ++s) {
             roller_step(r, s);
             roller_step(rk, s);
-            st.h[s] = SPLIT ? murmur64(roller_fwd(r), p.seed) : murmur64_plain(roller_fwd(r), p.seed);  // (the compiler's multiply: see murmur64_plain)
-            st.h2[s] = SPLIT ? murmur64(roller_rc(r), p.seed) : murmur64_plain(roller_rc(r), p.seed);
+            st.h[s] = murmur64_plain(roller_fwd(r), p.seed);  // (the compiler's multiply here: see murmur64_plain)
+            st.h2[s] = murmur64_plain(roller_rc(r), p.seed);
             if (p.canonical && roller_rc(rk) < roller_fwd(rk)) strand |= 1u << s;  // kmer_view.hpp:196
         }
         st.strand = strand;
@@ -244,13 +244,21 @@ BL_DEV void phase_hash(const ScanParams& p, TileShared<MODE, W>& sh, int tid, Th
             st.h[s] = murmur64(v, p.seed);
         }
     } else {
+        uint32_t hmax = 0;
         BL_UNROLL
         for (int s = 0; s < S; ++s) {
             roller_step(r, s);
             const uint64_t fw = roller_fwd(r), rv = roller_rc(r);
             const uint64_t v = (p.canonical && rv < fw) ? rv : fw;  // minimizer_view.hpp:236-238
-            st.h[s] = GENERIC ? murmur64_plain(v, p.seed) : murmur64(v, p.seed);
+            if (APPROX) {
+                const uint32_t top = murmur64_top(v, p.seed);
+                hmax = top > hmax ? top : hmax;
+                st.h[s] = (uint64_t)top << 32;
+            } else {
+                st.h[s] = GENERIC ? murmur64_plain(v, p.seed) : murmur64(v, p.seed);
+            }
         }
+        st.hmax = hmax;
     }
     (void)sh;  // the runtime-width kernels write hashes to LDS only in their exact branch (lane_window_argmin_generic)
 }
@@ -346,7 +354,9 @@ __device__ unsigned long long bl_dbg_fallbacks;
 // DEFER: no exact form in here — a prefix tie in a lane that owns windows is reported through *tie, and the caller has the whole
 // tile decided again by a kernel that carries the exact form (the syncmer scan: without it, and without the hashes' low dwords it
 // would keep alive, the kernel fits three waves per SIMD instead of two).
-template <int NW, int W, bool LEFT, bool SECOND, bool RAW = false, bool DEFER = false>
+// APPROX (with DEFER): the keys come from murmur64_top — two of them are told apart when their prefixes are two or more apart, and a lane that
+// holds a key whose prefix could wrap reports a tie whether it owns windows or not (its keys are the halo of lanes that do)
+template <int NW, int W, bool LEFT, bool SECOND, bool RAW = false, bool DEFER = false, bool APPROX = false>
 BL_DEV void lane_window_argmin(const ThreadState* all, int tid, const ThreadState& st, bool owns, uint32_t* a, bool* tie = nullptr)
 {
     uint32_t key[S + W];
@@ -364,9 +374,10 @@ BL_DEV void lane_window_argmin(const ThreadState* all, int tid, const ThreadStat
         }
     }
 #endif
-    const uint32_t dmin = window_argmin_packed<NW, W, LEFT, RAW && LEFT>(key, a);
+    static_assert(!APPROX || DEFER, "keys from murmur64_top: no exact form in here");
+    const uint32_t dmin = window_argmin_packed<NW, W, LEFT, RAW && LEFT, APPROX>(key, a);
     if (DEFER) {
-        if (owns && dmin < 64u) *tie = true;
+        if ((owns && dmin < (APPROX ? 128u : 64u)) || (APPROX && st.hmax >= 0xffffffc0u)) *tie = true;
         return;
     }
     if (BL_COLD(wave_any(owns && dmin < 64u))) {
@@ -557,16 +568,18 @@ constexpr bool pos_occ_form() { return MODE == MODE_MINIMIZER && W >= 2 && W <= 
 // ------------------------------------------------------------------------------------------------
 // Phase 3 (minimizer / super-k-mer): window argmins, validity, start/end decisions.
 // Returns the packed per-thread counts: starts | ends << 16.
-template <int MODE, int W>
+// APPROX: the hashes are murmur64_top values (phase_hash<..., APPROX>); *tie is set where a lane could not tell two keys apart, and the
+// caller has the tile decided again on the hashes themselves
+template <int MODE, int W, bool APPROX = false>
 BL_DEV uint32_t phase_window(const ScanParams& p, TileShared<MODE, W>& sh, int tid, int64_t q0, ThreadState& st,
-                             const ThreadState* all)
+                             const ThreadState* all, bool* tie = nullptr)
 {
     const int wv = wave_index(tid), lane = tid & 63;
     const int w = W > 0 ? W : p.w;
     uint32_t a[S + 1];
     uint32_t below = 0x1ffffu;  // w = 1 with a hash threshold (hash_sampler): bit s = hash of unit s is below it
     if (W > 1) {
-        lane_window_argmin<S + 1, (W > 1 ? W : 2), true, false, true>(all, tid, st, owned_mask(p, tid & 63) != 0, a);
+        lane_window_argmin<S + 1, (W > 1 ? W : 2), true, false, true, APPROX, APPROX>(all, tid, st, owned_mask(p, tid & 63) != 0, a, tie);
     } else if (W == 1) {
         uint64_t e[S + 1];
         BL_UNROLL

@@ -118,9 +118,11 @@ class Context:
     def mark_times(self):
         """synchronises; milliseconds after the first marker at which the work in front of each marker had finished; forgets the markers"""
         n = C.c_uint32()
-        buf = (C.c_double * 4096)()
-        check(self._lib.bl_ctx_mark_times(self._h, buf, 4096, C.byref(n)))
-        return [float(buf[i]) for i in range(min(int(n.value), 4096))]
+        check(self._lib.bl_ctx_mark_times(self._h, None, 0, C.byref(n)))  # capacity 0: how many there are (they stay)
+        k = int(n.value)
+        buf = (C.c_double * max(k, 1))()
+        check(self._lib.bl_ctx_mark_times(self._h, buf, k, C.byref(n)))
+        return [float(buf[i]) for i in range(k)]
 
     # ---- batches
     def upload(self, bases, offsets=None, read_len=0):

@@ -200,7 +200,9 @@ int bl_ctx_kernel_time(bl_ctx* ctx, double* total_ms, uint64_t* launches);
 /* Markers on the device's timeline that do not stop it.  bl_ctx_mark enqueues one behind everything issued so far on the
  * context's stream(s); bl_ctx_mark_times synchronises, returns for each marker the milliseconds after marker 0 was reached at
  * which the work in front of it had finished (with two lanes: on both), and forgets the markers.  A benchmark times its steps
- * with them: a bl_ctx_sync between steps would cost the overlap of one step's last record pass with the next step's first scan. */
+ * with them: a bl_ctx_sync between steps would cost the overlap of one step's last record pass with the next step's first scan.
+ * At most 4,096 markers may be outstanding (BL_ERR_CAPACITY from bl_ctx_mark beyond that).  bl_ctx_mark_times with a capacity
+ * below the number of markers returns that number in *n_marks and keeps them: BL_OK for capacity 0 (a size query), BL_ERR_CAPACITY otherwise. */
 int bl_ctx_mark(bl_ctx* ctx);
 int bl_ctx_mark_times(bl_ctx* ctx, double* ms, uint32_t capacity, uint32_t* n_marks);
 

@@ -35,7 +35,7 @@ std::vector<uint32_t> make_start_bits(uint64_t n_bases, const uint64_t* offsets,
 }
 
 // pass 1 (scan_count_kernel) for every tile, the tile-count prefix scan, pass 2 (scan_emit_kernel)
-int g_closed_redone = 0, g_sy2_redone = 0;
+int g_closed_redone = 0, g_sy2_redone = 0, g_pos_redone = 0;
 
 // SY: the syncmer form of count_tile (bl_kernels.hip): 0 = argmins with the exact form inline, 1 = closed syncmers on murmur64_top,
 // 2 = argmins from phase_hash_closed<BOTH> with the exact form deferred to a second run of the tile (scan_redo_kernel)
@@ -67,6 +67,8 @@ void run_tiles(ScanParams p, unsigned long long* result)
                 for (int tid = 0; tid < TPB; ++tid) phase_hash_closed<MODE, W, (CSU ? CSU : 1), false, true>(p, *sh, tid, st[tid]);
             } else if (CSU) {
                 for (int tid = 0; tid < TPB; ++tid) phase_hash_closed<MODE, W, (CSU ? CSU : 1), true, false>(p, *sh, tid, st[tid], &sy2_tie);
+            } else if (MODE == MODE_MINIMIZER && SY == 2) {  // count_tile's MAX form: windows decided on murmur64_top
+                for (int tid = 0; tid < TPB; ++tid) phase_hash<MODE, W, 0, false, true>(p, *sh, tid, st[tid]);
             } else {
                 for (int tid = 0; tid < TPB; ++tid) phase_hash<MODE, W, (MODE != MODE_SYNCMER ? U : 0)>(p, *sh, tid, st[tid]);
             }
@@ -103,6 +105,15 @@ void run_tiles(ScanParams p, unsigned long long* result)
                 for (int tid = 0; tid < TPB; ++tid) phase_sync_fwd<MODE, W>(p, *sh, tid, st[tid], st.data(), &af[tid * (S + 1)]);
                 for (int tid = 0; tid < TPB; ++tid)
                     packed[tid] = phase_sync_rev<MODE, W>(p, *sh, tid, q0, st[tid], st.data(), &af[tid * (S + 1)]);
+            } else if (MODE == MODE_MINIMIZER && SY == 2) {
+                bool tie = false;
+                for (int tid = 0; tid < TPB; ++tid) packed[tid] = phase_window<MODE, W, MODE == MODE_MINIMIZER && SY == 2>(p, *sh, tid, q0, st[tid], st.data(), &tie);
+                if (tie) {  // scan_redo_kernel<MINIMIZER, W, U, C>: the tile again on the hashes themselves
+                    ++g_pos_redone;
+                    std::memset(st.data(), 0x5A, st.size() * sizeof(ThreadState));
+                    for (int tid = 0; tid < TPB; ++tid) phase_hash<MODE, W>(p, *sh, tid, st[tid]);
+                    for (int tid = 0; tid < TPB; ++tid) packed[tid] = phase_window<MODE, W>(p, *sh, tid, q0, st[tid], st.data());
+                }
             } else {
                 for (int tid = 0; tid < TPB; ++tid) packed[tid] = phase_window<MODE, W>(p, *sh, tid, q0, st[tid], st.data());
             }
@@ -273,6 +284,10 @@ void run_mode(const ScanParams& p, unsigned long long* result)
         else run_tiles<MODE_SYNCMER, -16, 1>(p, result);
         return;
     }
+    if (MODE == MODE_MINIMIZER && p.w == 11 && p.unit == 31 && p.canonical) {  // the BASELINE shape, position-tiled: decided on murmur64_top (launch_count_mode)
+        run_tiles<MODE_MINIMIZER, 11, 2>(p, result);
+        return;
+    }
     if (MODE == MODE_MINIMIZER && p.w >= 2 && p.w <= 32) {  // a kernel per width (launch_count_mode)
         constexpr int MM = MODE_MINIMIZER;
         switch (p.w) {
@@ -395,6 +410,7 @@ int emu_frl_scans() { return g_frl_scans; }
 int emu_frl_redone() { return g_frl_redone; }
 int emu_closed_redone() { return g_closed_redone; }
 int emu_sy2_redone() { return g_sy2_redone; }
+int emu_pos_redone() { return g_pos_redone; }
 int emu_frl_tiles() { return g_frl_tiles; }
 
 void emu_hash_sample(const EmuBatch* b, uint64_t first, uint64_t n, unsigned k, uint64_t seed, uint64_t threshold, unsigned flags,

@@ -32,6 +32,7 @@ int emu_frl_scans();
 int emu_frl_redone();
 int emu_closed_redone();
 int emu_sy2_redone();
+int emu_pos_redone();
 int emu_frl_tiles();
 }
 
@@ -298,6 +299,8 @@ int main(int argc, char** argv)
     CHECK(emu_frl_scans() > 100, "the read-tiled path was hardly exercised: %d scans", emu_frl_scans());
     std::printf("read-tiled scans run: %d (tiles %d, of which decided again on the hashes: %d; tiles of closed-syncmer scans decided again: %d, of argmin syncmer scans with the exact form deferred: %d)\n", emu_frl_scans(), emu_frl_tiles(), emu_frl_redone(), emu_closed_redone(), emu_sy2_redone());
     CHECK(emu_sy2_redone() > 0, "no tile of a deferred-argmin syncmer scan was decided again: the tie path did not run");
+    std::printf("tiles of the position-tiled minimizer scan on murmur64_top decided again: %d\n", emu_pos_redone());
+    CHECK(emu_pos_redone() > 0, "no tile of the position-tiled approximate minimizer scan was decided again: the tie path did not run");
 
     if (g_fail) {
         std::printf("emu_selftest: %d mismatches\n", g_fail);

@@ -5,7 +5,7 @@ traffic.json — each stamped with where and from which commit it was measured. 
 import collections, csv, json, os, shutil, subprocess, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-RND = sys.argv[1] if len(sys.argv) > 1 else "r03"
+RND = sys.argv[1] if len(sys.argv) > 1 else "r04"
 src = os.path.join(ROOT, "gpurun_out", "prof")
 dst = os.path.join(ROOT, "profiles")
 sys.path.insert(0, ROOT)
@@ -44,10 +44,10 @@ for lanes in ("lanes2", "lanes1"):
 
 # kernel key -> substring of the kernel name rocprofv3 reports
 kernels = {
-    "c3_count": "scan_count_frl_kernel<0, 11, 15, 31, 150, 1, true>", "c3_emit": "scan_emit_kernel<0>",
+    "c3_count": "scan_count_frl_kernel<0, 11, 15, 31, 150, 1, true>", "c3_emit": "scan_emit_kernel<0, 31, 1, 1>",
     "c2_kmer": "kmer_kernel",
-    "c4_count": "scan_count_kernel<1, 17, 15, 1, 0>", "c4_emit": "scan_emit_kernel<1>",
-    "c5_count": "scan_count_kernel<2, 21, 11, 1, 1>", "c5_emit": "scan_emit_kernel<2>",
+    "c4_count": "scan_count_kernel<1, 17, 15, 1, 0>", "c4_emit": "scan_emit_kernel<1, 0, -1, -1>",
+    "c5_count": "scan_count_kernel<2, 21, 11, 1, 1>", "c5_emit": "scan_emit_kernel<2, 0, -1, -1>",
     "c3_redo": "scan_redo_frl_kernel<0, 11, 15, 31, 150, 1>", "c5_redo": "scan_redo_kernel<2, 21, 11, 1>",  # the tiles pass 1 could not decide, again
 }
 means = {k: {} for k in kernels}
