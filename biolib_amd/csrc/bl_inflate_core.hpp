@@ -706,6 +706,9 @@ BL_IDEV uint32_t inflate_member(Shared& sh, In& in, uint32_t n_in, uint8_t* out,
                     b.drop((int)(de & 15u));
                     const uint32_t dist = ((de >> 8) & 0x7fffu) + b.take((int)((de >> 4) & 15u));
                     bad |= (de & E_RESERVED) | (uint32_t)(dist > q - shift);
+#ifdef BL_INFLATE_HIST  // (host harness only: how far back matches reach; tests/emu/emu_inflate.cpp --hist)
+                    BL_INFLATE_HIST(dist, len);
+#endif
                     // the previous match's bytes go into the ring now (see below), then the literals written since are in place
                     BL_LANES(lane)
                     {

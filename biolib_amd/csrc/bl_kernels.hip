@@ -15,7 +15,10 @@
 #define BL_CS_WAVES 3  // waves per SIMD the closed-syncmer kernel is compiled for
 #endif
 #ifndef BL_POSAX_WAVES
-#define BL_POSAX_WAVES 5  // ... and the position-tiled minimizer kernel that decides on murmur64_top
+#define BL_POSAX_WAVES 4  // ... and the position-tiled minimizer kernel that decides on murmur64_top (111 registers; compiled for 5 it spills 30 accesses and runs at the exact kernel's rate, 4 gives +5.5 %)
+#endif
+#ifndef BL_SKAX_WAVES
+#define BL_SKAX_WAVES 4  // ... and the BASELINE super-k-mer kernel that decides on murmur64_top
 #endif
 #ifndef BL_CSRT_WAVES
 #define BL_CSRT_WAVES 3  // ... and the closed-syncmer kernels for a window count given at run time
@@ -170,7 +173,7 @@ __device__ __forceinline__ void count_tile(const ScanParams& p, TileShared<MODE,
 #else
     constexpr bool AP = DIRECT && CS;  // ... on murmur64_top (phase_hash_closed)
 #endif
-    constexpr bool MAX = MODE == MODE_MINIMIZER && SY == 2;  // minimizer scans: windows decided on murmur64_top, the exact form in scan_redo_kernel
+    constexpr bool MAX = MODE != MODE_SYNCMER && SY == 2;  // minimizer / super-k-mer scans: windows decided on murmur64_top, the exact form in scan_redo_kernel
     if (DIRECT) phase_hash_closed<MODE, W, (DIRECT ? U : 1), SY == 2, AP>(p, sh, tid, st, &tie);
     else phase_hash<MODE, W, (MODE != MODE_SYNCMER && U >= 1 && U <= 16 ? U : 0), U == 0, MAX>(p, sh, tid, st);
 
@@ -329,7 +332,7 @@ __device__ __forceinline__ void emit_tile(const ScanParams& p, uint32_t* codes, 
 // (constant shifts and masks in the roller, no strand selects).  U = 0 / C = -1: taken from the arguments.
 // SY: the syncmer form (count_tile): 1 = closed syncmers (offsets {0, W - 1}; phase_sync_closed), 2 = argmins with the exact form deferred
 template <int MODE, int W, int U, int C, int SY = 0>
-__global__ __launch_bounds__(TPB, (MODE == MODE_MINIMIZER && SY == 2 ? BL_POSAX_WAVES : SY == 1 && W < 0 ? BL_CSRT_WAVES : SY == 1 ? BL_CS_WAVES : SY == 2 ? BL_SY2_WAVES : (MODE == MODE_SYNCMER && W > 0 ? BL_SY0_WAVES : MODE == MODE_SYNCMER || (MODE == MODE_SUPERKMER && W == -32) ? 2 : (W == -32 || (W < 0 && MODE == MODE_SUPERKMER) ? 3 : (W == -16 ? 5 : (W < 0 ? 4 : (W <= 11 ? 5 : 4))))))) void scan_count_kernel(const ScanParams pin, GroupRange g)
+__global__ __launch_bounds__(TPB, (MODE == MODE_MINIMIZER && SY == 2 ? BL_POSAX_WAVES : MODE == MODE_SUPERKMER && SY == 2 ? BL_SKAX_WAVES : SY == 1 && W < 0 ? BL_CSRT_WAVES : SY == 1 ? BL_CS_WAVES : SY == 2 ? BL_SY2_WAVES : (MODE == MODE_SYNCMER && W > 0 ? BL_SY0_WAVES : MODE == MODE_SYNCMER || (MODE == MODE_SUPERKMER && W == -32) ? 2 : (W == -32 || (W < 0 && MODE == MODE_SUPERKMER) ? 3 : (W == -16 ? 5 : (W < 0 ? 4 : (W <= 11 ? 5 : 4))))))) void scan_count_kernel(const ScanParams pin, GroupRange g)
 {
     __shared__ TileShared<MODE, W> sh;
     ScanParams p = pin;
@@ -731,6 +734,13 @@ static hipError_t launch_count_mode(const ScanParams& p, GroupRange g, hipStream
         return hipGetLastError();
     }
     if (MODE == MODE_SUPERKMER && p.w == 17 && p.unit == 15 && p.canonical) {
+#ifndef BL_NO_SKAX
+        if (p.redo_list && g.first == 0 && !p.exact_windows) {  // BASELINE C4: windows decided on murmur64_top, the listed tiles again on the hashes
+            hipLaunchKernelGGL((scan_count_kernel<MODE_SUPERKMER, 17, 15, 1, 2>), grid, block, 0, stream, p, g);
+            hipLaunchKernelGGL((scan_redo_kernel<MODE_SUPERKMER, 17, 15, 1>), dim3(g.count < 512u ? g.count : 512u), block, 0, stream, p);
+            return hipGetLastError();
+        }
+#endif
         hipLaunchKernelGGL((scan_count_kernel<MODE, 17, 15, 1>), grid, block, 0, stream, p, g);
         return hipGetLastError();
     }

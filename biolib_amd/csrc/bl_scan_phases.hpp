@@ -233,6 +233,7 @@ BL_DEV void phase_hash(const ScanParams& p, TileShared<MODE, W>& sh, int tid, Th
         st.strand = strand;
     } else if (U >= 1 && U <= 16) {
         const uint32_t r0 = revcomp16(c2), r1 = revcomp16(c1), r2 = revcomp16(c0);  // base b of the lane = base 47 - b of r0:r1:r2
+        uint32_t hmax = 0;
         BL_UNROLL
         for (int s = 0; s < S; ++s) {
             const uint32_t fw = bases_at(c0, c1, c2, s, U >= 1 && U <= 16 ? U : 1);
@@ -241,8 +242,15 @@ BL_DEV void phase_hash(const ScanParams& p, TileShared<MODE, W>& sh, int tid, Th
                 const uint32_t rv = bases_at(r0, r1, r2, 48 - (U >= 1 && U <= 16 ? U : 1) - s, U >= 1 && U <= 16 ? U : 1);
                 v = rv < fw ? rv : fw;  // numeric minimum, minimizer_view.hpp:236-238
             }
-            st.h[s] = murmur64(v, p.seed);
+            if (APPROX) {
+                const uint32_t top = murmur64_top(v, p.seed);
+                hmax = top > hmax ? top : hmax;
+                st.h[s] = (uint64_t)top << 32;
+            } else {
+                st.h[s] = murmur64(v, p.seed);
+            }
         }
+        st.hmax = hmax;
     } else {
         uint32_t hmax = 0;
         BL_UNROLL

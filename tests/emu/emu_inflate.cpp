@@ -12,6 +12,9 @@
 #include <vector>
 
 #define BL_INFLATE_EMU 1
+// match statistics of the decoded streams (--hist): matches and matched bytes by distance, in 4-KiB bins of the 32-KiB window
+static unsigned long long g_hist_n[8], g_hist_bytes[8];
+#define BL_INFLATE_HIST(dist, len) do { const unsigned b_ = (unsigned)(((dist) - 1u) >> 12) & 7u; ++g_hist_n[b_]; g_hist_bytes[b_] += (len); } while (0)
 #include "../../biolib_amd/csrc/bl_inflate_core.hpp"
 
 namespace {
@@ -163,6 +166,37 @@ int main(int argc, char** argv)
         const bool ok = r.status == bl_inflate::OK && r.text == text && !r.wrote_outside;
         std::printf("%s status %u\n", ok ? "same" : "DIFFERENT", r.status);
         return ok ? 0 : 1;
+    }
+    // emu_inflate --hist LEVEL: a FASTQ of 150-bp reads (Illumina-style names, binned qualities), 65280-byte members deflated by zlib at
+    // LEVEL, decoded here; prints where the matches reach — the reason the decoder's window is LDS and not the member's own output in HBM:
+    // four letters make any 8-mer recur within a few KiB, and zlib takes those matches wherever in the window it finds them
+    if (argc == 3 && std::string(argv[1]) == "--hist") {
+        const int level = std::atoi(argv[2]);
+        std::mt19937_64 rng(1);
+        std::string text;
+        for (int i = 0; text.size() < 64u * 65280u; ++i) {
+            char name[96];
+            std::snprintf(name, sizeof name, "@A00123:45:HXXXXXXXX:1:1101:%d:%d 1:N:0:ACGTACGT\n", 1000 + i % 30000, 1000 + i / 7);
+            text += name;
+            for (int b = 0; b < 150; ++b) text += "ACGT"[rng() & 3];
+            text += "\n+\n";
+            for (int b = 0; b < 150; ++b) text += (rng() % 100 < 93) ? 'F' : ":,#"[rng() % 3];
+            text += "\n";
+        }
+        unsigned long long text_bytes = 0;
+        for (size_t a = 0; a + 65280 <= text.size(); a += 65280) {
+            const std::vector<uint8_t> chunk(text.begin() + a, text.begin() + a + 65280);
+            const auto packed = deflate_raw(chunk, level, Z_DEFAULT_STRATEGY);
+            const Result r = ours(packed, 65280, 0);
+            if (r.status != bl_inflate::OK || r.text != chunk) return 1;
+            text_bytes += 65280;
+        }
+        unsigned long long n = 0, bytes = 0;
+        for (int b = 0; b < 8; ++b) { n += g_hist_n[b]; bytes += g_hist_bytes[b]; }
+        std::printf("{\"zlib_level\": %d, \"text_bytes\": %llu, \"matches\": %llu, \"matched_bytes\": %llu, \"by_distance_4KiB_bins\": [", level, text_bytes, n, bytes);
+        for (int b = 0; b < 8; ++b) std::printf("%s{\"upto_KiB\": %d, \"matches_frac\": %.4f, \"bytes_frac_of_text\": %.4f}", b ? ", " : "", 4 * (b + 1), (double)g_hist_n[b] / (double)n, (double)g_hist_bytes[b] / (double)text_bytes);
+        std::printf("]}\n");
+        return 0;
     }
     const size_t n_sound = argc > 1 ? std::strtoul(argv[1], nullptr, 10) : 400;
     const size_t n_damaged = argc > 2 ? std::strtoul(argv[2], nullptr, 10) : 4000;

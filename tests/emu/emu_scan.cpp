@@ -67,8 +67,8 @@ void run_tiles(ScanParams p, unsigned long long* result)
                 for (int tid = 0; tid < TPB; ++tid) phase_hash_closed<MODE, W, (CSU ? CSU : 1), false, true>(p, *sh, tid, st[tid]);
             } else if (CSU) {
                 for (int tid = 0; tid < TPB; ++tid) phase_hash_closed<MODE, W, (CSU ? CSU : 1), true, false>(p, *sh, tid, st[tid], &sy2_tie);
-            } else if (MODE == MODE_MINIMIZER && SY == 2) {  // count_tile's MAX form: windows decided on murmur64_top
-                for (int tid = 0; tid < TPB; ++tid) phase_hash<MODE, W, 0, false, true>(p, *sh, tid, st[tid]);
+            } else if (MODE != MODE_SYNCMER && SY == 2) {  // count_tile's MAX form: windows decided on murmur64_top
+                for (int tid = 0; tid < TPB; ++tid) phase_hash<MODE, W, (MODE != MODE_SYNCMER ? U : 0), false, true>(p, *sh, tid, st[tid]);
             } else {
                 for (int tid = 0; tid < TPB; ++tid) phase_hash<MODE, W, (MODE != MODE_SYNCMER ? U : 0)>(p, *sh, tid, st[tid]);
             }
@@ -105,13 +105,13 @@ void run_tiles(ScanParams p, unsigned long long* result)
                 for (int tid = 0; tid < TPB; ++tid) phase_sync_fwd<MODE, W>(p, *sh, tid, st[tid], st.data(), &af[tid * (S + 1)]);
                 for (int tid = 0; tid < TPB; ++tid)
                     packed[tid] = phase_sync_rev<MODE, W>(p, *sh, tid, q0, st[tid], st.data(), &af[tid * (S + 1)]);
-            } else if (MODE == MODE_MINIMIZER && SY == 2) {
+            } else if (MODE != MODE_SYNCMER && SY == 2) {
                 bool tie = false;
-                for (int tid = 0; tid < TPB; ++tid) packed[tid] = phase_window<MODE, W, MODE == MODE_MINIMIZER && SY == 2>(p, *sh, tid, q0, st[tid], st.data(), &tie);
+                for (int tid = 0; tid < TPB; ++tid) packed[tid] = phase_window<MODE, W, MODE != MODE_SYNCMER && SY == 2>(p, *sh, tid, q0, st[tid], st.data(), &tie);
                 if (tie) {  // scan_redo_kernel<MINIMIZER, W, U, C>: the tile again on the hashes themselves
                     ++g_pos_redone;
                     std::memset(st.data(), 0x5A, st.size() * sizeof(ThreadState));
-                    for (int tid = 0; tid < TPB; ++tid) phase_hash<MODE, W>(p, *sh, tid, st[tid]);
+                    for (int tid = 0; tid < TPB; ++tid) phase_hash<MODE, W, (MODE != MODE_SYNCMER ? U : 0)>(p, *sh, tid, st[tid]);
                     for (int tid = 0; tid < TPB; ++tid) packed[tid] = phase_window<MODE, W>(p, *sh, tid, q0, st[tid], st.data());
                 }
             } else {
@@ -305,7 +305,7 @@ void run_mode(const ScanParams& p, unsigned long long* result)
         case 19: if (MODE != MODE_SYNCMER) { run_tiles<MODE, 19>(p, result); break; } run_tiles<MODE, -16>(p, result); break;
         case 11: run_tiles<MODE, 11>(p, result); break;
         case 17:
-            if (MODE == MODE_SUPERKMER && p.unit == 15 && p.canonical) { run_tiles<MODE_SUPERKMER, 17, 0, 15>(p, result); break; }  // the BASELINE C4 kernel
+            if (MODE == MODE_SUPERKMER && p.unit == 15 && p.canonical) { run_tiles<MODE_SUPERKMER, 17, 2, 15>(p, result); break; }  // the BASELINE C4 kernel (windows on murmur64_top)
             run_tiles<MODE, 17>(p, result);
             break;
         case 21:
