@@ -721,7 +721,6 @@ static hipError_t launch_count_mode(const ScanParams& p, GroupRange g, hipStream
 {
     const dim3 grid(g.count), block(TPB);
     // the BASELINE.json configurations, fully specialised
-    // (pass 1 on murmur64_top for the super-k-mer scan: no faster, 394 against 397 Gbp/s)
     if (MODE == MODE_MINIMIZER && p.w == 11 && p.unit == 31 && p.canonical) {
 #ifndef BL_NO_POSAX
         if (p.redo_list && g.first == 0 && !p.exact_windows) {  // long reads, contigs, reads of mixed lengths: windows decided on murmur64_top here too
@@ -734,7 +733,8 @@ static hipError_t launch_count_mode(const ScanParams& p, GroupRange g, hipStream
         return hipGetLastError();
     }
     if (MODE == MODE_SUPERKMER && p.w == 17 && p.unit == 15 && p.canonical) {
-#ifndef BL_NO_SKAX
+#ifdef BL_SKAX  // measured twice (rounds 3 and 4; this form: 112 registers, no spills, 17 % fewer static instructions): 398.5 / 399.9 against 399.0 / 401.6
+               // Gbp/s for the exact kernel, A/B on one box — the super-k-mer scan is not limited by the hash's four instructions.  Not built by default.
         if (p.redo_list && g.first == 0 && !p.exact_windows) {  // BASELINE C4: windows decided on murmur64_top, the listed tiles again on the hashes
             hipLaunchKernelGGL((scan_count_kernel<MODE_SUPERKMER, 17, 15, 1, 2>), grid, block, 0, stream, p, g);
             hipLaunchKernelGGL((scan_redo_kernel<MODE_SUPERKMER, 17, 15, 1>), dim3(g.count < 512u ? g.count : 512u), block, 0, stream, p);

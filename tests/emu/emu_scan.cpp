@@ -305,7 +305,7 @@ void run_mode(const ScanParams& p, unsigned long long* result)
         case 19: if (MODE != MODE_SYNCMER) { run_tiles<MODE, 19>(p, result); break; } run_tiles<MODE, -16>(p, result); break;
         case 11: run_tiles<MODE, 11>(p, result); break;
         case 17:
-            if (MODE == MODE_SUPERKMER && p.unit == 15 && p.canonical) { run_tiles<MODE_SUPERKMER, 17, 2, 15>(p, result); break; }  // the BASELINE C4 kernel (windows on murmur64_top)
+            if (MODE == MODE_SUPERKMER && p.unit == 15 && p.canonical) { run_tiles<MODE_SUPERKMER, 17, 0, 15>(p, result); break; }  // the BASELINE C4 kernel
             run_tiles<MODE, 17>(p, result);
             break;
         case 21:

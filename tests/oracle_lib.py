@@ -42,6 +42,8 @@ def oracle():
         L.blo_murmur3_x64_128.argtypes = [vp, C.c_int, C.c_uint32, vp]
         L.blo_hash64_u64.restype = C.c_uint64
         L.blo_hash64_u64.argtypes = [C.c_uint64, C.c_uint64]
+        L.blo_hash64_u64_general.restype = C.c_uint64
+        L.blo_hash64_u64_general.argtypes = [C.c_uint64, C.c_uint64]
         L.blo_hash64_bytes.restype = C.c_uint64
         L.blo_hash64_bytes.argtypes = [vp, C.c_uint32, C.c_uint32]
         L.blo_remix.restype = C.c_uint64

@@ -175,3 +175,15 @@ def test_live_against_reference_library():
             for canon in (0, 1):
                 got = O.syncmers(s, one, k, m, a, b, canon, drop_last=True, positions=False)[0]
                 assert got == R.ref_syncmer_count(O._ptr(s), n, k, m, a, b, canon)
+
+
+def test_closed_form_hash_equals_the_general_murmur3():
+    """blo_hash64_u64 (MurmurHash3_x64_128 written out for an 8-byte key, what the timed CPU baseline runs) against the byte-wise
+    general form on random keys and seeds, seeds beyond 32 bits among them (hash.hpp:16,50 truncates them)"""
+    rng = np.random.default_rng(11)
+    L = O.oracle()
+    for v, s in zip(rng.integers(0, 2**64, 20000, dtype=np.uint64), rng.integers(0, 2**40, 20000, dtype=np.uint64)):
+        assert L.blo_hash64_u64(int(v), int(s)) == L.blo_hash64_u64_general(int(v), int(s))
+    for v in (0, 1, 2**64 - 1, 0x0123456789abcdef):
+        for s in (0, 42, 2**32 - 1, 2**32 + 42):
+            assert L.blo_hash64_u64(v, s) == L.blo_hash64_u64_general(v, s)

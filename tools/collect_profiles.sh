@@ -25,4 +25,10 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write 
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES SQ_BUSY_CYCLES --output-format csv -d $OUT/pmc_sq1 -o p -- $PMC_CMD > $OUT/pmc_sq1.log 2>&1 || exit 1
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_LDS --output-format csv -d $OUT/pmc_sq2 -o p -- $PMC_CMD > $OUT/pmc_sq2.log 2>&1 || exit 1
 rocprofv3 --kernel-trace --pmc SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_sq3 -o p -- $PMC_CMD > $OUT/pmc_sq3.log 2>&1 || exit 1
+# 4. power / clock sensors beside the headline scan, two lanes and one (is the shader clock held by the card's power management?), and the
+#    shape sweep off the BASELINE shapes
+cd $ROOT
+python3 tools/power_probe.py $OUT/power_lanes2.json -- python3 bench.py --steps 40 --no-cpu-baseline --no-other-configs --no-next-rows --no-h2d > $OUT/power_lanes2.log 2>&1 || exit 1
+python3 tools/power_probe.py $OUT/power_lanes1.json -- python3 bench.py --lanes 1 --steps 40 --no-cpu-baseline --no-other-configs --no-next-rows --no-h2d > $OUT/power_lanes1.log 2>&1 || exit 1
+python3 tests/perf/shape_sweep.py 3 > $OUT/shape_sweep.json 2> $OUT/shape_sweep.err || exit 1
 find $OUT -name "*.csv" | head -40

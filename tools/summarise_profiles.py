@@ -42,6 +42,27 @@ for lanes in ("lanes2", "lanes1"):
     if line:
         open(os.path.join(dst, f"{RND}_bench_1gpu{'' if lanes == 'lanes2' else '_lanes1'}_under_rocprof.json"), "w").write(line[-1] + "\n")
 
+# power / clock sensors of the card beside the headline scan (tools/power_probe.py), and the shape sweep
+power = {}
+for lanes in ("lanes2", "lanes1"):
+    pj, lg = os.path.join(src, f"power_{lanes}.json"), os.path.join(src, f"power_{lanes}.log")
+    if os.path.exists(pj):
+        d = json.load(open(pj))
+        busy = {k: v for k, v in d["sensors"].items() if k.endswith("power1_input") and v["max"] > 600e6}  # the card that ran the scan
+        card = (list(busy) or [""])[0].split(":")[0]
+        line = [x for x in open(lg).read().splitlines() if x.startswith("{\"metric")] if os.path.exists(lg) else []
+        bl = json.loads(line[-1]) if line else {}
+        power[lanes] = {"sensors": {k: v for k, v in d["sensors"].items() if k.startswith(card + ":")}, "seconds": d["seconds"],
+                        "bench": {"value_Gbps": bl.get("value"), "shader_clock_GHz_in_timed_region": bl.get("roofline", {}).get("valu", {}).get("shader_clock_GHz"), "steps": bl.get("steps")},
+                        "trace_every_10th": [(t, {k.split(":")[1]: v for k, v in s.items() if k.startswith(card + ":")}) for t, s in d["trace_every_10th"]]}
+if power:
+    json.dump({"provenance": prov, "note": "hwmon sensors of the card sampled every 50 ms beside `bench.py --steps 40` (C3, 50 Gbp): power in microwatts, clocks in Hz", **power},
+              open(os.path.join(dst, f"{RND}_power_probe.json"), "w"), indent=1)
+if os.path.exists(os.path.join(src, "shape_sweep.json")):
+    sw = json.loads(open(os.path.join(src, "shape_sweep.json")).read().strip().splitlines()[-1])
+    sw["provenance"] = prov
+    json.dump(sw, open(os.path.join(dst, f"{RND}_shape_sweep.json"), "w"), indent=1)
+
 # kernel key -> substring of the kernel name rocprofv3 reports
 kernels = {
     "c3_count": "scan_count_frl_kernel<0, 11, 15, 31, 150, 1, true>", "c3_emit": "scan_emit_kernel<0, 31, 1, 1>",
