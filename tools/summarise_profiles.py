@@ -48,8 +48,8 @@ for lanes in ("lanes2", "lanes1"):
     pj, lg = os.path.join(src, f"power_{lanes}.json"), os.path.join(src, f"power_{lanes}.log")
     if os.path.exists(pj):
         d = json.load(open(pj))
-        busy = {k: v for k, v in d["sensors"].items() if k.endswith("power1_input") and v["max"] > 600e6}  # the card that ran the scan
-        card = (list(busy) or [""])[0].split(":")[0]
+        # the card that ran the scan: the host's other cards (other tenants') show in hwmon too; ours draws the most on average
+        card = max((k for k in d["sensors"] if k.endswith("power1_input")), key=lambda k: d["sensors"][k]["mean"]).split(":")[0]
         line = [x for x in open(lg).read().splitlines() if x.startswith("{\"metric")] if os.path.exists(lg) else []
         bl = json.loads(line[-1]) if line else {}
         power[lanes] = {"sensors": {k: v for k, v in d["sensors"].items() if k.startswith(card + ":")}, "seconds": d["seconds"],
