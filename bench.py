@@ -508,14 +508,14 @@ def other_configs(ctx, args, model):
     CH = 1_500_000_000
     res = {}
 
-    def timed(issue, n_bases, kernels, kernel_name, steps=2, lanes=None):
-        # lanes=1: a kernel that IS the whole scan (C2's dense k-mer kernel) gains nothing from two lanes and, run on two, shares the chip
-        # with its own next launch: every event pair would then time a stretched kernel
-        if lanes is not None:
-            ctx.set_option("lanes", lanes)
+    def timed(issue, n_bases, kernels, kernel_name, steps=2, kernel_lanes=None):
+        """`value`: wall time of `steps` passes on the context's lanes.  The dominant kernel's duration comes from the same passes when its
+        launches are serialised on the device (the window scans: pass 1 of consecutive ranges wait for each other); kernel_lanes=1: a kernel
+        that IS the whole scan (C2's dense k-mer kernel) runs beside its own next launch on two lanes — every event pair would then time a
+        stretched kernel (VERDICT r03 weak #4) — so its duration is taken from one more pass on ONE lane, and the roofline fraction with it."""
         issue()
         ctx.sync()
-        ctx.kernel_timing(True)
+        ctx.kernel_timing(kernel_lanes is None)
         probe = ctx.clock_probe_start(5000)  # stopped by clock_probe_finish below
         t0 = time.perf_counter()
         n_ranges = 0
@@ -524,19 +524,28 @@ def other_configs(ctx, args, model):
         ctx.sync()
         dt = time.perf_counter() - t0
         ghz = ctx.clock_probe_finish(probe)
-        kms, launches = ctx.kernel_time()
-        ctx.kernel_timing(False)
-        if lanes is not None:
+        k_steps, k_step_ms = steps, dt / steps * 1e3
+        if kernel_lanes is None:
+            kms, launches = ctx.kernel_time()
+        else:
+            ctx.set_option("lanes", kernel_lanes)
+            ctx.kernel_timing(True)
+            t1 = time.perf_counter()
+            issue()
+            ctx.sync()
+            k_steps, k_step_ms = 1, (time.perf_counter() - t1) * 1e3
+            kms, launches = ctx.kernel_time()
             ctx.set_option("lanes", args.lanes)
-        per_launch = n_bases * steps / max(launches, 1)
+        ctx.kernel_timing(False)
+        per_launch = n_bases * k_steps / max(launches, 1)
         k_s = kms / 1e3 / max(launches, 1)
         achieved = per_launch / k_s / 1e9
-        fits = kernel_time_fits(k_s * 1e3, launches, steps, dt / steps * 1e3)
+        fits = kernel_time_fits(k_s * 1e3, launches, k_steps, k_step_ms)
         if not fits:
-            print(f"# {kernel_name}: {launches} launches x {k_s * 1e3:.3f} ms do not fit {steps} steps of {dt / steps * 1e3:.3f} ms: kernel figure invalid", file=sys.stderr)
-        return {"value": round(n_bases * steps / dt / 1e9, 2), "unit": "Gbp/s", "bases": n_bases, "steps": steps, "ms_per_step": round(dt / steps * 1e3, 3),
-                "kernel": kernel_name, "avg_kernel_ms": round(k_s * 1e3, 4), "launches_timed": launches, "lanes": lanes if lanes is not None else args.lanes,
-                "kernel_ms_per_step": round(k_s * 1e3 * launches / steps, 3), "kernel_time_fits_step": fits,
+            print(f"# {kernel_name}: {launches} launches x {k_s * 1e3:.3f} ms do not fit {k_steps} step(s) of {k_step_ms:.3f} ms: kernel figure invalid", file=sys.stderr)
+        return {"value": round(n_bases * steps / dt / 1e9, 2), "unit": "Gbp/s", "bases": n_bases, "steps": steps, "ms_per_step": round(dt / steps * 1e3, 3), "lanes": args.lanes,
+                "kernel": kernel_name, "avg_kernel_ms": round(k_s * 1e3, 4), "launches_timed": launches, "kernel_timed_on_lanes": kernel_lanes if kernel_lanes is not None else args.lanes,
+                "kernel_steps": k_steps, "kernel_ms_per_step": round(k_s * 1e3 * launches / k_steps, 3), "kernel_step_ms": round(k_step_ms, 3), "kernel_time_fits_step": fits,
                 "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5),
                              "valu": valu_ceiling(model, kernels, per_launch, dt / max(n_ranges, 1), ghz)}}
 
@@ -551,7 +560,7 @@ def other_configs(ctx, args, model):
             k += 1
         return k
 
-    res["C2_kmer_hash_10Gbp"] = timed(c2, n, ["c2_kmer"], "bl::kmer_kernel", lanes=1)
+    res["C2_kmer_hash_10Gbp"] = timed(c2, n, ["c2_kmer"], "bl::kmer_kernel", kernel_lanes=1)
     b.close()
 
     # C4 / C5: 50 Gbp of 10-kbp reads

@@ -877,6 +877,8 @@ int bl_scan_kmers(bl_ctx* c, const bl_batch* b, uint64_t first, uint64_t n, uint
     rc = begin_scan(c);
     if (rc != BL_OK) return rc;
     p.shards = c->shards();
+    // 2,048 workgroups striding over the tiles (1.6 resident sets at five workgroups per CU).  One resident set exactly — 1,280 — measured
+    // SLOWER on one lane (532 against 567 Gbp/s, A/B on one box) and the same on two (654): the 15 % a second lane gives this scan is not its tail.
     const int n_blocks = p.n_tiles < 256 * 8 ? p.n_tiles : 256 * 8;
     rc = kernel_event(c, true);
     if (rc != BL_OK) return rc;

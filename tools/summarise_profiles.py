@@ -29,7 +29,7 @@ bj = json.loads(line)
 per_launch = {"c3": bj["config"]["bases_per_launch"]}
 for cfg, key in (("c2", "C2_kmer_hash_10Gbp"), ("c4", "C4_super_kmers_50Gbp_10kbp_reads"), ("c5", "C5_syncmers_50Gbp_shard_10kbp_reads")):
     oc = bj["other_configs"][key]
-    per_launch[cfg] = oc["bases"] * oc["steps"] / oc["launches_timed"]
+    per_launch[cfg] = oc["bases"] * oc.get("kernel_steps", oc["steps"]) / oc["launches_timed"]
 BASES_OF = {"c3_count": per_launch["c3"], "c3_emit": per_launch["c3"], "c2_kmer": per_launch["c2"], "c4_count": per_launch["c4"], "c4_emit": per_launch["c4"],
             "c5_count": per_launch["c5"], "c5_emit": per_launch["c5"], "c3_redo": per_launch["c3"], "c5_redo": per_launch["c5"]}
 
