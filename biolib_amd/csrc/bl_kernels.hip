@@ -767,11 +767,11 @@ static hipError_t launch_count_mode(const ScanParams& p, GroupRange g, hipStream
         else hipLaunchKernelGGL((scan_count_kernel<MODE_SYNCMER, -16, 0, -1, 1>), grid, block, 0, stream, p, g);
         return hipGetLastError();
     }
-    if (MODE == MODE_MINIMIZER && p.w >= 2 && p.w <= 32) {
-        // minimizer scans: every window width up to 32 has its own kernel — van Herk / Gil-Werman on packed keys in registers, the
-        // element-centric decisions up to 16.  (The sparse-table kernels below, which take the width at run time, ran these widths at
-        // 220-340 Gbp/s where a width of its own gives 390-420; 27 more kernels cost the build 17 seconds.)
-        constexpr int MM = MODE_MINIMIZER;
+    if (MODE != MODE_SYNCMER && p.w >= 2 && p.w <= 32) {
+        // minimizer and super-k-mer scans: every window width up to 32 has its own kernel — van Herk / Gil-Werman on packed keys in
+        // registers, for minimizers the element-centric decisions up to 16.  (The sparse-table kernels below, which take the width at run
+        // time, ran these widths at 220-340 Gbp/s where a width of its own gives 340-420; 2 x 27 more kernels cost the build half a minute.)
+        constexpr int MM = MODE == MODE_SYNCMER ? MODE_MINIMIZER : MODE;  // never instantiated for syncmers
         switch (p.w) {
 #define BL_W(WV) case WV: hipLaunchKernelGGL((scan_count_kernel<MM, WV, 0, -1>), grid, block, 0, stream, p, g); return hipGetLastError();
             BL_W(2) BL_W(3) BL_W(4) BL_W(5) BL_W(6) BL_W(7) BL_W(8) BL_W(9) BL_W(10) BL_W(11) BL_W(12) BL_W(13) BL_W(14) BL_W(15) BL_W(16)
@@ -780,27 +780,19 @@ static hipError_t launch_count_mode(const ScanParams& p, GroupRange g, hipStream
 #undef BL_W
         }
     }
-    if (MODE != MODE_SYNCMER) {
-        // more window sizes in registers for the minimizer / super-k-mer scans: the widths of minimap2's presets
-        // (k15 w10, k19 w19, k15/k19 w5); every other width runs the sparse-table kernels (W < 0, 1.2-2x slower)
-        constexpr int M2 = MODE == MODE_SYNCMER ? MODE_MINIMIZER : MODE;  // never instantiated for syncmers
-        switch (p.w) {
-            case 5: hipLaunchKernelGGL((scan_count_kernel<M2, 5, 0, -1>), grid, block, 0, stream, p, g); return hipGetLastError();
-            case 10: hipLaunchKernelGGL((scan_count_kernel<M2, 10, 0, -1>), grid, block, 0, stream, p, g); return hipGetLastError();
-            case 19: hipLaunchKernelGGL((scan_count_kernel<M2, 19, 0, -1>), grid, block, 0, stream, p, g); return hipGetLastError();
-            default: break;
-        }
-    }
     switch (p.w) {
         case 1: hipLaunchKernelGGL((scan_count_kernel<MODE, 1, 0, -1>), grid, block, 0, stream, p, g); break;
         case 11: hipLaunchKernelGGL((scan_count_kernel<MODE, 11, 0, -1>), grid, block, 0, stream, p, g); break;
         case 17: hipLaunchKernelGGL((scan_count_kernel<MODE, 17, 0, -1>), grid, block, 0, stream, p, g); break;
         case 21: hipLaunchKernelGGL((scan_count_kernel<MODE, 21, 0, -1>), grid, block, 0, stream, p, g); break;
         default:
-            // runtime window size: sparse-table argmin in registers, one kernel per size group
-            if (p.w <= 16) hipLaunchKernelGGL((scan_count_kernel<MODE, -8, 0, -1>), grid, block, 0, stream, p, g);
-            else if (p.w <= 32) hipLaunchKernelGGL((scan_count_kernel<MODE, -16, 0, -1>), grid, block, 0, stream, p, g);
-            else hipLaunchKernelGGL((scan_count_kernel<MODE, -32, 0, -1>), grid, block, 0, stream, p, g);
+            // runtime window size: sparse-table argmin in registers, one kernel per size group (minimizer and super-k-mer scans come
+            // here with widths beyond 32 only)
+            if constexpr (MODE == MODE_SYNCMER) {
+                if (p.w <= 16) { hipLaunchKernelGGL((scan_count_kernel<MODE, -8, 0, -1>), grid, block, 0, stream, p, g); break; }
+                if (p.w <= 32) { hipLaunchKernelGGL((scan_count_kernel<MODE, -16, 0, -1>), grid, block, 0, stream, p, g); break; }
+            }
+            hipLaunchKernelGGL((scan_count_kernel<MODE, -32, 0, -1>), grid, block, 0, stream, p, g);
             break;
     }
     return hipGetLastError();

@@ -288,8 +288,9 @@ void run_mode(const ScanParams& p, unsigned long long* result)
         run_tiles<MODE_MINIMIZER, 11, 2>(p, result);
         return;
     }
-    if (MODE == MODE_MINIMIZER && p.w >= 2 && p.w <= 32) {  // a kernel per width (launch_count_mode)
-        constexpr int MM = MODE_MINIMIZER;
+    if (MODE == MODE_SUPERKMER && p.w == 17 && p.unit == 15 && p.canonical) { run_tiles<MODE_SUPERKMER, 17, 0, 15>(p, result); return; }  // the BASELINE C4 kernel
+    if (MODE != MODE_SYNCMER && p.w >= 2 && p.w <= 32) {  // a kernel per width (launch_count_mode)
+        constexpr int MM = MODE == MODE_SYNCMER ? MODE_MINIMIZER : MODE;
         switch (p.w) {
 #define BL_W(WV) case WV: run_tiles<MM, WV>(p, result); return;
             BL_W(2) BL_W(3) BL_W(4) BL_W(5) BL_W(6) BL_W(7) BL_W(8) BL_W(9) BL_W(10) BL_W(11) BL_W(12) BL_W(13) BL_W(14) BL_W(15) BL_W(16)

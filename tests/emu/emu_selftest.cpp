@@ -113,7 +113,12 @@ static void check_case(const Case& c, std::mt19937_64& rng)
 
     struct SK { unsigned k, m; uint64_t seed; int canon; };
     const SK sks[] = {{31, 15, 42, 1}, {21, 8, 0, 0}, {24, 15, 6, 1}, {27, 9, 7, 1}, {19, 15, 8, 0}, {31, 31, 5, 1}, {31, 21, 1, 1}, {21, 11, 2, 0}, {32, 1, 3, 1}, {40, 9, 4, 1}};
-    for (const SK& k : sks) {
+    std::vector<SK> sk_cases(sks, sks + sizeof(sks) / sizeof(sks[0]));
+    for (int extra = 0; extra < 2; ++extra) {  // every width from 2 to 32 has a kernel of its own in this mode too: two at random per case
+        const unsigned m = (unsigned)(1 + rng() % 32), w = (unsigned)(2 + rng() % 31);
+        sk_cases.push_back(SK{m + w - 1, m, rng() % 100, (int)(rng() % 2)});
+    }
+    for (const SK& k : sk_cases) {
         size_t cnt = blo_super_kmers(s, c.offsets.data(), n_seqs, k.k, k.m, k.seed, k.canon, ov.data(), of.data(), om.data(), os.data(),
                                      oh.data(), cap);
         emu_super_kmers(b, 0, 0, k.k, k.m, k.seed, k.canon ? 1 : 0, ev.data(), ef.data(), em.data(), es.data(), eh.data(), cap, res);
