@@ -455,3 +455,41 @@ def test_approximate_pass1_soak_ten_batches():
     assert bad == 0 and len(lines) == 20
     assert redone > 0
     assert all(d["count"] > 0 and d["status"] == 0 for d in lines)
+
+
+def test_context_options_and_marker_limits():
+    """round-4 ABI: bl_ctx_set_option (names the scan path used to read from the environment) and the bounds of the marker calls"""
+    import ctypes as C
+
+    import biolib_amd as B
+
+    c = B.Context(0, torch_stream=False)
+    lib = c._lib
+    L, n = 150, 150 * 30_000
+    b = c.synth(9, n, L)
+    ref = b.minimizers(31, 11, seed=42, canonical=True)
+    assert ref["count"] > 0
+    # every switch leaves the records alone
+    for name, value in (("position_tiled", 1), ("exact_windows", 1), ("lanes", 2), ("emit_lds_bytes", 40960), ("emit_lds_bytes", 0), ("lanes", 1),
+                        ("exact_windows", 0), ("position_tiled", 0)):
+        c.set_option(name, value)
+        got = b.minimizers(31, 11, seed=42, canonical=True)
+        assert got["count"] == ref["count"] and np.array_equal(got["positions"], ref["positions"]) and np.array_equal(got["hashes"], ref["hashes"]), (name, value)
+    # unknown names and values out of range are refused, with a message
+    for name, value in (("no_such_switch", 1), ("lanes", 3), ("exact_windows", 2), ("emit_lds_bytes", -1), ("emit_lds_bytes", 1 << 20)):
+        with pytest.raises(B.BiolibError) as e:
+            c.set_option(name, value)
+        assert e.value.code == -1  # BL_ERR_INVALID
+    # markers: a size query keeps them, a buffer too small is refused and keeps them, the 4,097th is refused
+    for _ in range(5):
+        c.mark()
+    k = C.c_uint32()
+    assert lib.bl_ctx_mark_times(c._h, None, 0, C.byref(k)) == 0 and k.value == 5
+    small = (C.c_double * 2)()
+    assert lib.bl_ctx_mark_times(c._h, small, 2, C.byref(k)) == -4 and k.value == 5  # BL_ERR_CAPACITY
+    assert len(c.mark_times()) == 5 and c.mark_times() == []
+    for _ in range(4096):
+        c.mark()
+    assert lib.bl_ctx_mark(c._h) == -4
+    assert len(c.mark_times()) == 4096
+    b.close(); c.close()
