@@ -20,6 +20,9 @@
 #ifndef BL_SKAX_WAVES
 #define BL_SKAX_WAVES 4  // ... and the BASELINE super-k-mer kernel that decides on murmur64_top
 #endif
+#ifndef BL_C4_WAVES
+#define BL_C4_WAVES 5  // ... and the BASELINE super-k-mer kernel (96 registers and two scratch accesses; at 4 — 97 registers — 1-2 % slower, A/B on one box)
+#endif
 #ifndef BL_CSRT_WAVES
 #define BL_CSRT_WAVES 3  // ... and the closed-syncmer kernels for a window count given at run time
 #endif
@@ -332,7 +335,7 @@ __device__ __forceinline__ void emit_tile(const ScanParams& p, uint32_t* codes, 
 // (constant shifts and masks in the roller, no strand selects).  U = 0 / C = -1: taken from the arguments.
 // SY: the syncmer form (count_tile): 1 = closed syncmers (offsets {0, W - 1}; phase_sync_closed), 2 = argmins with the exact form deferred
 template <int MODE, int W, int U, int C, int SY = 0>
-__global__ __launch_bounds__(TPB, (MODE == MODE_MINIMIZER && SY == 2 ? BL_POSAX_WAVES : MODE == MODE_SUPERKMER && SY == 2 ? BL_SKAX_WAVES : SY == 1 && W < 0 ? BL_CSRT_WAVES : SY == 1 ? BL_CS_WAVES : SY == 2 ? BL_SY2_WAVES : (MODE == MODE_SYNCMER && W > 0 ? BL_SY0_WAVES : MODE == MODE_SYNCMER || (MODE == MODE_SUPERKMER && W == -32) ? 2 : (W == -32 || (W < 0 && MODE == MODE_SUPERKMER) ? 3 : (W == -16 ? 5 : (W < 0 ? 4 : (W <= 11 ? 5 : 4))))))) void scan_count_kernel(const ScanParams pin, GroupRange g)
+__global__ __launch_bounds__(TPB, (MODE == MODE_MINIMIZER && SY == 2 ? BL_POSAX_WAVES : MODE == MODE_SUPERKMER && SY == 2 ? BL_SKAX_WAVES : SY == 1 && W < 0 ? BL_CSRT_WAVES : SY == 1 ? BL_CS_WAVES : SY == 2 ? BL_SY2_WAVES : (MODE == MODE_SYNCMER && W > 0 ? BL_SY0_WAVES : MODE == MODE_SYNCMER || (MODE == MODE_SUPERKMER && W == -32) ? 2 : (W == -32 || (W < 0 && MODE == MODE_SUPERKMER) ? 3 : (W == -16 ? 5 : (W < 0 ? 4 : (W <= 11 ? 5 : (MODE == MODE_SUPERKMER && W == 17 && U == 15 ? BL_C4_WAVES : 4)))))))) void scan_count_kernel(const ScanParams pin, GroupRange g)
 {
     __shared__ TileShared<MODE, W> sh;
     ScanParams p = pin;
