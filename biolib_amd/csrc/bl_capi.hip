@@ -58,7 +58,7 @@ struct Pending {
 
 }  // namespace
 
-// One execution lane: a stream plus the scratch its scans use.  With two lanes (bl_ctx_set_lanes / BL_LANES=2) and the
+// One execution lane: a stream plus the scratch its scans use.  With two lanes (bl_ctx_set_lanes) and the
 // context's own streams, consecutive asynchronous scans alternate between the lanes and are staggered by an event: a
 // scan's pass 1 starts when the previous scan's pass 1 has finished, i.e. beside that scan's pass 2.  Pass 1 is bound by
 // VALU issue and leaves HBM idle, pass 2 is bound by HBM writes: together they run at the VALU rate of their combined
@@ -86,12 +86,12 @@ struct bl_ctx {
     Lane lanes[2];
     Lane* cur = nullptr;               // lane of the scan being issued / issued last
     int next_lane = 0;
-    int n_lanes = 1;                   // 2: consecutive async scans alternate lanes, staggered (bl_ctx_set_lanes, env BL_LANES)
+    int n_lanes = 1;                   // 2: consecutive async scans alternate lanes, staggered (bl_ctx_set_lanes)
     // two-lane mode: LDS footprint pass-2 workgroups are padded to, which caps how many of them a CU holds beside the next scan's pass 1
     // (uncapped, the memory-bound record pass crowds the ALU-bound one out of the SIMDs: 214 Gbp/s at C3 in round 1).  0 = by mode
-    // (emit_lds_default); BL_EMIT_LDS overrides.  Swept on MI355X with the round-3 kernels — minimizers on 150-bp reads (pass 1 holds
+    // (emit_lds_default); bl_ctx_set_option("emit_lds_bytes") overrides.  Swept on MI355X with the round-3 kernels — minimizers on 150-bp reads (pass 1 holds
     // 12.4 KB per workgroup): 16 K -> 497, 22-26 K -> 517, 28 K -> 495, 40 K -> 460 Gbp/s; super-k-mers on 10-kbp reads (pass 1: 28.7 KB):
-    // 16 K -> 400, 24 K -> 383.
+    // 16 K -> 400, 24 K -> 383.  Round 4 (four-tile record kernel for minimizers): see scan_windows.
     uint32_t emit_lds_per_wg = 0;
     hipStream_t user_stream = nullptr; // borrowed (bl_ctx_set_stream); NULL while borrowed = the legacy default stream
     bool borrowed = false;             // scans run on user_stream instead of the lanes' own streams
@@ -966,7 +966,9 @@ static int scan_windows(int mode, bl_ctx* c, const bl_batch* b, uint64_t first, 
     if (rc != BL_OK) return rc;
     e = bl::launch_tile_scan(p, all, block_tot, carry, c->stream);
     if (e != hipSuccess) return fail(BL_ERR_HIP, std::string("tile_scan: ") + hipGetErrorString(e));
-    const uint32_t emit_lds_default = mode == bl::MODE_SUPERKMER ? 16384u : 24576u;
+    // (minimizer scans: 28 K since the record kernel takes four tiles per workgroup and carries 10 KB of its own — three of its workgroups per
+    // CU; never below round 3's form in three A/B sweeps of round 4, where 24 K was once 2.7 % below it: profiles/r04_ab_summary.txt)
+    const uint32_t emit_lds_default = mode == bl::MODE_SUPERKMER ? 16384u : 28672u;
     e = bl::launch_scan_emit(mode, p, all, c->stream, staggered ? (c->emit_lds_per_wg ? c->emit_lds_per_wg : emit_lds_default) : 0);  // pass 2
     if (e != hipSuccess) return fail(BL_ERR_HIP, std::string("scan_emit_kernel: ") + hipGetErrorString(e));
     return BL_OK;
