@@ -99,6 +99,64 @@ def kernel_time_fits(avg_kernel_ms, launches, steps, ms_per_step, slack=1.01):
     return avg_kernel_ms * launches / max(steps, 1) <= ms_per_step * slack
 
 
+class PowerSampler:
+    """The cards' hwmon sensors (power, shader clock) sampled every 50 ms beside the timed region — the headline scan sits on the card's
+    power limit, and the line should say what the limit was in THIS run.  The host's other cards show in hwmon too: the
+    summary is of the card that drew the most on average.  Never fatal: no sensors, no `power` object."""
+
+    def __init__(self, root="/sys/class/drm"):
+        import glob
+        import threading
+
+        self.cards = {}
+        for hw in glob.glob(os.path.join(root, "card*/device/hwmon/hwmon*")):
+            files = {n: os.path.join(hw, n) for n in ("power1_input", "power1_average", "power1_cap", "freq1_input") if os.path.exists(os.path.join(hw, n))}
+            if "power1_input" in files or "power1_average" in files:
+                self.cards[os.path.relpath(hw, root).split(os.sep)[0]] = files
+        self.samples = []
+        self.stop = False
+        self.thread = threading.Thread(target=self._loop, daemon=True) if self.cards else None
+
+    @staticmethod
+    def _read(path):
+        try:
+            with open(path) as f:
+                return int(f.read().strip())
+        except Exception:
+            return None
+
+    def _loop(self):
+        while not self.stop:
+            self.samples.append({c: {n: self._read(p) for n, p in files.items()} for c, files in self.cards.items()})
+            time.sleep(0.05)
+
+    def start(self):
+        if self.thread:
+            self.thread.start()
+        return self
+
+    def finish(self):
+        if not self.thread:
+            return None
+        self.stop = True
+        self.thread.join()
+        best, best_mean = None, -1.0
+        for c in self.cards:
+            v = [s[c].get("power1_input") or s[c].get("power1_average") for s in self.samples]
+            v = [x for x in v if x is not None]
+            if v and sum(v) / len(v) > best_mean:
+                best, best_mean = c, sum(v) / len(v)
+        if best is None or len(self.samples) < 3:
+            return None
+        pw = sorted(x for x in ((s[best].get("power1_input") or s[best].get("power1_average")) for s in self.samples) if x is not None)
+        fq = sorted(x for x in (s[best].get("freq1_input") for s in self.samples) if x is not None)
+        cap = next((s[best].get("power1_cap") for s in self.samples if s[best].get("power1_cap")), None)
+        q = lambda a, f: a[int(f * (len(a) - 1))] if a else None
+        return {"card": best, "samples": len(pw), "power_W": {"median": round(q(pw, 0.5) / 1e6), "p90": round(q(pw, 0.9) / 1e6), "max": round(pw[-1] / 1e6)},
+                "power_cap_W": round(cap / 1e6) if cap else None, "sensor_clock_MHz": {"median": round(q(fq, 0.5) / 1e6), "p10": round(q(fq, 0.1) / 1e6)} if fq else None,
+                "note": "hwmon of the busiest card, every 50 ms over the timed region (steps shorter than a few samples say little)"}
+
+
 def free_port():
     import socket
 
@@ -261,6 +319,12 @@ def main():
     # shader clock over the timed region: one sleeping wave on its own stream, started with the region and stopped at its end
     # (before the barrier's device-wide synchronise, which would otherwise wait for it); the duration is only an upper bound
     probe = None if os.environ.get("BL_NO_CLOCK_PROBE") else ctx.clock_probe_start(5000)  # (switch: A/B runs under a profiler)
+    sampler = None
+    if rank == 0 and world == 1:
+        try:
+            sampler = PowerSampler().start()
+        except Exception:
+            sampler = None
     t0 = time.perf_counter()
     all_res = []
     ctx.mark()  # markers on the device's timeline behind every step: per-step times without a sync between the steps
@@ -271,6 +335,12 @@ def main():
     clock_ghz = ctx.clock_probe_finish(probe) if probe is not None else 2.4
     barrier()
     elapsed = time.perf_counter() - t0
+    power = None
+    if sampler is not None:
+        try:
+            power = sampler.finish()
+        except Exception:
+            power = None
     marks = ctx.mark_times()
     step_ms = [b - a for a, b in zip(marks[:-1], marks[1:])]
     kernel_ms, launches = ctx.kernel_time()
@@ -395,6 +465,8 @@ def main():
         out["roofline"]["valu"] = valu_ceiling(model, ["c3_count", "c3_emit"], bases_per_launch, range_s, clock_ghz)
         if hbm_actual is not None:
             out["roofline"]["hbm_actual"] = hbm_actual
+        if power is not None:
+            out["power"] = power
         if n_gpus == 1:
             try:
                 rd, cp = ctx.probe_hbm(8 << 30, 5)

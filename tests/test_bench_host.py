@@ -92,3 +92,21 @@ def test_kernel_time_must_fit_the_step_it_ran_in():
     assert not bench.kernel_time_fits(4.4005, 14, 2, 16.0)
     assert bench.kernel_time_fits(2.585, 14, 2, 18.2)
     assert bench.kernel_time_fits(2.9389, 34 * 20, 20, 101.6)
+
+
+def test_power_sampler_reports_the_busiest_card(tmp_path):
+    """the bench line's `power` object: hwmon sensors of every card are sampled, the summary is of the one that draws the most"""
+    import time
+
+    for card, (power, freq) in {"card0": (250_000_000, 150_000_000), "card8": (1_270_000_000, 2_080_000_000)}.items():
+        d = tmp_path / card / "device" / "hwmon" / "hwmon3"
+        d.mkdir(parents=True)
+        (d / "power1_input").write_text(str(power))
+        (d / "power1_cap").write_text("1400000000")
+        (d / "freq1_input").write_text(str(freq))
+    s = bench.PowerSampler(str(tmp_path)).start()
+    time.sleep(0.3)
+    out = s.finish()
+    assert out["card"] == "card8" and out["power_W"] == {"median": 1270, "p90": 1270, "max": 1270} and out["power_cap_W"] == 1400
+    assert out["sensor_clock_MHz"]["median"] == 2080 and out["samples"] >= 3
+    assert bench.PowerSampler(str(tmp_path / "nothing_here")).start().finish() is None

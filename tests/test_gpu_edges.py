@@ -493,3 +493,72 @@ def test_context_options_and_marker_limits():
     assert lib.bl_ctx_mark(c._h) == -4
     assert len(c.mark_times()) == 4096
     b.close(); c.close()
+
+
+@pytest.mark.parametrize("case", ["reads151_minimizers", "reads10k_minimizers", "closed_syncmers_25_12", "super_kmers_31_9"])
+def test_round4_kernels_at_size(case):
+    """the kernels round 4 added, at sizes the oracle cannot follow whole: 20 Gbp each, scanned in two different cuttings (which must
+    agree on count and on every digest: ranges compose exactly), once more with bl_ctx_set_exact_windows where the default decides on an
+    approximation (same digests), a closed-form density, and the first 64 Mbp against the oracle record for record.
+      reads151_minimizers     (31, 11) on 151-bp reads: read-tiled murmur64_top kernel with 16 units per lane
+      reads10k_minimizers     (31, 11) on 10-kbp reads: position-tiled murmur64_top kernel + scan_redo_kernel
+      closed_syncmers_25_12   closed syncmers with the width at run time, ties decided per k-mer in the kernel
+      super_kmers_31_9        w = 23: one of the per-width kernels of the super-k-mer scan"""
+    import biolib_amd as B
+
+    c = B.Context(0, torch_stream=False, lanes=2)
+    L = 151 if case == "reads151_minimizers" else 10_000
+    n_reads = 20_000_000_000 // L
+    n = n_reads * L
+    b = c.synth(4242, n, L)
+    cap = 420_000_000
+    bufs = [tuple(c.empty_u64(cap) for _ in range(3)) for _ in range(2)]
+    u8s = [tuple(c.empty_u8(cap) for _ in range(2)) for _ in range(2)] if case == "super_kmers_31_9" else None
+    flags = B.FLAG_CANONICAL
+
+    def one(i, first, m):
+        v, p, h = bufs[i & 1]
+        if case.endswith("minimizers"):
+            return b.minimizers_raw(31, 11, 42, flags, first=first, n=m, values=v, positions=p, hashes=h, capacity=cap)
+        if case == "closed_syncmers_25_12":
+            return b.syncmers_raw(25, 12, 0, 13, 0, flags, first=first, n=m, positions=p, capacity=cap)
+        mp, sz = u8s[i & 1]
+        return b.super_kmers_raw(31, 9, 42, flags, first=first, n=m, minimizers=v, first_pos=p, mm_pos=mp, sizes=sz, hashes=h, capacity=cap)
+
+    def scan(reads_per_range):
+        res = [one(i, a * L, min(reads_per_range, n_reads - a) * L) for i, a in enumerate(range(0, n_reads, reads_per_range))]
+        c.sync()
+        return _fold(res)
+
+    per = 1_900_000_000 // L
+    a = scan(per)
+    d = scan(per * 2 // 3 + 1)
+    assert a == d, (a, d)
+    if case != "super_kmers_31_9":  # (that kernel decides on the hashes themselves already)
+        c.set_exact_windows(True)
+        e = scan(per)
+        c.set_exact_windows(False)
+        assert e[:4] == a[:4]
+    if case.endswith("minimizers"):
+        assert abs(a[0] / (n_reads * (L - 41 + 1)) - 2 / 12) < 0.01
+    elif case == "closed_syncmers_25_12":
+        assert abs(a[0] / (n_reads * (L - 25 + 1)) - 2 / 14) < 0.01   # closed syncmers: 2 / (k - s + 1) of the k-mers
+    else:
+        assert a[0] == a[4] and abs(a[0] / (n_reads * (L - 31 + 1)) - 2 / 24) < 0.005
+    s = 64_000_000 // L * L
+    seq = b.download(0, s)
+    offs = O.fixed_offsets(s, L)
+    if case.endswith("minimizers"):
+        ev, ep, eh = O.minimizers(seq, offs, 31, 11, 42, True, brute=False)
+        g = b.minimizers(31, 11, seed=42, canonical=True, first=0, n=s)
+        assert g["count"] == len(ev) and np.array_equal(g["positions"], ep) and np.array_equal(g["hashes"], eh) and np.array_equal(g["values"], ev)
+    elif case == "closed_syncmers_25_12":
+        cnt, pos = O.syncmers(seq, offs, 25, 12, 0, 13, True, threads=_cores())
+        g = b.syncmers(25, 12, 0, 13, canonical=True, first=0, n=s)
+        assert g["count"] == cnt and np.array_equal(g["positions"], pos)
+    else:
+        mn, fp, mp, sz, hs = O.super_kmers(seq, offs, 31, 9, 42, True)
+        g = b.super_kmers(31, 9, seed=42, canonical=True, first=0, n=s)
+        assert g["count"] == len(mn) and np.array_equal(g["first_pos"], fp) and np.array_equal(g["sizes"], sz) and np.array_equal(g["mm_pos"], mp) and np.array_equal(g["hashes"], hs)
+    b.close()
+    c.close()
