@@ -5,7 +5,7 @@ Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it
 torch.distributed.run with one rank per GPU.  A step = one pass of the fused minimizer scan
 (bl_scan_minimizers, canonical 31-mers, window 11, seed 42) over this rank's whole shard
 (BASELINE.json configs[2]: 50 Gbp of 150-bp reads per GPU, synthetic, resident in HBM before the
-timed region), issued as consecutive <= 1.5 Gbp ranges whose records (value, position, hash) are
+timed region), issued as consecutive <= 0.75 Gbp ranges whose records (value, position, hash) are
 materialised into HBM output arrays.  Shards are independent (weak scaling, no data-path collective);
 the only collective is the optional count reduction, done after the timed region over RCCL.
 
@@ -217,7 +217,10 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--gbp", type=float, default=50.0, help="Gbp per GPU (BASELINE config: 50)")
-    ap.add_argument("--chunk-reads", type=int, default=10_000_000, help="reads per scan range (<= 2^31 bases)")
+    ap.add_argument("--chunk-reads", type=int, default=5_000_000,
+                    help="reads per scan range (<= 2^31 bases).  5 M reads = 0.75 Gbp: the scratch between the two passes of a range (0.5 B/base) and the lane's "
+                         "reuse of it stay closer to the 256 MB Infinity Cache — 525-527 Gbp/s against 512-515 with ranges of 1.5 Gbp, three rounds on one box "
+                         "(profiles/r04_ab_summary.txt); below 2.5 M reads the launches show")
     ap.add_argument("--lanes", type=int, default=2, choices=(1, 2),
                     help="execution lanes of the context: 2 = the record pass of one range runs beside the hashing pass of the next")
     ap.add_argument("--no-cpu-baseline", action="store_true")

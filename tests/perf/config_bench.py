@@ -12,8 +12,8 @@ import oracle_lib as O
 gbp = float(sys.argv[1]) if len(sys.argv) > 1 else 12.0
 lanes = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 ctx = B.Context(0, torch_stream=False, lanes=lanes)
-out = {"lanes": lanes}
-CH = 1_500_000_000
+CH = int(float(sys.argv[3]) * 1e9) if len(sys.argv) > 3 else 1_500_000_000  # bases per scan range
+out = {"lanes": lanes, "range_Gbp": CH / 1e9}
 
 def timed(fn, n_bases, reps=3):
     fn(); ctx.sync()
