@@ -218,9 +218,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--gbp", type=float, default=50.0, help="Gbp per GPU (BASELINE config: 50)")
     ap.add_argument("--chunk-reads", type=int, default=5_000_000,
-                    help="reads per scan range (<= 2^31 bases).  5 M reads = 0.75 Gbp: the scratch between the two passes of a range (0.5 B/base) and the lane's "
-                         "reuse of it stay closer to the 256 MB Infinity Cache — 525-527 Gbp/s against 512-515 with ranges of 1.5 Gbp, three rounds on one box "
-                         "(profiles/r04_ab_summary.txt); below 2.5 M reads the launches show")
+                    help="reads per scan range (<= 2^31 bases).  5 M reads = 0.75 Gbp: 525-527 Gbp/s against 512-515 with ranges of 1.5 Gbp, three rounds on one box, "
+                         "the card drawing 1,370 instead of 1,310 W (profiles/r04_ab_summary.txt, DESIGN.md section 6.3); below 2.5 M reads the launches show")
     ap.add_argument("--lanes", type=int, default=2, choices=(1, 2),
                     help="execution lanes of the context: 2 = the record pass of one range runs beside the hashing pass of the next")
     ap.add_argument("--no-cpu-baseline", action="store_true")
