@@ -381,6 +381,11 @@ def test_random_parameters_vs_oracle(ctx):
         cnt, pos = O.syncmers(seq, offs, kk, s, a, e, canon, drop_last=drop)
         gs = b.syncmers(kk, s, a, e, canonical=canon, drop_last=drop)
         assert gs["count"] == cnt and np.array_equal(gs["positions"], pos), (it, flavour, n, kk, s, a, e, canon, drop)
+        # the closed shape of the same (k, s) — offsets {0, k - s}, either way round: the run-time width kernels with ties decided per k-mer
+        a, e = (0, kk - s) if rng.integers(2) else (kk - s, 0)
+        cnt, pos = O.syncmers(seq, offs, kk, s, a, e, canon, drop_last=drop)
+        gs = b.syncmers(kk, s, a, e, canonical=canon, drop_last=drop)
+        assert gs["count"] == cnt and np.array_equal(gs["positions"], pos), (it, flavour, n, kk, s, a, e, canon, drop, "closed")
         b.close()
 
 
