@@ -95,6 +95,8 @@ int bl_ctx_sync(bl_ctx* ctx);
 /* Execution lanes of a context that runs on its own streams: with n = 2 consecutive asynchronous scans alternate between two
  * streams, staggered so that the record pass of one scan runs beside the hashing pass of the next (+12 % on MI355X).  Scans in
  * flight together must not share output arrays.  n = 1 (default) keeps scans strictly ordered.  Ignored on a borrowed stream. */
+/* (Measured on MI355X: a stream of minimizer scans with records runs fastest in ranges of 0.5-1 Gbp — 525-535 Gbp/s with two lanes, 2-2.5 %
+ * above ranges of 1.5 Gbp; below 0.3 Gbp the per-scan launches show.  Consecutive scans must not share output arrays: double-buffer them.) */
 int bl_ctx_set_lanes(bl_ctx* ctx, int n);
 
 /* ---- batches (device-resident sequences) -------------------------------------------------------- */
