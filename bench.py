@@ -225,6 +225,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true")
     ap.add_argument("--no-next-rows", action="store_true")
+    ap.add_argument("--no-other-shapes", action="store_true", help="skip the 151-bp companion of the headline in other_configs (the PMC passes of tools/collect_profiles.sh: "
+                                                                   "its record kernel is the headline's, and a counter mean should belong to one workload)")
     ap.add_argument("--no-h2d", action="store_true", help="skip the upload-inclusive companion figure")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
                     help="context switch for A/B runs (bl_ctx_set_option: exact_windows, position_tiled, emit_lds_bytes); repeatable; named in the JSON line")
@@ -621,7 +623,7 @@ def other_configs(ctx, args, model):
                 "kernel": kernel_name, "avg_kernel_ms": round(k_s * 1e3, 4), "launches_timed": launches, "kernel_timed_on_lanes": kernel_lanes if kernel_lanes is not None else args.lanes,
                 "kernel_steps": k_steps, "kernel_ms_per_step": round(k_s * 1e3 * launches / k_steps, 3), "kernel_step_ms": round(k_step_ms, 3), "kernel_time_fits_step": fits,
                 "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5),
-                             "valu": valu_ceiling(model, kernels, per_launch, dt / max(n_ranges, 1), ghz)}}
+                             **({"valu": valu_ceiling(model, kernels, per_launch, dt / max(n_ranges, 1), ghz)} if kernels else {"shader_clock_GHz": round(ghz, 3)})}}
 
     # C2: canonical 31-mer 2-bit encode + hash64 digest over 10 Gbp, one sequence (digest only: 80 GB of hashes are not materialised)
     n = int((args.other_gbp or 10.0) * 1e9)
@@ -636,6 +638,28 @@ def other_configs(ctx, args, model):
 
     res["C2_kmer_hash_10Gbp"] = timed(c2, n, ["c2_kmer"], "bl::kmer_kernel", kernel_lanes=1)
     b.close()
+
+    # beside the headline shape: the same scan on 151-bp reads (what current sequencers write) — the read-tiled murmur64_top kernel with the read
+    # geometry at run time (16 units per lane); same call pattern as the headline (ranges of 5 M reads, records materialised)
+    if not args.no_other_shapes:
+        L = 151
+        n = int((args.other_gbp or 50.0) * 1e9) // L * L
+        b = ctx.synth(SEED, n, L)
+        chunk = 5_000_000 * L
+        cap3 = int(chunk * 2.25 / (W + 1)) + 65536
+        bufs = [(ctx.empty_u64(cap3), ctx.empty_u64(cap3), ctx.empty_u64(cap3)) for _ in range(2)]
+
+        def c3b():
+            k = 0
+            for i, a in enumerate(range(0, n, chunk)):
+                v, p, h = bufs[i & 1]
+                b.minimizers_raw(UNIT, W, SEED, B.FLAG_CANONICAL, first=a, n=min(chunk, n - a), values=v, positions=p, hashes=h, capacity=cap3)
+                k += 1
+            return k
+
+        res["C3_shape_on_151bp_reads_50Gbp"] = timed(c3b, n, [], "bl::scan_count_frl_kernel<MODE_MINIMIZER,W=11,NS=16,U=31,L=run time,C=1,APPROX> + scan_redo_frl_kernel")
+        b.close()
+        del bufs
 
     # C4 / C5: 50 Gbp of 10-kbp reads
     L = 10_000

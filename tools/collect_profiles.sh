@@ -18,7 +18,7 @@ cd /tmp && export TMPDIR=/tmp
 $ROOT/tools/_build/ubench_valu --json $OUT/ubench_valu.json > $OUT/ubench_valu.txt 2>&1 || exit 1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_lanes2 -o s -- python3 $ROOT/bench.py --no-cpu-baseline --no-next-rows --no-h2d > $OUT/stats_lanes2.log 2>&1 || exit 1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_lanes1 -o s -- python3 $ROOT/bench.py --lanes 1 --no-cpu-baseline --no-next-rows --no-h2d > $OUT/stats_lanes1.log 2>&1 || exit 1
-PMC_CMD="python3 $ROOT/bench.py --steps 1 --warmup 0 --lanes 1 --no-cpu-baseline --no-next-rows --no-h2d"
+PMC_CMD="python3 $ROOT/bench.py --steps 1 --warmup 0 --lanes 1 --no-cpu-baseline --no-next-rows --no-h2d --no-other-shapes"
 echo "$PMC_CMD" > $OUT/pmc_command.txt
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o p -- $PMC_CMD > $OUT/pmc_fetch.log 2>&1 || exit 1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o p -- $PMC_CMD > $OUT/pmc_write.log 2>&1 || exit 1
