@@ -968,7 +968,9 @@ static int scan_windows(int mode, bl_ctx* c, const bl_batch* b, uint64_t first, 
     if (e != hipSuccess) return fail(BL_ERR_HIP, std::string("tile_scan: ") + hipGetErrorString(e));
     // (minimizer scans: 28 K since the record kernel takes four tiles per workgroup and carries 10 KB of its own — three of its workgroups per
     // CU; never below round 3's form in three A/B sweeps of round 4, where 24 K was once 2.7 % below it: profiles/r04_ab_summary.txt)
-    const uint32_t emit_lds_default = mode == bl::MODE_SUPERKMER ? 16384u : 28672u;
+    // (super-k-mer scans: 8 K since their pass 1 is compiled for five waves per SIMD and holds 5 x 28.7 KB of a CU's 160: 393 / 396 / 394 / 390 / 382 Gbp/s
+    // at 4 / 8 / 12 / 16 / 24 K on one box, C4 at 24 Gbp)
+    const uint32_t emit_lds_default = mode == bl::MODE_SUPERKMER ? 8192u : 28672u;
     e = bl::launch_scan_emit(mode, p, all, c->stream, staggered ? (c->emit_lds_per_wg ? c->emit_lds_per_wg : emit_lds_default) : 0);  // pass 2
     if (e != hipSuccess) return fail(BL_ERR_HIP, std::string("scan_emit_kernel: ") + hipGetErrorString(e));
     return BL_OK;

@@ -14,6 +14,9 @@ lanes = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 ctx = B.Context(0, torch_stream=False, lanes=lanes)
 CH = int(float(sys.argv[3]) * 1e9) if len(sys.argv) > 3 else 1_500_000_000  # bases per scan range
 out = {"lanes": lanes, "range_Gbp": CH / 1e9}
+if len(sys.argv) > 4:  # LDS footprint the record pass is padded to beside the next hashing pass (bl_ctx_set_option)
+    ctx.set_option("emit_lds_bytes", int(sys.argv[4]))
+    out["emit_lds_bytes"] = int(sys.argv[4])
 
 def timed(fn, n_bases, reps=3):
     fn(); ctx.sync()
